@@ -1,0 +1,161 @@
+"""Drive the *unmodified* Python reference and emit canonical tick records.
+
+Works ONLY in the build container (needs /root/reference). Nothing here is copied
+from the reference: it is imported read-only and driven through its public surface
+(`TrafficInteraction(...)`, `.step`, `.scene_update`, `.delete_vehicle`, `veh_info`).
+
+Crash guard: the reference's diagnostics loop at
+traffic_interaction_scene.py:371-375 raises IndexError when lane 0 is empty and
+`virtual_lane_4[0]` still holds stale indices. Just for the duration of the
+`scene_update()` call we substitute a list subclass that iterates as empty (len()/[0]
+unchanged, so `step` :1517 sees the real content), and restore the plain list after.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF_DIR = "/root/reference"
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+from oracle.record import VEH_I_COLS, VEH_F_COLS  # noqa: E402
+
+
+def reference_available():
+    return os.path.isfile(os.path.join(REF_DIR, "traffic_interaction_scene.py"))
+
+
+def import_reference():
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    if REF_DIR not in sys.path:
+        sys.path.insert(0, REF_DIR)
+    import traffic_interaction_scene as tis  # noqa
+    if not tis.__file__.startswith(REF_DIR):
+        raise RuntimeError("wrong traffic_interaction_scene imported: %s" % tis.__file__)
+    return tis
+
+
+def load_stream(name):
+    import scipy.io as scio
+    path = os.path.join(REF_DIR, "data", "test", "arvTimeNewVeh_new_%s_12.mat" % name)
+    return np.ascontiguousarray(scio.loadmat(path)["arvTimeNewVeh"], dtype=np.float64)
+
+
+class _SilentIter(list):
+    def __iter__(self):
+        return iter(())
+
+
+def default_args():
+    return types.SimpleNamespace(collision_thr=2, o_agent_num=6, c_mode="closer")
+
+
+class RefRunner:
+    """One reference env + a policy; `tick()` performs one caller-protocol tick and returns
+    the canonical record (snapshot before delete_vehicle) and then compacts."""
+
+    def __init__(self, arrive_time, policy, want_state=False, **ctor_kw):
+        tis = import_reference()
+        self.env = tis.TrafficInteraction(arrive_time, 150, default_args(), show_col=False,
+                                          virtual_l=True, lane_num=12, **ctor_kw)
+        self.policy = policy
+        self.want_state = want_state
+        self.tick_no = 0
+        self.guard_hits = 0
+        self.tape = []          # actions fed this tick, (lane, j) order, all alive vehicles
+        self._nbr_log = []
+        env = self.env
+        orig = env.virtual_lane_search_closer
+
+        def spy(i, j, vl4, mode="front", veh_num=3):
+            orig(i, j, vl4, mode=mode, veh_num=veh_num)
+            self._nbr_log.append([list(c) for c in env.closer_cars])
+        env.virtual_lane_search_closer = spy
+
+    def alive_view(self):
+        env = self.env
+        ids, ctl, obs = [], [], []
+        for lane in range(12):
+            for veh in env.veh_info[lane]:
+                ids.append(veh["id_info"][0])
+                ctl.append(1 if veh["control"] else 0)
+                obs.append(np.asarray(veh["state"][0], np.float64))
+        return np.array(ids, np.int64), np.array(ctl, np.int32), \
+            (np.stack(obs) if obs else np.zeros((0, 28)))
+
+    def tick(self, actions=None):
+        env = self.env
+        veh_id, ctl, obs0 = self.alive_view()
+        if actions is None:
+            actions = self.policy(self.tick_no, veh_id, ctl, obs0)
+        actions = np.asarray(actions, np.float64)
+        self.tape = actions
+        k = 0
+        for lane in range(12):
+            for ind, veh in enumerate(env.veh_info[lane]):
+                a = float(actions[k]) if veh["control"] else 0
+                env.step(lane, ind, a)
+                k += 1
+        self._nbr_log.clear()
+        guarded = False
+        plain = None
+        if len(env.veh_info[0]) == 0 and len(env.virtual_lane_4[0]) > 0:
+            plain = env.virtual_lane_4[0]
+            env.virtual_lane_4[0] = _SilentIter(plain)
+            guarded = True
+            self.guard_hits += 1
+        try:
+            out = env.scene_update()
+        finally:
+            if guarded:
+                # lane 0 was empty so scene_update did not rebuild it (:234): put the plain list back
+                env.virtual_lane_4[0] = plain
+        rec = self._snapshot(out)
+        env.delete_vehicle()
+        self.tick_no += 1
+        return rec
+
+    def _snapshot(self, out):
+        env = self.env
+        ids, re_state, reward, actions, collisions, _estm, cpv, jerks, lock = out
+        C = len(ids)
+        rec = dict(tick=self.tick_no, time=float(env.current_time))
+        rec["ids"] = np.array(ids, np.int32).reshape(C, 2)
+        rec["nbr"] = np.array(self._nbr_log, np.int32).reshape(C, 6, 2)
+        rec["reward"] = np.array([float(r) for r in reward], np.float64)
+        st = np.array(re_state, np.float64).reshape(C, 7, 28)
+        rec["obs0"] = np.ascontiguousarray(st[:, 0, :])
+        rec["state"] = st if self.want_state else None
+        rec["act7"] = np.array(actions, np.float64).reshape(C, 7) if self.want_state else None
+        rec["coll_pv"] = np.array([c[0] for c in cpv], np.int32)
+        rec["collisions"] = int(collisions)
+        rec["lock"] = int(lock)
+        rec["jerks"] = np.array([float(x) for x in jerks], np.float64)
+        rec["deleted"] = np.array(env.delete_veh, np.int32).reshape(len(env.delete_veh), 2)
+        vi, vf = [], []
+        for lane in range(12):
+            for j, v in enumerate(env.veh_info[lane]):
+                d = dict(lane=lane, j=j, id=v["id_info"][0], seq=v["seq_in_lane"], vnum=v["id_info"][1],
+                         control=int(bool(v["control"])), finish=int(bool(v["finish"])),
+                         done=int(bool(v["Done"])), collision=int(v["collision"]), step=int(v["step"]),
+                         count=int(v["count"]), lock=int(bool(v["lock"])), lock_a=int(v["lock_a"]),
+                         hdr_lane=int(v["vir_header"][0]), hdr_j=int(v["vir_header"][1]))
+                vi.append([d[c] for c in VEH_I_COLS])
+                vf.append([float(v[c]) for c in VEH_F_COLS])
+        rec["veh_i"] = np.array(vi, np.int32).reshape(len(vi), len(VEH_I_COLS))
+        rec["veh_f"] = np.array(vf, np.float64).reshape(len(vf), len(VEH_F_COLS))
+        rec["id_seq"] = int(env.id_seq)
+        rec["passed"] = int(env.passed_veh)
+        rec["passed_step_total"] = int(env.passed_veh_step_total)
+        rec["veh_num"] = np.array(env.veh_num, np.int32)
+        rec["veh_rec"] = np.array(env.veh_rec, np.int32)
+        heads = np.zeros((12, 3), np.int32)
+        for d in range(12):
+            vl = env.virtual_lane_4[d]
+            if len(vl) > 0:
+                heads[d] = (1, vl[0][1], vl[0][2])
+            else:
+                heads[d] = (0, -1, -1)
+        rec["heads"] = heads
+        return rec

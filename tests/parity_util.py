@@ -1,0 +1,71 @@
+"""Shared helpers for the parity tests: golden-case loading, digest checks, replay loops."""
+import json
+import os
+
+import numpy as np
+
+from oracle.record import (DIGEST_F_COLS, DIGEST_I_COLS, compare_records, digest, get_policy)
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASE_NAMES = ["s1000_zero", "s1000_sin1", "s200_sin1", "s1200_sin1", "s1200_zero", "s400_sin2",
+              "s1000_sin3", "s1000_sin1_vm6"]
+DENSE_FIELDS = ("ids", "nbr", "reward", "obs0", "coll_pv", "deleted", "jerks", "veh_i", "veh_f",
+                "heads", "veh_num", "veh_rec")
+
+
+class GoldenCase:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.meta = json.loads(str(self.z["meta"]))
+        self.arrive = np.ascontiguousarray(self.z["arrive"], np.float64)
+        self.dig_i = self.z["dig_i"]
+        self.dig_f = self.z["dig_f"]
+        self.ticks = int(self.meta["ticks"])
+        self.ctor = dict(self.meta["ctor"])
+        self.policy = get_policy(self.meta["policy"])
+        self.dense_ticks = set(int(t) for t in self.z["dense_ticks"])
+        self.state_ticks = set(int(t) for t in self.z["state_ticks"])
+
+    def dense_record(self, t):
+        z = self.z
+        rec = {f: z["t%d_%s" % (t, f)] for f in DENSE_FIELDS}
+        sc = z["t%d_scalars" % t]
+        rec.update(tick=t, time=float(z["t%d_time" % t]), collisions=int(sc[0]), lock=int(sc[1]),
+                   id_seq=int(sc[2]), passed=int(sc[3]), passed_step_total=int(sc[4]))
+        if t in self.state_ticks:
+            rec["state"] = z["t%d_state" % t]
+            rec["act7"] = z["t%d_act7" % t]
+        else:
+            rec["state"] = None
+            rec["act7"] = None
+        return rec
+
+
+def check_against_golden(case, t, rec, ftol=1e-9, dtol=1e-9):
+    """Digest check on every tick (ints + CRC exact, float sums within ftol relative-to-scale) and a
+    field-by-field check on the dense ticks."""
+    di, df = digest(rec)
+    gi, gf = case.dig_i[t], case.dig_f[t]
+    for k, col in enumerate(DIGEST_I_COLS):
+        assert int(di[k]) == int(gi[k]), "%s tick %d: digest int %s: %d vs golden %d" % (
+            case.name, t, col, di[k], gi[k])
+    for k, col in enumerate(DIGEST_F_COLS):
+        scale = max(1.0, abs(gf[k]))
+        if col in ("sum_obs0",):
+            scale = max(scale, abs(gf[DIGEST_F_COLS.index("sum_abs_obs0")]))
+        assert abs(df[k] - gf[k]) <= ftol * scale, "%s tick %d: digest float %s: %r vs golden %r" % (
+            case.name, t, col, df[k], gf[k])
+    if t in case.dense_ticks:
+        compare_records(case.dense_record(t), rec, tol=dtol, label=case.name + "/dense")
+
+
+def replay_case(case, env, ticks=None, ftol=1e-9, dtol=1e-9, want_state=True):
+    """env: object with alive_view() -> (ids, ctl, obs0) and tick(actions, want_state) -> record."""
+    n = case.ticks if ticks is None else min(ticks, case.ticks)
+    for t in range(n):
+        vid, ctl, obs0 = env.alive_view()
+        acts = case.policy(t, vid, ctl, obs0)
+        rec = env.tick(acts, want_state=(want_state and t in case.state_ticks))
+        check_against_golden(case, t, rec, ftol, dtol)
+    return n
