@@ -1,0 +1,175 @@
+/*
+ * pve_env.h -- C ABI of libpveenv.so: the MI355X-native batched unsignalised-intersection
+ * environment (drop-in for the hot path of Mingtzge/PVE-MCC_for_unsignalized_intersection).
+ *
+ * The reference has no FFI / plugin interface: its boundary is the Python object surface of
+ * `TrafficInteraction` that main.py touches.  Each entry point below names the
+ * reference call it replaces ("ref :N" = traffic_interaction_scene.py line N).  The Python host
+ * mirror (pve-mcc_for_unsignalized_intersection_amd/traffic_interaction_scene.py and batched.py)
+ * binds exactly these symbols through ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types: device buffers are `void*` device addresses, the stream is a
+ *     `void*` holding a hipStream_t (NULL = default stream).
+ *   - every function returns PVE_OK (0) or a negative error code; pve_last_error() gives the text.
+ *   - all per-vehicle device buffers are caller-allocated, laid out [n_envs][capacity] (row-major),
+ *     "slot" = rank of the vehicle in (lane, j) order inside its environment.
+ *   - calls on one handle are asynchronous on the handle's stream and must not be issued
+ *     concurrently from several host threads.
+ */
+#ifndef PVE_ENV_H
+#define PVE_ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVE_ABI_VERSION 1
+#define PVE_LANES 12
+#define PVE_OBS_WIDTH 28      /* (o_agent_num + 1) * 4, ref :1295 */
+#define PVE_NBR 6             /* ref :1324 hard-codes 6 neighbours */
+#define PVE_STATE_ROWS 7
+#define PVE_N_METRICS 12
+
+enum {
+    PVE_OK = 0,
+    PVE_ERR_INVALID = -1,     /* bad argument */
+    PVE_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error (text in pve_last_error) */
+    PVE_ERR_STATE = -3,       /* call sequence error (e.g. step before set_arrivals/reset) */
+    PVE_ERR_NOMEM = -4
+};
+
+/* Constructor arguments of the reference, ref :21-23 (`TrafficInteraction.__init__`), plus
+ * args.collision_thr (ref :32).  lane_num must be 12 (3/4/8-lane branches are out of scope). */
+typedef struct pve_config {
+    double deltaT;          /* 0.1 */
+    double vm, vM;          /* 5, 13   (train(): vm = 6, main.py:230) */
+    double am, aM;          /* -3, 3 */
+    double v0;              /* 10 */
+    double lane_cw;         /* 2.5 */
+    double dis_ctl;         /* 150 */
+    double collision_thr;   /* 2 (main.py:104) */
+    int32_t lane_num;       /* 12 */
+    int32_t reserved;
+} pve_config;
+
+/* Per-tick outputs.  Every pointer may be NULL (that output is skipped).
+ * "pre" arrays are indexed by the slot a vehicle had when the tick started (= the `[lane, j]`
+ * the reference reports in `ids`, ref :291); "post" arrays by the slot it has after compaction
+ * and spawning (= where the next tick's action for it must be written). */
+typedef struct pve_outputs {
+    double  *obs_post;      /* [n_envs][cap][28]  row 0 of the state (ref :1336) of the vehicle now in
+                               each slot; zeros for vehicles spawned this tick (ref :380,420) */
+    double  *obs_pre;       /* [n_envs][cap][28]  same rows, pre-compaction indexing (`re_state[k][0]`) */
+    double  *state_pre;     /* [n_envs][cap][7][28] full state incl. neighbour rows (ref :1325-1337);
+                               needs obs_prev_post and obs_pre */
+    const double *obs_prev_post; /* obs_post buffer written by the previous tick (stale neighbour rows, ref :1332) */
+    double  *reward;        /* [n_envs][cap]  pre; 0 for uncontrolled slots (ref :311-320, 346, 357) */
+    int32_t *flags;         /* [n_envs][cap]  pre; PVE_F_* bits | collisions_per_veh << 8 (ref :339) */
+    int32_t *lanej;         /* [n_envs][cap]  pre; lane << 16 | j  (the `ids` entry, ref :291) */
+    int32_t *nbr;           /* [n_envs][cap][6] pre; lane << 16 | j of the 6 nearest, -1 = none (ref :1391-1405) */
+    int32_t *new_slot;      /* [n_envs][cap]  pre -> post slot, -1 if deleted this tick (ref :435-444) */
+    int32_t *env_out;       /* [n_envs][PVE_ENV_OUT_N] per-env scalars of this tick, see PVE_EO_* */
+} pve_outputs;
+
+/* bits of pve_outputs.flags */
+#define PVE_F_ALIVE     0x01  /* slot held a vehicle at tick start */
+#define PVE_F_CTL       0x02  /* controlled: appears in `ids`, has reward/obs (ref :282) */
+#define PVE_F_DONE      0x04  /* veh["Done"] after this tick (ref :347, 351) */
+#define PVE_F_DELETED   0x08  /* in delete_veh (exit or collision, ref :348) */
+#define PVE_F_FINISHED  0x10  /* passed the box this tick: reward 5, jerks entry (ref :350-359) */
+#define PVE_F_LOCK      0x20  /* veh["lock"] set by the dead-lock scan (ref :1482) */
+
+#define PVE_ENV_OUT_N 8
+enum { PVE_EO_N_PRE = 0,      /* vehicles alive at tick start */
+       PVE_EO_N_CTL,          /* len(ids) */
+       PVE_EO_COLLISIONS,     /* `collisions` of the 9-tuple (ref :337) */
+       PVE_EO_LOCK,           /* `lock` of the 9-tuple (ref :365-370) */
+       PVE_EO_N_DELETED, PVE_EO_N_FINISHED, PVE_EO_N_SPAWNED,
+       PVE_EO_N_POST };       /* vehicles alive after the call */
+
+/* metrics vector of pve_get_metrics (sums over all envs of the handle since reset) */
+enum { PVE_M_SLOT_STEPS = 0, PVE_M_ALIVE_STEPS, PVE_M_CTL_STEPS, PVE_M_SPAWNED /* id_seq */,
+       PVE_M_PASSED, PVE_M_COLLIDED /* main.py:410-412 count */, PVE_M_LOCKS, PVE_M_SUM_REWARD,
+       PVE_M_SUM_JERK /* of passed vehicles */, PVE_M_PASSED_STEPS, PVE_M_OVERFLOW, PVE_M_TICKS };
+
+/* Per-vehicle record for the dict view `env.veh_info[lane][ind]` (ref :396-427, live keys only). */
+typedef struct pve_vehicle {
+    double p, v, a, jerk, jerk_sum, vir_dis, closer_p;
+    int32_t lane, j, id /* id_info[0] */, vnum /* id_info[1] */, seq_in_lane;
+    int32_t control, finish, done, collision, step, count, lock, lock_a;
+    int32_t vir_header[2];
+    int32_t intention, route;
+} pve_vehicle;
+
+typedef struct pve_env_info {
+    double current_time;                 /* ref :223 */
+    int32_t n_alive;
+    int32_t lane_count[PVE_LANES];       /* veh_num, ref :206 */
+    int32_t veh_rec[PVE_LANES];          /* ref :207 */
+    int32_t id_seq, passed_veh, passed_veh_step_total;   /* ref :197-198, 212 */
+    int32_t head_valid[PVE_LANES], head_lane[PVE_LANES], head_j[PVE_LANES];  /* virtual_lane_4[d][0][1:3], ref :1517 */
+    int32_t overflow;                    /* spawns deferred because the env was full */
+} pve_env_info;
+
+typedef struct pve_handle_s *pve_handle;
+
+int pve_abi_version(void);
+const char *pve_last_error(void);
+void pve_default_config(pve_config *cfg);
+
+/* Bytes of device workspace a handle needs (persistent SoA vehicle state + env headers). */
+size_t pve_workspace_bytes(int n_envs, int capacity);
+
+/* Replaces `TrafficInteraction(arrive_time, dis_ctl, args, ...)` object creation (ref :21) for
+ * n_envs independent intersections with `capacity` (64 or 128) vehicle slots each.
+ * workspace: device buffer of pve_workspace_bytes() bytes, or NULL to let the library allocate. */
+int pve_create(const pve_config *cfg, int n_envs, int capacity, int device_id,
+               void *workspace, void *stream, pve_handle *out);
+int pve_destroy(pve_handle h);
+int pve_set_stream(pve_handle h, void *stream);
+
+/* Arrival streams `arrive_time` (ref :195, main.py:388-389): DEVICE buffer of float64
+ * [n_envs][rows][12] (env_stride_rows = rows) or one shared [rows][12] stream (env_stride_rows = 0).
+ * Times beyond the run must be padded with +inf.  The buffer must outlive the handle's use of it. */
+int pve_set_arrivals(pve_handle h, const double *arrivals, int rows, int env_stride_rows);
+
+/* Constructor warm-up (ref :196-220): zero all state, then advance each env's clock tick by tick
+ * (spawning, ref :378) until it holds at least one vehicle. */
+int pve_reset(pve_handle h);
+
+/* FUSED TICK = `for lane, ind: env.step(lane, ind, a)` (ref :1501, main.py:398-406) +
+ * `env.scene_update()` (ref :222) + `env.delete_vehicle()` (ref :435) for every env.
+ * actions: device float64 [n_envs][capacity], indexed by current (post-compaction) slot;
+ * entries of uncontrolled / empty slots are ignored (main.py:401 passes 0). */
+int pve_step_all(pve_handle h, const double *actions, const pve_outputs *out);
+
+/* Split protocol for the single-env compatibility class (same kernels, three launches):
+ *   pve_scene_update   = all step() calls + scene_update(); vehicles marked Done stay in place
+ *   pve_compact        = delete_vehicle() */
+int pve_scene_update(pve_handle h, const double *actions, const pve_outputs *out);
+int pve_compact(pve_handle h, double *obs_post /* optional: rows are moved with the vehicles */);
+
+/* Host read-back (synchronises the stream). */
+int pve_read_env(pve_handle h, int env, pve_env_info *out);
+int pve_read_vehicles(pve_handle h, int env, pve_vehicle *out, int max_n, int *n_out);
+int pve_get_metrics(pve_handle h, double out[PVE_N_METRICS]);
+
+/* Device views of the persistent per-slot state for zero-copy consumers (actor input masks):
+ * field = "p","v","a","jerk","jerk_sum","vir_dis","closer_p" (float64 [n_envs][cap]) or
+ * "id","seq","vnum","step","count","meta","hdr" (int32 [n_envs][cap]); meta bit0 = control. */
+int pve_state_field(pve_handle h, const char *field, void **dev_ptr, int *elem_bytes);
+#define PVE_META_CONTROL 0x1
+#define PVE_META_FINISH  0x2
+#define PVE_META_DONE    0x4
+#define PVE_META_LOCK    0x8
+
+int pve_synchronize(pve_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVE_ENV_H */

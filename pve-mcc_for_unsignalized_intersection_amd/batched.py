@@ -1,0 +1,217 @@
+"""BatchedIntersections: thousands of independent 12-lane intersections per GPU.
+
+Python host code over the C ABI (include/pve_env.h); torch is used only for device memory and
+the stream.  One fused HIP kernel launch per tick = the reference's
+`for lane, ind: env.step(lane, ind, a)` + `env.scene_update()` + `env.delete_vehicle()`
+(reference traffic_interaction_scene.py:1501, :222, :435; caller protocol main.py:398-441).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import PveConfig, PveEnvInfo, PveOutputs, PveVehicle, PveError, check
+
+ALL_OUTPUTS = ("obs_post", "obs_pre", "reward", "flags", "lanej", "nbr", "new_slot", "env_out", "state_pre")
+DEFAULT_OUTPUTS = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
+
+
+def make_config(lib, **kw):
+    cfg = PveConfig()
+    lib.pve_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise TypeError("unknown config field %r" % k)
+        setattr(cfg, k, type(getattr(cfg, k))(v))
+    return cfg
+
+
+class BatchedIntersections:
+    """n_envs environments x `capacity` vehicle slots, state resident in HBM (struct of arrays).
+
+    arrivals: float64 array/tensor [rows, 12] (shared by all envs) or [n_envs, rows, 12]; the
+              reference's `arrive_time` matrix (main.py:388-389). Pad with +inf.
+    outputs:  names of per-tick output buffers to allocate (see include/pve_env.h `pve_outputs`).
+    """
+
+    def __init__(self, n_envs, capacity, arrivals, device=None, outputs=DEFAULT_OUTPUTS, stream=None,
+                 _lib=None, **config):
+        if device is None:
+            device = "cuda"
+        self.device = torch.device(device)
+        if _lib is None:
+            if self.device.type != "cuda":
+                raise PveError("BatchedIntersections runs on an AMD GPU only (device=%s); there is no CPU path"
+                               % self.device)
+            _lib = _capi.load_library()
+        self.lib = _lib
+        self.n_envs, self.capacity = int(n_envs), int(capacity)
+        self.cfg = make_config(self.lib, **config)
+        nbytes = self.lib.pve_workspace_bytes(self.n_envs, self.capacity)
+        if nbytes == 0:
+            raise PveError("invalid n_envs/capacity (capacity must be 64 or 128)")
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        dev_index = self.device.index if self.device.index is not None else (
+            torch.cuda.current_device() if self.device.type == "cuda" else 0)
+        self._stream_obj = stream
+        sptr = self._stream_ptr()
+        h = C.c_void_p()
+        check(self.lib, self.lib.pve_create(C.byref(self.cfg), self.n_envs, self.capacity, dev_index,
+                                            C.c_void_p(self.workspace.data_ptr()), sptr, C.byref(h)),
+              "pve_create")
+        self._h = h
+        self.set_arrivals(arrivals)
+        E, K = self.n_envs, self.capacity
+        dev = self.device
+        self.out = {}
+        names = set(outputs)
+        if "state_pre" in names:
+            names.update(("obs_pre", "obs_post"))
+        self._obs = None
+        if "obs_post" in names:
+            self._obs = [torch.zeros(E, K, 28, dtype=torch.float64, device=dev) for _ in range(2)]
+            self._obs_cur = 0
+        shapes = dict(obs_pre=((E, K, 28), torch.float64), state_pre=((E, K, 7, 28), torch.float64),
+                      reward=((E, K), torch.float64), flags=((E, K), torch.int32), lanej=((E, K), torch.int32),
+                      nbr=((E, K, 6), torch.int32), new_slot=((E, K), torch.int32), env_out=((E, 8), torch.int32))
+        for n in names:
+            if n == "obs_post":
+                continue
+            if n not in shapes:
+                raise TypeError("unknown output %r" % n)
+            shp, dt = shapes[n]
+            self.out[n] = torch.zeros(shp, dtype=dt, device=dev)
+        self._zero_actions = torch.zeros(E, K, dtype=torch.float64, device=dev)
+        self.ticks = 0
+        self._is_reset = False
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream_ptr(self):
+        if self._stream_obj is not None:
+            return C.c_void_p(self._stream_obj.cuda_stream)
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(0)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.pve_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_arrivals(self, arrivals):
+        a = torch.as_tensor(np.asarray(arrivals) if not torch.is_tensor(arrivals) else arrivals,
+                            dtype=torch.float64)
+        if a.dim() == 2:
+            assert a.shape[1] == 12, "arrivals must be [rows, 12]"
+            stride_rows = 0
+            rows = a.shape[0]
+        else:
+            assert a.dim() == 3 and a.shape[0] == self.n_envs and a.shape[2] == 12, \
+                "arrivals must be [rows,12] or [n_envs,rows,12]"
+            rows = a.shape[1]
+            stride_rows = rows
+        self.arrivals = a.contiguous().to(self.device)
+        check(self.lib, self.lib.pve_set_arrivals(self._h, C.c_void_p(self.arrivals.data_ptr()), rows, stride_rows),
+              "pve_set_arrivals")
+
+    def state_field(self, name):
+        """Zero-copy [n_envs, capacity] view of a persistent per-slot field (see pve_state_field)."""
+        p = C.c_void_p()
+        eb = C.c_int()
+        check(self.lib, self.lib.pve_state_field(self._h, name.encode(), C.byref(p), C.byref(eb)), "pve_state_field")
+        off = p.value - self.workspace.data_ptr()
+        n = self.n_envs * self.capacity * eb.value
+        dt = torch.float64 if eb.value == 8 else torch.int32
+        return self.workspace[off:off + n].view(dt).view(self.n_envs, self.capacity)
+
+    @property
+    def obs(self):
+        """[n_envs, capacity, 28] observation (state row 0) of the vehicle now in each slot."""
+        return self._obs[self._obs_cur]
+
+    def control_mask(self):
+        return (self.state_field("meta") & _capi.META_CONTROL) != 0
+
+    # ------------------------------------------------------------------ reference-shaped calls
+    def reset(self):
+        """New episode: the reference builds a new TrafficInteraction (main.py:394) whose constructor
+        warms up until the first vehicle exists (ref :214-220)."""
+        self.lib.pve_set_stream(self._h, self._stream_ptr())
+        check(self.lib, self.lib.pve_reset(self._h), "pve_reset")
+        if self._obs is not None:
+            for o in self._obs:
+                o.zero_()
+        self.ticks = 0
+        self._is_reset = True
+
+    def _outputs_struct(self, flip_obs):
+        o = PveOutputs()
+        if self._obs is not None:
+            if flip_obs:
+                self._obs_cur ^= 1
+            o.obs_post = self._obs[self._obs_cur].data_ptr()
+            o.obs_prev_post = self._obs[self._obs_cur ^ 1].data_ptr()
+        for n, tns in self.out.items():
+            setattr(o, n, tns.data_ptr())
+        return o
+
+    def step(self, actions=None):
+        """One fused tick for every env. actions: float64 [n_envs, capacity] indexed by current slot
+        (None = zeros). Returns the dict of output tensors (views, overwritten by the next call)."""
+        a = self._zero_actions if actions is None else actions
+        assert a.dtype == torch.float64 and a.is_contiguous() and a.shape == (self.n_envs, self.capacity)
+        self.lib.pve_set_stream(self._h, self._stream_ptr())
+        o = self._outputs_struct(flip_obs=True)
+        check(self.lib, self.lib.pve_step_all(self._h, C.c_void_p(a.data_ptr()), C.byref(o)), "pve_step_all")
+        self.ticks += 1
+        return self.outputs()
+
+    def scene_update(self, actions=None):
+        """Split protocol, part 1: all step() calls + scene_update(); Done vehicles stay in place."""
+        a = self._zero_actions if actions is None else actions
+        assert a.dtype == torch.float64 and a.is_contiguous() and a.shape == (self.n_envs, self.capacity)
+        self.lib.pve_set_stream(self._h, self._stream_ptr())
+        o = self._outputs_struct(flip_obs=True)
+        check(self.lib, self.lib.pve_scene_update(self._h, C.c_void_p(a.data_ptr()), C.byref(o)), "pve_scene_update")
+        self.ticks += 1
+        return self.outputs()
+
+    def compact(self):
+        """Split protocol, part 2: delete_vehicle() (ref :435)."""
+        self.lib.pve_set_stream(self._h, self._stream_ptr())
+        obs = C.c_void_p(self._obs[self._obs_cur].data_ptr()) if self._obs is not None else C.c_void_p(0)
+        check(self.lib, self.lib.pve_compact(self._h, obs), "pve_compact")
+
+    def outputs(self):
+        d = dict(self.out)
+        if self._obs is not None:
+            d["obs_post"] = self._obs[self._obs_cur]
+        return d
+
+    def synchronize(self):
+        check(self.lib, self.lib.pve_synchronize(self._h), "pve_synchronize")
+
+    # ------------------------------------------------------------------ host read-back
+    def read_env(self, env=0):
+        info = PveEnvInfo()
+        check(self.lib, self.lib.pve_read_env(self._h, env, C.byref(info)), "pve_read_env")
+        return info
+
+    def read_vehicles(self, env=0):
+        buf = (PveVehicle * self.capacity)()
+        n = C.c_int()
+        check(self.lib, self.lib.pve_read_vehicles(self._h, env, buf, self.capacity, C.byref(n)), "pve_read_vehicles")
+        return [buf[i] for i in range(min(n.value, self.capacity))]
+
+    def metrics(self):
+        """dict of the 12 metric sums over this handle's envs since reset (SURVEY §8e vector)."""
+        out = (C.c_double * _capi.PVE_N_METRICS)()
+        check(self.lib, self.lib.pve_get_metrics(self._h, out), "pve_get_metrics")
+        return dict(zip(_capi.METRIC_NAMES, [float(x) for x in out]))

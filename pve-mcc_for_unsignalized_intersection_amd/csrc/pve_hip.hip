@@ -1,0 +1,130 @@
+// pve_hip.hip -- gfx950 (MI355X / CDNA4) kernels + HIP backend of the C ABI -> libpveenv.so
+//
+//   k_tick<CAP>     one workgroup (CAP = 64 or 128 threads = 1 or 2 wave64) per intersection:
+//                   fused step* + scene_update + delete_vehicle, state staged in LDS, phases of
+//                   pve_tick_core.h separated by workgroup barriers.
+//   k_compact<CAP>  delete_vehicle() alone (split protocol of the single-env compat class)
+//   k_reset<CAP>    constructor warm-up, one thread per intersection
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction: the discrete
+// decisions of the reference sit on margins down to 4e-16).
+#include <hip/hip_runtime.h>
+#include <new>
+
+#include "pve_host.h"
+#include "pve_tick_core.h"
+
+using namespace pve;
+
+template <int CAP>
+__global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
+{
+    __shared__ Shared<CAP> sh;
+    const int t = threadIdx.x;
+    const int env = blockIdx.x;
+    Regs r;
+    typedef Tick<CAP> T;
+    T::ph_load(c, P, env, t, sh, r);
+    __syncthreads();
+    T::ph_step1(c, P, env, t, sh, r);
+    __syncthreads();
+    T::ph_step2(c, t, sh, r);
+    __syncthreads();
+    T::ph_step3(c, t, sh, r);
+    T::ph_step3_publish(t, sh, r);
+    __syncthreads();
+    T::ph_scan(c, t, sh, r);
+    __syncthreads();
+    T::ph_effects(c, t, sh, r);
+    __syncthreads();
+    T::ph_lock(c, t, sh, r);
+    __syncthreads();
+    T::ph_final(c, P, env, t, sh, r);
+}
+
+template <int CAP>
+__global__ __launch_bounds__(CAP) void k_compact(const Params P)
+{
+    __shared__ Shared<CAP> sh;
+    const int t = threadIdx.x;
+    const int env = blockIdx.x;
+    CRegs r;
+    Tick<CAP>::ph_c_load(P, env, t, sh, r);
+    __syncthreads();
+    Tick<CAP>::ph_c_store(P, env, t, sh, r);
+}
+
+template <int CAP>
+__global__ __launch_bounds__(64) void k_reset(const Const c, const Params P, int cap_ticks)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env < P.n_envs) reset_env<CAP>(c, P, env, cap_ticks);
+}
+
+static std::string hip_err(const char *what, hipError_t e)
+{
+    return std::string(what) + ": " + hipGetErrorString(e);
+}
+
+struct Backend {
+    static int set_device(int dev, std::string &err)
+    {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) { err = "no HIP device visible (libpveenv.so needs an AMD GPU; there is no CPU fallback)"; return -1; }
+        if (dev < 0 || dev >= n) { err = "device_id out of range"; return -1; }
+        e = hipSetDevice(dev);
+        if (e != hipSuccess) { err = hip_err("hipSetDevice", e); return -1; }
+        return 0;
+    }
+    static void *dmalloc(size_t n)
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, n) != hipSuccess) return nullptr;
+        return p;
+    }
+    static void dfree(void *p) { (void)hipFree(p); }
+    static int d2h(void *dst, const void *src, size_t n, void *stream)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        if (hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        return 0;
+    }
+    static int sync(void *stream, std::string &err)
+    {
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) { err = hip_err("hipStreamSynchronize", e); return -1; }
+        return 0;
+    }
+    static int check_launch(std::string &err)
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = hip_err("kernel launch", e); return -1; }
+        return 0;
+    }
+    static int launch_tick(const Const &c, const Params &P, int cap, void *stream, std::string &err)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        if (cap == 64) hipLaunchKernelGGL(k_tick<64>, dim3(P.n_envs), dim3(64), 0, s, c, P);
+        else hipLaunchKernelGGL(k_tick<128>, dim3(P.n_envs), dim3(128), 0, s, c, P);
+        return check_launch(err);
+    }
+    static int launch_compact(const Params &P, int cap, void *stream, std::string &err)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        if (cap == 64) hipLaunchKernelGGL(k_compact<64>, dim3(P.n_envs), dim3(64), 0, s, P);
+        else hipLaunchKernelGGL(k_compact<128>, dim3(P.n_envs), dim3(128), 0, s, P);
+        return check_launch(err);
+    }
+    static int launch_reset(const Const &c, const Params &P, int cap, void *stream, std::string &err)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        const int blocks = (P.n_envs + 63) / 64;
+        if (cap == 64) hipLaunchKernelGGL(k_reset<64>, dim3(blocks), dim3(64), 0, s, c, P, 200000);
+        else hipLaunchKernelGGL(k_reset<128>, dim3(blocks), dim3(128 / 2), 0, s, c, P, 200000);
+        return check_launch(err);
+    }
+};
+
+#include "pve_capi.inc"

@@ -1,0 +1,764 @@
+// pve_tick_core.h -- the environment tick as barrier-separated phases.
+//
+// One workgroup = one intersection; thread t = vehicle slot t (slots are kept sorted by
+// (lane, j), so "order" in the reference's sequential loops == slot index, and every lane is a
+// contiguous slot range).  The reference's order-dependent (Gauss-Seidel) semantics are turned
+// into closed-form parallel rules:
+//   S1-S3  step()            ref traffic_interaction_scene.py:1501-1539  (in-lane brake chain)
+//   SCAN   scene_update()    ref :233-334  (virtual lane, predecessor, 6 nearest, reward, XY hit)
+//   FX     ordered effects   ref :333-359  (collision visibility by order, Done / finish)
+//   LOCK   dead-lock scan    ref :365-370, :1469-1499 ; spawn ref :378-433
+//   FIN    delete_vehicle()  ref :435-444  (stable re-pack) + coalesced write-back
+//
+// The same phase bodies are compiled (a) by hipcc as __device__ code called from the kernels in
+// pve_hip.hip with __syncthreads() between phases, and (b) by g++ for the CPU *test* emulator
+// (tests/emu), which runs each phase for t = 0..CAP-1 in a loop.  The product library contains
+// only (a).
+#pragma once
+#include "pve_types.h"
+#include <math.h>
+
+#if defined(__HIPCC__)
+#undef PVE_HD
+#define PVE_HD __device__ __forceinline__
+#define PVE_DEVICE_CODE 1
+#else
+#define PVE_DEVICE_CODE 0
+#endif
+
+namespace pve {
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------ wave / block primitives
+template <int NW> PVE_HD void vote(u64 *m, int t, bool f)
+{
+#if PVE_DEVICE_CODE
+    u64 b = __ballot(f);               // 64-wide wavefront ballot
+    if ((t & 63) == 0) m[t >> 6] = b;
+#else
+    if (f) m[t >> 6] |= 1ull << (t & 63);   // emulator: masks are zeroed per env
+#endif
+}
+PVE_HD bool mask_test(const u64 *m, int t) { return (m[t >> 6] >> (t & 63)) & 1ull; }
+template <int NW> PVE_HD int mask_below(const u64 *m, int t)   // set bits at positions < t
+{
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        if (t >= (k + 1) * 64) c += __builtin_popcountll(m[k]);
+        else if (t > k * 64) c += __builtin_popcountll(m[k] & ((1ull << (t - k * 64)) - 1ull));
+    }
+    return c;
+}
+template <int NW> PVE_HD int mask_count(const u64 *m)
+{
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) c += __builtin_popcountll(m[k]);
+    return c;
+}
+template <int NW> PVE_HD int mask_prev(const u64 *m, int t)    // highest set bit < t, or -1
+{
+#pragma unroll
+    for (int k = NW - 1; k >= 0; k--) {
+        int lo = k * 64;
+        if (t <= lo) continue;
+        u64 b = m[k];
+        if (t < lo + 64) b &= (1ull << (t - lo)) - 1ull;
+        if (b) return lo + 63 - __builtin_clzll(b);
+    }
+    return -1;
+}
+PVE_HD void lds_add(int *p, int v)
+{
+#if PVE_DEVICE_CODE
+    atomicAdd(p, v);
+#else
+    *p += v;
+#endif
+}
+PVE_HD void lds_or(int *p, int v)
+{
+#if PVE_DEVICE_CODE
+    atomicOr(p, v);
+#else
+    *p |= v;
+#endif
+}
+PVE_HD void lds_and(int *p, int v)
+{
+#if PVE_DEVICE_CODE
+    atomicAnd(p, v);
+#else
+    *p &= v;
+#endif
+}
+// deterministic block sum: wave shuffle tree, one partial per wave (red[] summed by thread 0 later)
+PVE_HD void block_sum(double *red, int t, double x)
+{
+#if PVE_DEVICE_CODE
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if ((t & 63) == 0) red[t >> 6] = x;
+#else
+    red[0] += x;
+#endif
+}
+
+// ------------------------------------------------------------------ shared (LDS) block of one env
+template <int CAP> struct Shared {
+    static constexpr int NW = CAP / 64;
+    EnvHeader hd;
+    double p[CAP], v[CAP], a[CAP];   // post-step kinematics of every slot
+    double p1[CAP], v1[CAP];         // step outcome "if braking" (S1-S3 only)
+    double virdis[CAP];
+    double next_arr[NL];
+    double red_reward[NW], red_jerk[NW];
+    int cnt[CAP];                    // collision hits received: early | late << 16
+    int acc_passed_steps, acc_collisions;
+    int16_t hdr[CAP];                // slot of the virtual header (predecessor) or -1
+    uint8_t bb[CAP];                 // brake bits: bit0 if front did not brake, bit1 if it did
+    uint8_t lockf[CAP];
+    int8_t locka[CAP];
+    uint8_t rew_ovr[CAP];
+    u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW];
+    u64 m_spawn[NW];
+};
+
+struct Regs {
+    double p, v, a, jerk, jerk_sum, vir_dis, closer_p;
+    double a0, a1;
+    double reward;
+    double kv[NNB];
+    int kr[NNB];
+    int id, seq, vnum, step, count, meta;
+    int lane, j;
+    int hdr;
+    int hit, coll_seen, coll_fin;
+    int alive, ctl, del, fin;
+};
+struct CRegs {                       // MODE_COMPACT moves every persistent field verbatim
+    double p, v, a, jerk, jerk_sum, vir_dis, closer_p;
+    int id, seq, vnum, step, count, meta, hdr_word, alive;
+    double obsrow[OBSW];
+};
+
+// ------------------------------------------------------------------ geometry: ref :1250-1289
+PVE_HD void get_xy(const Const &c, double p, int lane, double &X, double &Y)
+{
+    const double cw = c.cw;
+    const int m = lane % 3;
+    double x, y;
+    if (m == 0) {
+        const double L0 = c.inbox[0];
+        if (p > L0) { x = p - L0 + 6 * cw; y = cw; }
+        else if (p > 0) {
+            double r_a = (L0 - p) / L0 * c.arc_k / 2;
+            double p0x = 6 * cw, p0y = cw, prx = 6 * cw, pry = -6 * cw;
+            double cs = cos(r_a), sn = sin(r_a);
+            x = prx + (p0x - prx) * cs - (p0y - pry) * sn;
+            y = pry + (p0y - pry) * cs + (p0x - prx) * sn;
+        } else { x = -cw; y = -6 * cw + p; }
+    } else if (m == 1) {
+        x = p - 6 * cw; y = 3 * cw;
+    } else {
+        const double L2 = c.inbox[2];
+        if (p > L2) { x = p - L2 + 6 * cw; y = 5 * cw; }
+        else if (p > 0) {
+            double r_a = (L2 - p) / L2 * c.arc_k / 2;
+            double p0x = 6 * cw, p0y = 5 * cw, prx = 6 * cw, pry = 6 * cw;
+            double cs = cos(r_a), sn = sin(r_a);
+            x = prx + (p0x - prx) * cs + (p0y - pry) * sn;
+            y = pry + (p0y - pry) * cs - (p0x - prx) * sn;
+        } else { x = 5 * cw; y = 6 * cw - p; }
+    }
+    const double rc = c.rot_cos[lane / 3], rs = c.rot_sin[lane / 3];
+    X = x * rc - y * rs;
+    Y = y * rc + x * rs;
+}
+
+PVE_HD bool key_less(double d1, double v1, int r1, double d2, double v2, int r2)
+{   // total order of the reference's stable sort on |vd - vd_self| over a vd-sorted list (ref :271, :1389)
+    return d1 < d2 || (d1 == d2 && (v1 < v2 || (v1 == v2 && r1 < r2)));
+}
+
+PVE_HD int brake_needed(const Const &c, double p, double v, double fp, double fv)
+{   // ref :1509-1516 (front = vehicle j-1 AFTER its own update)
+    if (fv < v) {
+        double d_safe = v * 0.4 + (v * v - fv * fv) / c.two_abs_am - (v - fv) * c.vm / c.abs_am;
+        if (p - fp < d_safe) return 1;
+    }
+    return 0;
+}
+
+PVE_HD int slot_lane(const EnvHeader &hd, int t)
+{
+    int lane = 0;
+#pragma unroll
+    for (int L = 1; L < NL; L++) lane += (t >= hd.lane_start[L]) ? 1 : 0;
+    return lane;
+}
+
+template <int CAP> struct Tick {
+    typedef Shared<CAP> Sh;
+    static constexpr int NW = CAP / 64;
+
+    // ============================================================== L: load
+    static PVE_HD void ph_load(const Const &c, const Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        const EnvHeader &gh = P.headers[env];
+        {
+            const int *src = (const int *)&gh;
+            int *dst = (int *)&sh.hd;
+            for (int w = t; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];
+        }
+        const int N = gh.n_alive;
+        const size_t g = (size_t)env * CAP + t;
+        r.alive = t < N;
+        r.p = r.v = r.a = r.jerk = r.jerk_sum = 0; r.vir_dis = 100; r.closer_p = 150;
+        r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
+        if (r.alive) {
+            r.p = P.f64[F_P][g]; r.v = P.f64[F_V][g]; r.a = P.f64[F_A][g];
+            r.jerk_sum = P.f64[F_JERK_SUM][g]; r.vir_dis = P.f64[F_VIR_DIS][g];
+            r.closer_p = P.f64[F_CLOSER_P][g];
+            r.id = P.i32[I_ID][g]; r.seq = P.i32[I_SEQ][g]; r.vnum = P.i32[I_VNUM][g];
+            r.step = P.i32[I_STEP][g]; r.count = P.i32[I_COUNT][g]; r.meta = P.i32[I_META][g];
+        }
+        sh.cnt[t] = 0; sh.lockf[t] = 0; sh.locka[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
+        if (t < NL) {
+            int rec = gh.veh_rec[t];
+            double nxt = INFINITY;
+            if (rec < P.rows) nxt = P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec * NL + t];
+            sh.next_arr[t] = nxt;
+        }
+        if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; }
+    }
+
+    // ============================================================== S1: step, both outcomes
+    static PVE_HD void outcome(const Const &c, double p, double v, double a, bool ctl, double &pn, double &vn)
+    {   // ref :1528-1535
+        pn = p - v * c.deltaT - 0.5 * a * c.dt2;
+        double x = v + a * c.deltaT;
+        x = (c.vm > x) ? c.vm : x;
+        vn = (x < c.vM) ? x : c.vM;
+        if (!ctl) vn = c.v0;
+    }
+    static PVE_HD double clip_a(const Const &c, double x)
+    {   // min(aM, max(am, x)), ref :1502, 1521
+        double y = (x > c.am) ? x : c.am;
+        return (c.aM < y) ? c.aM : y;
+    }
+    static PVE_HD void ph_step1(const Const &c, const Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        r.ctl = 0; r.lane = 0; r.j = 0; r.a0 = r.a1 = 0;
+        if (t == 0) sh.hd.current_time += c.deltaT;      // ref :223 (repeated +=, not tick*dt)
+        if (r.alive) {
+            const int lane = slot_lane(sh.hd, t);
+            r.lane = lane; r.j = t - sh.hd.lane_start[lane];
+            r.ctl = (r.meta & M_CONTROL) ? 1 : 0;
+            double act = P.actions ? P.actions[(size_t)env * CAP + t] : 0.0;
+            if (P.mask_uncontrolled && !r.ctl) act = 0.0;   // main.py:401
+            double target = clip_a(c, act);                                       // ref :1502
+            if ((r.meta & M_LOCK) && (r.meta & (M_LOCKA_POS | M_LOCKA_NEG)) && r.p > 70)   // ref :1503-1505
+                target = r.a + ((r.meta & M_LOCKA_POS) ? 1.0 : -1.0);
+            r.meta &= ~(M_LOCK | M_LOCKA_POS | M_LOCKA_NEG);                      // ref :1506-1507
+            bool ovr = ((sh.hd.head_valid >> lane) & 1) && sh.hd.head_lane[lane] == lane &&
+                       sh.hd.head_j[lane] == r.j;                                // ref :1517-1518 (stale j)
+            ovr = ovr || (lane % 3 == 2);                                         // ref :1519-1520
+            r.a0 = clip_a(c, ovr ? c.aM : target);                                // ref :1521
+            r.a1 = clip_a(c, ovr ? c.aM : c.am);                                  // ref :1516
+            double pn, vn;
+            outcome(c, r.p, r.v, r.a0, r.ctl, pn, vn); sh.p[t] = pn; sh.v[t] = vn;
+            outcome(c, r.p, r.v, r.a1, r.ctl, pn, vn); sh.p1[t] = pn; sh.v1[t] = vn;
+        }
+        vote<NW>(sh.m_alive, t, r.alive);
+        vote<NW>(sh.m_ctl, t, r.alive && r.ctl);
+    }
+
+    // ============================================================== S2: brake decision per front outcome
+    static PVE_HD void ph_step2(const Const &c, int t, Sh &sh, Regs &r)
+    {
+        int bb = 0;
+        if (r.alive && r.j > 0 && r.ctl && mask_test(sh.m_ctl, t - 1)) {         // ref :1509-1510
+            bb = brake_needed(c, r.p, r.v, sh.p[t - 1], sh.v[t - 1]) |
+                 (brake_needed(c, r.p, r.v, sh.p1[t - 1], sh.v1[t - 1]) << 1);
+        }
+        sh.bb[t] = (uint8_t)bb;
+    }
+
+    // ============================================================== S3: resolve the in-lane chain
+    static PVE_HD void ph_step3(const Const &c, int t, Sh &sh, Regs &r)
+    {
+        if (r.alive) {
+            int k = t;
+            while (sh.bb[k] == 1 || sh.bb[k] == 2) k--;   // first slot whose decision ignores its front (j==0 -> 0)
+            int br = sh.bb[k] & 1;
+            for (int q = k + 1; q <= t; q++) br = (sh.bb[q] >> br) & 1;
+            double an = br ? r.a1 : r.a0;
+            r.jerk = an - r.a;                                                    // ref :1522
+            r.a = an;
+            r.p = br ? sh.p1[t] : sh.p[t];
+            r.v = br ? sh.v1[t] : sh.v[t];
+            r.step += 1;                                                          // ref :1533
+        }
+    }
+    static PVE_HD void ph_step3_publish(int t, Sh &sh, Regs &r)
+    {
+        if (r.alive) { sh.p[t] = r.p; sh.v[t] = r.v; sh.a[t] = r.a; }
+    }
+
+    // ============================================================== SCAN: virtual lane of own direction
+    static PVE_HD void ph_scan(const Const &c, int t, Sh &sh, Regs &r)
+    {
+        r.reward = 0; r.hit = 0; r.hdr = -1;
+#pragma unroll
+        for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
+        const bool ctl = r.alive && r.ctl;
+        const bool head_thread = r.alive && r.j == 0;     // lane non-empty -> its list is rebuilt (ref :234)
+        if (!(ctl || head_thread)) return;
+        const int lane = r.lane, m = lane % 3;
+        const double ps = r.p;
+        double hvd = INFINITY; int hr = -1;               // list head = min (vd, slot)
+        double pvd = -INFINITY; int pr = -1;              // predecessor = max key < own key
+        double kd[NNB], kv[NNB]; int kr[NNB];
+#pragma unroll
+        for (int k = 0; k < NNB; k++) { kd[k] = INFINITY; kv[k] = INFINITY; kr[k] = 0x7fffffff; }
+        for (int q = 0; q < 5; q++) {
+            int L = lane; double A = 0, B = 0, Cc = 0;
+            const bool own = (q == 0);
+            if (!own) {
+                if (m == 2) break;                        // right turns conflict with nobody (ref :156)
+                L = c.l2l[lane][q - 1]; A = c.vdA[m][q - 1]; B = c.vdB[m][q - 1]; Cc = c.vdC[m][q - 1];
+            }
+            const int lo = sh.hd.lane_start[L], hi = sh.hd.lane_start[L + 1];
+            for (int x = lo; x < hi; x++) {
+                if (!mask_test(sh.m_ctl, x)) continue;    // only vehicles appended by step (ref :1539)
+                const double pp = sh.p[x];
+                double vd;
+                if (own) vd = pp;                         // ref :242-249
+                else {                                    // ref :259-270, :733-803
+                    double delta = pp - A + B;
+                    if (!(delta > 0)) continue;
+                    vd = Cc + delta;
+                }
+                if (vd < hvd || (vd == hvd && x < hr)) { hvd = vd; hr = x; }
+                if (ctl && x != t) {
+                    bool lt = vd < ps || (vd == ps && x < t);
+                    if (lt && (vd > pvd || (vd == pvd && x > pr))) { pvd = vd; pr = x; }
+                    double d = fabs(vd - ps);             // ref :1388
+                    if (key_less(d, vd, x, kd[NNB - 1], kv[NNB - 1], kr[NNB - 1])) {
+                        kd[NNB - 1] = d; kv[NNB - 1] = vd; kr[NNB - 1] = x;
+#pragma unroll
+                        for (int s = NNB - 1; s > 0; s--) {
+                            if (key_less(kd[s], kv[s], kr[s], kd[s - 1], kv[s - 1], kr[s - 1])) {
+                                double td = kd[s]; kd[s] = kd[s - 1]; kd[s - 1] = td;
+                                double tv = kv[s]; kv[s] = kv[s - 1]; kv[s - 1] = tv;
+                                int tr = kr[s]; kr[s] = kr[s - 1]; kr[s - 1] = tr;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (head_thread) {                                // persisted for next tick's step (ref :1517)
+            if (hr >= 0) {
+                lds_or(&sh.hd.head_valid, 1 << lane);
+                int hl = slot_lane(sh.hd, hr);
+                sh.hd.head_lane[lane] = (int16_t)hl;
+                sh.hd.head_j[lane] = (int16_t)(hr - sh.hd.lane_start[hl]);
+            } else {
+                lds_and(&sh.hd.head_valid, ~(1 << lane));
+            }
+        }
+        if (!ctl) return;
+#pragma unroll
+        for (int k = 0; k < NNB; k++) {
+            r.kr[k] = (kr[k] == 0x7fffffff) ? -1 : kr[k];
+            r.kv[k] = (kr[k] == 0x7fffffff) ? 0.0 : kv[k];
+        }
+        // ref :1348-1354
+        r.hdr = pr;
+        r.vir_dis = (pr >= 0) ? (ps - pvd) : 100.0;
+        sh.hdr[t] = (int16_t)pr;
+        sh.virdis[t] = r.vir_dis;
+        r.count += 1;                                                             // ref :292
+        // ref :280-310
+        double t_distance = 2, d_distance = 10;
+        const int n0 = r.kr[0];
+        if (n0 >= 0) {
+            const double vdn = r.kv[0];
+            d_distance = fabs(ps - vdn);
+            r.closer_p = vdn;
+            if (d_distance != 0) t_distance = (ps - vdn) / (r.v - sh.v[n0] + 0.0001);
+        } else {
+            r.closer_p = 150;
+        }
+        // ref :311-320
+        double r_ = 0;
+        if (0 < t_distance && t_distance < 4) r_ += 1 / tanh(-t_distance / 4.0);
+        {
+            double jd = r.jerk / c.deltaT;
+            r_ -= jd * jd / 3600.0 * 3.0;
+        }
+        if (d_distance < 10) {
+            double q1 = d_distance / 10, q2 = q1 * q1;
+            r_ += log(q2 * q2 * q1 + 0.00001);
+        }
+        r_ += (r.v - c.vm) / c.aM_minus_am * 2.0;
+        r_ = (r_ > -20) ? r_ : -20;
+        r.reward = (r_ < 20) ? r_ : 20;
+        r.jerk_sum += fabs(r.jerk / c.deltaT);                                    // ref :321
+        // ref :322-334
+        if (n0 >= 0) {
+            double ax, ay, bx, by;
+            get_xy(c, ps, lane, ax, ay);
+            get_xy(c, sh.p[n0], slot_lane(sh.hd, n0), bx, by);
+            double dx = bx - ax, dy = by - ay;
+            double dxy = sqrt(dx * dx + dy * dy);
+            if (fabs(dxy) < c.collision_thr) {
+                r.hit = 1;
+                lds_add(&sh.cnt[n0], (t < n0) ? 1 : (1 << 16));   // seen by n0 this tick only if we precede it
+            }
+        }
+    }
+
+    // ============================================================== FX: ordered effects
+    static PVE_HD void ph_effects(const Const &c, int t, Sh &sh, Regs &r)
+    {
+        r.del = 0; r.fin = 0; r.coll_seen = 0; r.coll_fin = 0;
+        if (r.alive) {
+            const int cc = sh.cnt[t];
+            const int prev = (r.meta >> M_COLL_SHIFT) & M_COLL_MASK;
+            r.coll_seen = prev + r.hit + (cc & 0xffff);                           // ref :337-340
+            r.coll_fin = r.coll_seen + (cc >> 16);
+            if (r.ctl && r.coll_seen > 0) lds_add(&sh.acc_collisions, r.coll_seen);   // ref :337
+            if (r.p < c.exit_p || r.coll_seen > 0) {                              // ref :341-349
+                r.del = 1;
+                if (r.coll_seen > 0) {
+                    if (r.ctl) r.reward = -10;
+                    else {                                                        // reward[-1] of someone else
+                        int pv = mask_prev<NW>(sh.m_ctl, t);
+                        if (pv >= 0) sh.rew_ovr[pv] = 1;
+                    }
+                }
+                r.meta |= M_DONE;
+                r.hdr = -1; sh.hdr[t] = -1;
+            } else if (r.p < 0 && (r.meta & M_CONTROL)) {                         // ref :350-359
+                r.fin = 1;
+                r.meta |= M_DONE | M_FINISH;
+                r.meta &= ~(M_CONTROL | M_LOCK);
+                r.hdr = -1; sh.hdr[t] = -1;
+                r.reward = 5;
+                lds_add(&sh.acc_passed_steps, r.step);
+            }
+        }
+        vote<NW>(sh.m_del, t, r.del);
+        vote<NW>(sh.m_fin, t, r.fin);
+        vote<NW>(sh.m_ctlnow, t, r.alive && !r.del && (r.meta & M_CONTROL));
+        vote<NW>(sh.m_coll, t, r.alive && r.ctl && r.coll_seen > 0);              // main.py:410-412
+        vote<NW>(sh.m_spawn, t, t < NL && sh.hd.current_time >= sh.next_arr[t < NL ? t : 0]);   // ref :379
+    }
+
+    // ============================================================== LOCK: dead-lock scan + reductions
+    static PVE_HD void ph_lock(const Const &c, int t, Sh &sh, Regs &r)
+    {
+        if (r.alive && r.ctl && sh.rew_ovr[t]) r.reward = -10;                    // ref :346 via reward[-1]
+        block_sum(sh.red_reward, t, (r.alive && r.ctl) ? r.reward : 0.0);
+        block_sum(sh.red_jerk, t, r.fin ? r.jerk_sum : 0.0);                      // ref :358
+        bool lead = false;
+        if (r.alive && !r.del && (r.meta & M_CONTROL)) {                          // ref :365-370
+            int cur = t, len = 0;
+            bool found = false;
+            for (int hop = 0; hop < 10; hop++) {                                  // ref :1470-1478
+                cur = sh.hdr[cur];
+                if (cur < 0) break;
+                if (cur == t) { found = true; len = hop + 1; break; }
+            }
+            if (found) {
+                int mn = t; cur = t;
+                for (int q = 0; q < len; q++) { cur = sh.hdr[cur]; mn = cur < mn ? cur : mn; }
+                lead = (mn == t);                         // the first member in order discovers the cycle
+            }
+            if (lead) {
+                // records [vir_dis(o), o, header(o)] sorted ascending (ref :1486-1493); members are
+                // distinct so (vir_dis, slot) is a strict order.  Selection sort by repeated walks.
+                double last_d = -INFINITY; int last_o = -1;
+                double sum = 0, best_d = 0; int best_o = -1;
+                for (int s = 0; s < len; s++) {
+                    double md = INFINITY; int mo = 0x7fffffff;
+                    cur = t;
+                    for (int q = 0; q < len; q++) {
+                        double d = sh.virdis[cur];
+                        bool gt_last = d > last_d || (d == last_d && cur > last_o);
+                        if (gt_last && (d < md || (d == md && cur < mo))) { md = d; mo = cur; }
+                        cur = sh.hdr[cur];
+                    }
+                    sum = sum + md;
+                    if (s == 0) { best_d = md; best_o = mo; }
+                    last_d = md; last_o = mo;
+                }
+                cur = t;
+                for (int q = 0; q < len; q++) { sh.lockf[cur] = 1; cur = sh.hdr[cur]; }   // ref :1482
+                if (best_d < c.collision_thr || sum / (double)len < c.lock_mean_thr) {    // ref :1495-1497
+                    sh.locka[best_o] = 1;
+                    sh.locka[sh.hdr[best_o]] = -1;
+                }
+            }
+        }
+        vote<NW>(sh.m_lead, t, lead);
+    }
+    // NOTE: if the tightest record's header is the tightest vehicle itself (1-cycle) the reference
+    // writes +1 then -1; a vehicle is never its own predecessor, so cycles have length >= 2.
+
+    // ============================================================== FIN: re-pack + write-back
+    template <class R> static PVE_HD void store_slot(const Params &P, size_t g, const R &r, int meta, int hdr_word)
+    {
+        P.f64[F_P][g] = r.p; P.f64[F_V][g] = r.v; P.f64[F_A][g] = r.a; P.f64[F_JERK][g] = r.jerk;
+        P.f64[F_JERK_SUM][g] = r.jerk_sum; P.f64[F_VIR_DIS][g] = r.vir_dis; P.f64[F_CLOSER_P][g] = r.closer_p;
+        P.i32[I_ID][g] = r.id; P.i32[I_SEQ][g] = r.seq; P.i32[I_VNUM][g] = r.vnum;
+        P.i32[I_STEP][g] = r.step; P.i32[I_COUNT][g] = r.count; P.i32[I_META][g] = meta;
+        P.i32[I_HDR][g] = hdr_word;
+    }
+    static PVE_HD int pack_lanej(const EnvHeader &hd, int slot)
+    {
+        if (slot < 0) return -1;
+        int l = slot_lane(hd, slot);
+        return (l << 16) | (slot - hd.lane_start[l]);
+    }
+
+    static PVE_HD void ph_final(const Const &c, const Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        EnvHeader &gh = P.headers[env];
+        const int N = sh.hd.n_alive;
+        const size_t gpre = (size_t)env * CAP + t;
+        const bool fused = (P.mode == MODE_FUSED);
+        // ---- spawn set (ref :361, :378-433); a full env defers the spawn (cursor not advanced)
+        const unsigned want = (unsigned)(sh.m_spawn[0] & 0xFFFull);
+        unsigned sp = 0; int room = CAP - N;
+#pragma unroll
+        for (int l = 0; l < NL; l++) if ((want >> l) & 1) { if (room > 0) { sp |= 1u << l; room--; } }
+        const int n_over = __builtin_popcount(want) - __builtin_popcount(sp);
+        // ---- keep mask: FUSED drops delete_veh now, SCENE keeps everybody (marked M_DEL)
+        u64 keep[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) keep[k] = fused ? (sh.m_alive[k] & ~sh.m_del[k]) : sh.m_alive[k];
+        // ---- per-slot meta
+        int meta = 0, hdr_word = -1, new_slot = -1;
+        if (r.alive) {
+            int coll = r.coll_fin > M_COLL_MASK ? M_COLL_MASK : r.coll_fin;
+            meta = (r.meta & (M_CONTROL | M_FINISH | M_DONE)) | M_ALIVE | (coll << M_COLL_SHIFT);
+            if (sh.lockf[t]) meta |= M_LOCK;
+            if (sh.locka[t] > 0) meta |= M_LOCKA_POS;
+            if (sh.locka[t] < 0) meta |= M_LOCKA_NEG;
+            if (r.del) meta |= M_DEL;
+            hdr_word = pack_lanej(sh.hd, r.hdr);
+            if (mask_test(keep, t)) {
+                new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
+                store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word);
+            }
+        }
+        // ---- new lane starts
+        int n_post;
+        {
+            int ls12 = mask_below<NW>(keep, sh.hd.lane_start[NL]) + __builtin_popcount(sp);
+            n_post = ls12;
+        }
+        if (t <= NL) {
+            int ls = mask_below<NW>(keep, sh.hd.lane_start[t]) + __builtin_popcount(sp & ((1u << t) - 1u));
+            gh.lane_start[t] = ls;
+        }
+        // ---- spawned vehicles (one per lane at most), ref :395-433
+        if (t < NL && ((sp >> t) & 1)) {
+            int slot = mask_below<NW>(keep, sh.hd.lane_start[t + 1]) + __builtin_popcount(sp & ((1u << t) - 1u));
+            Regs nv;
+            nv.p = c.spawn_p[t % 3]; nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
+            nv.vir_dis = 100; nv.closer_p = 150;
+            nv.id = sh.hd.id_seq + __builtin_popcount(sp & ((1u << t) - 1u));
+            nv.seq = sh.hd.veh_rec[t];
+            nv.vnum = sh.hd.lane_start[t + 1] - sh.hd.lane_start[t];
+            nv.step = 0; nv.count = 0;
+            size_t gs = (size_t)env * CAP + slot;
+            store_slot(P, gs, nv, M_CONTROL | M_ALIVE, -1);
+            if (P.out.obs_post) {
+                double *o = P.out.obs_post + gs * OBSW;
+                for (int k = 0; k < OBSW; k++) o[k] = 0.0;
+            }
+            gh.veh_rec[t] = sh.hd.veh_rec[t] + 1;
+        }
+        // ---- clear the tail so stale slots never look alive
+        if (t >= n_post) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
+        // ---- header
+        if (t < NL) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
+        const int n_ctl = mask_count<NW>(sh.m_ctl);
+        const int n_lock = mask_count<NW>(sh.m_lead);
+        const int n_fin = mask_count<NW>(sh.m_fin);
+        const int n_del = mask_count<NW>(sh.m_del);
+        if (t == 0) {
+            double sr = 0, sj = 0;
+#if PVE_DEVICE_CODE
+            for (int k = 0; k < NW; k++) { sr += sh.red_reward[k]; sj += sh.red_jerk[k]; }
+#else
+            sr = sh.red_reward[0]; sj = sh.red_jerk[0];
+#endif
+            gh.current_time = sh.hd.current_time;
+            gh.n_alive = n_post;
+            gh.id_seq = sh.hd.id_seq + __builtin_popcount(sp);
+            gh.passed = sh.hd.passed + n_fin;                                     // ref :356
+            gh.passed_step_total = sh.hd.passed_step_total + sh.acc_passed_steps; // ref :359
+            gh.head_valid = sh.hd.head_valid;
+            gh.sum_reward = sh.hd.sum_reward + sr;
+            gh.sum_jerk = sh.hd.sum_jerk + sj;
+            gh.alive_steps = sh.hd.alive_steps + N;
+            gh.ctl_steps = sh.hd.ctl_steps + n_ctl;
+            gh.ticks = sh.hd.ticks + 1;
+            gh.collided = sh.hd.collided + mask_count<NW>(sh.m_coll);
+            gh.locks = sh.hd.locks + n_lock;
+            gh.overflow = sh.hd.overflow + n_over;
+            if (P.out.env_out) {
+                int *eo = P.out.env_out + (size_t)env * 8;
+                eo[0] = N; eo[1] = n_ctl; eo[2] = sh.acc_collisions;
+                eo[3] = n_lock; eo[4] = n_del; eo[5] = n_fin; eo[6] = __builtin_popcount(sp); eo[7] = n_post;
+            }
+        }
+        // ---- per-tick outputs, pre-compaction indexing
+        if (P.out.flags) {
+            int f = 0;
+            if (r.alive) {
+                f = 0x01 | (r.ctl ? 0x02 : 0) | ((r.meta & M_DONE) ? 0x04 : 0) | (r.del ? 0x08 : 0) |
+                    (r.fin ? 0x10 : 0) | (sh.lockf[t] ? 0x20 : 0) | (r.ctl ? (r.coll_seen << 8) : 0);
+            }
+            P.out.flags[gpre] = f;
+        }
+        if (P.out.reward) P.out.reward[gpre] = (r.alive && r.ctl) ? r.reward : 0.0;
+        if (P.out.lanej) P.out.lanej[gpre] = r.alive ? ((r.lane << 16) | r.j) : -1;
+        if (P.out.new_slot) P.out.new_slot[gpre] = new_slot;
+        if (P.out.nbr) {
+            int *nb = P.out.nbr + gpre * NNB;
+#pragma unroll
+            for (int k = 0; k < NNB; k++) nb[k] = (r.alive && r.ctl) ? pack_lanej(sh.hd, r.kr[k]) : -1;
+        }
+        if (r.alive && r.ctl && (P.out.obs_pre || (P.out.obs_post && new_slot >= 0))) {
+            // row 0 of the state, ref :1325-1337
+            double row[OBSW];
+            row[0] = r.p; row[1] = r.v; row[2] = r.a; row[3] = (double)r.lane;
+#pragma unroll
+            for (int k = 0; k < NNB; k++) {
+                const int x = r.kr[k];
+                if (x >= 0) {
+                    row[4 + 4 * k] = r.kv[k]; row[5 + 4 * k] = sh.v[x]; row[6 + 4 * k] = sh.a[x];
+                    row[7 + 4 * k] = (double)slot_lane(sh.hd, x);
+                } else {
+                    row[4 + 4 * k] = 0; row[5 + 4 * k] = 0; row[6 + 4 * k] = 0; row[7 + 4 * k] = 0;
+                }
+            }
+            if (P.out.obs_pre) {
+                double *o = P.out.obs_pre + gpre * OBSW;
+#pragma unroll
+                for (int k = 0; k < OBSW; k++) o[k] = row[k];
+            }
+            if (P.out.obs_post && new_slot >= 0) {
+                double *o = P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+#pragma unroll
+                for (int k = 0; k < OBSW; k++) o[k] = row[k];
+            }
+        }
+    }
+    // ============================================================== COMPACT (delete_vehicle only)
+    static PVE_HD void ph_c_load(const Params &P, int env, int t, Sh &sh, CRegs &r)
+    {
+        const EnvHeader &gh = P.headers[env];
+        {
+            const int *src = (const int *)&gh;
+            int *dst = (int *)&sh.hd;
+            for (int w = t; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];
+        }
+        const int N = gh.n_alive;
+        const size_t g = (size_t)env * CAP + t;
+        r.alive = t < N;
+        r.meta = 0;
+        if (r.alive) {
+            r.p = P.f64[F_P][g]; r.v = P.f64[F_V][g]; r.a = P.f64[F_A][g]; r.jerk = P.f64[F_JERK][g];
+            r.jerk_sum = P.f64[F_JERK_SUM][g]; r.vir_dis = P.f64[F_VIR_DIS][g]; r.closer_p = P.f64[F_CLOSER_P][g];
+            r.id = P.i32[I_ID][g]; r.seq = P.i32[I_SEQ][g]; r.vnum = P.i32[I_VNUM][g];
+            r.step = P.i32[I_STEP][g]; r.count = P.i32[I_COUNT][g]; r.meta = P.i32[I_META][g];
+            r.hdr_word = P.i32[I_HDR][g];
+            if (P.out.obs_post) {
+                const double *o = P.out.obs_post + g * OBSW;
+                for (int k = 0; k < OBSW; k++) r.obsrow[k] = o[k];
+            }
+        }
+        vote<NW>(sh.m_keep, t, r.alive && !(r.meta & M_DEL));
+    }
+    static PVE_HD void ph_c_store(const Params &P, int env, int t, Sh &sh, CRegs &r)
+    {
+        EnvHeader &gh = P.headers[env];
+        const int n_post = mask_count<NW>(sh.m_keep);
+        if (r.alive && !(r.meta & M_DEL)) {
+            int ns = mask_below<NW>(sh.m_keep, t);
+            size_t g = (size_t)env * CAP + ns;
+            store_slot(P, g, r, r.meta, r.hdr_word);
+            if (P.out.obs_post) {
+                double *o = P.out.obs_post + g * OBSW;
+                for (int k = 0; k < OBSW; k++) o[k] = r.obsrow[k];
+            }
+        }
+        if (t <= NL) gh.lane_start[t] = mask_below<NW>(sh.m_keep, sh.hd.lane_start[t]);
+        if (t >= n_post) { P.i32[I_META][(size_t)env * CAP + t] = 0; P.i32[I_ID][(size_t)env * CAP + t] = -1; }
+        if (t == 0) gh.n_alive = n_post;
+    }
+};
+
+// ================================================================== reset / warm-up, ref :196-220
+// One thread per environment: advance the clock (repeated += deltaT) and spawn (lane order) until
+// at least one vehicle exists.  cap_ticks bounds the loop for streams that never deliver.
+template <int CAP>
+PVE_HD void reset_env(const Const &c, const Params &P, int env, int cap_ticks)
+{
+    EnvHeader h;
+    {
+        int *z = (int *)&h;
+        for (int w = 0; w < (int)(sizeof(EnvHeader) / 4); w++) z[w] = 0;
+    }
+    for (int l = 0; l < NL; l++) { h.head_lane[l] = -1; h.head_j[l] = -1; }
+    const double *arr = P.arrivals + (size_t)env * P.arr_env_stride;
+    int n = 0;
+    int lane_of[NL];
+    for (int it = 0; it < cap_ticks && n == 0; it++) {
+        h.current_time += c.deltaT;
+        for (int l = 0; l < NL; l++) {
+            if (h.veh_rec[l] < P.rows && h.current_time >= arr[(size_t)h.veh_rec[l] * NL + l] && n < CAP) {
+                lane_of[n] = l;
+                n++;
+                h.veh_rec[l] += 1;
+            }
+        }
+    }
+    for (int s = 0; s < CAP; s++) {
+        size_t g = (size_t)env * CAP + s;
+        if (s < n) {
+            int l = lane_of[s];
+            P.f64[F_P][g] = c.spawn_p[l % 3]; P.f64[F_V][g] = c.v0; P.f64[F_A][g] = 0; P.f64[F_JERK][g] = 0;
+            P.f64[F_JERK_SUM][g] = 0; P.f64[F_VIR_DIS][g] = 100; P.f64[F_CLOSER_P][g] = 150;
+            P.i32[I_ID][g] = s; P.i32[I_SEQ][g] = 0; P.i32[I_VNUM][g] = 0; P.i32[I_STEP][g] = 0;
+            P.i32[I_COUNT][g] = 0; P.i32[I_META][g] = M_CONTROL | M_ALIVE; P.i32[I_HDR][g] = -1;
+        } else {
+            P.f64[F_P][g] = 0; P.f64[F_V][g] = 0; P.f64[F_A][g] = 0; P.f64[F_JERK][g] = 0;
+            P.f64[F_JERK_SUM][g] = 0; P.f64[F_VIR_DIS][g] = 0; P.f64[F_CLOSER_P][g] = 0;
+            P.i32[I_ID][g] = -1; P.i32[I_SEQ][g] = 0; P.i32[I_VNUM][g] = 0; P.i32[I_STEP][g] = 0;
+            P.i32[I_COUNT][g] = 0; P.i32[I_META][g] = 0; P.i32[I_HDR][g] = -1;
+        }
+    }
+    {
+        int s = 0;
+        for (int l = 0; l <= NL; l++) {
+            h.lane_start[l] = s;
+            while (s < n && l < NL && lane_of[s] == l) s++;
+        }
+    }
+    h.n_alive = n;
+    h.id_seq = n;
+    P.headers[env] = h;
+}
+
+}  // namespace pve

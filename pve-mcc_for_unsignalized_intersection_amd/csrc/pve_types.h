@@ -1,0 +1,110 @@
+// pve_types.h -- internal data layout shared by the HIP kernels, the C-ABI host code and the
+// host-side phase emulator used by the CPU tests (tests/emu).  Not part of the public ABI.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PVE_HD __host__ __device__ __forceinline__
+#else
+#define PVE_HD inline
+#endif
+
+namespace pve {
+
+constexpr int NL = 12;        // lanes (12-lane geometry only, ref :146-186)
+constexpr int OBSW = 28;      // observation row width, ref :1295
+constexpr int NNB = 6;        // neighbours, ref :1324
+
+// meta word of a vehicle slot (persistent)
+constexpr int M_CONTROL = 0x1, M_FINISH = 0x2, M_DONE = 0x4, M_LOCK = 0x8;
+constexpr int M_LOCKA_POS = 0x10, M_LOCKA_NEG = 0x20;   // lock_a = +1 / -1 (ref :1496-1497)
+constexpr int M_DEL = 0x40;                             // in delete_veh, awaiting delete_vehicle() (ref :348)
+constexpr int M_ALIVE = 0x80;
+constexpr int M_COLL_SHIFT = 8, M_COLL_MASK = 0xFFFF;   // veh["collision"] (ref :333-334)
+
+// launch modes
+constexpr int MODE_FUSED = 0;     // step* + scene_update + delete_vehicle
+constexpr int MODE_SCENE = 1;     // step* + scene_update (Done vehicles stay, marked M_DEL)
+constexpr int MODE_COMPACT = 2;   // delete_vehicle only
+
+// Geometry / limits, computed once on the host exactly as the reference's constructor does
+// (ref :21-45, :148-152, :182-186) and passed by value to the kernels.
+struct Const {
+    double deltaT, dt2;            // dt2 = pow(deltaT, 2) (ref :1529)
+    double vm, vM, am, aM, v0;
+    double abs_am, two_abs_am;     // |am|, 2*|am| (ref :1513-1514)
+    double aM_minus_am;            // float(aM - am) (ref :319)
+    double collision_thr, lock_mean_thr;   // thr, thr + 3 (ref :1471, 1495)
+    double exit_p;                 // -dis_ctl + int((12+1)/2)*cw (ref :341-342)
+    double cw;
+    double inbox[3];               // lane_info[m][1] (ref :149-151)
+    double spawn_p[3];             // sum(lane_info[m][0:2]) (ref :395)
+    // get_virtual_distance table (ref :733-803): ego movement m (0 left, 1 straight), k-th entry
+    // of lane2lane[ego]:  delta = (p1 - A) + B ; chosen iff delta > 0 ; vd = C + delta
+    double vdA[2][4], vdB[2][4], vdC[2][4];
+    double rot_cos[4], rot_sin[4]; // cos/sin(3.141593/2 * approach) (ref :1251, 1287-1288)
+    double arc_k;                  // 3.141593 (ref :1259, 1277)
+    int8_t l2l[NL][4];             // lane2lane (ref :153-166), -1 = none
+    int8_t l2l_inv[NL][4];         // position of ego inside lane2lane[l2l[ego][k]]
+};
+
+// Per-environment header (device memory, one per env).
+struct EnvHeader {
+    double current_time;           // ref :196, 223
+    double sum_reward, sum_jerk;   // metrics
+    long long alive_steps, ctl_steps, ticks;
+    int32_t n_alive;
+    int32_t lane_start[NL + 1];    // slot range of each lane; lane counts = veh_num (ref :206)
+    int32_t veh_rec[NL];           // arrival cursors (ref :207)
+    int32_t id_seq, passed, passed_step_total;   // ref :212, 197, 198
+    int32_t head_valid;            // bit d: len(virtual_lane_4[d]) > 0 at its last rebuild (ref :1517)
+    int16_t head_lane[NL], head_j[NL];           // virtual_lane_4[d][0][1:3] (stale by design)
+    int32_t collided, locks, overflow;
+    int32_t pad_;
+};
+
+// Persistent per-slot SoA field indices
+enum { F_P = 0, F_V, F_A, F_JERK, F_JERK_SUM, F_VIR_DIS, F_CLOSER_P, NF64 };
+enum { I_ID = 0, I_SEQ, I_VNUM, I_STEP, I_COUNT, I_META, I_HDR, NI32 };
+
+struct Outputs {        // mirrors pve_outputs (include/pve_env.h)
+    double *obs_post, *obs_pre, *state_pre;
+    const double *obs_prev_post;
+    double *reward;
+    int32_t *flags, *lanej, *nbr, *new_slot, *env_out;
+};
+
+struct Params {
+    EnvHeader *headers;
+    double *f64[NF64];           // each [n_envs][cap]
+    int32_t *i32[NI32];
+    const double *actions;       // [n_envs][cap] or null (all zero)
+    const double *arrivals;      // [rows][12] per env
+    long long arr_env_stride;    // doubles between envs (0 = shared stream)
+    int32_t rows;
+    int32_t n_envs;
+    int32_t mode;
+    int32_t mask_uncontrolled;   // 1: actions of uncontrolled slots are forced to 0 (main.py:401)
+    Outputs out;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Layout {
+    size_t off_headers, off_f64[NF64], off_i32[NI32], total;
+};
+
+inline Layout make_layout(int n_envs, int cap)
+{
+    Layout L;
+    size_t o = 0;
+    L.off_headers = o; o = align_up(o + sizeof(EnvHeader) * (size_t)n_envs, 256);
+    for (int k = 0; k < NF64; k++) { L.off_f64[k] = o; o = align_up(o + 8 * (size_t)n_envs * cap, 256); }
+    for (int k = 0; k < NI32; k++) { L.off_i32[k] = o; o = align_up(o + 4 * (size_t)n_envs * cap, 256); }
+    L.total = o;
+    return L;
+}
+
+}  // namespace pve

@@ -1,0 +1,133 @@
+"""Adapters that drive the product's BatchedIntersections (real HIP library on a GPU, or the CPU
+test emulator of the same kernels) and emit the canonical tick records of oracle/record.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+import pve_mcc_amd
+from pve_mcc_amd import _capi
+from pve_mcc_amd.batched import ALL_OUTPUTS, BatchedIntersections
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+_emu = None
+
+
+def emulator_lib():
+    """CPU test emulator of the HIP kernels (tests/emu). Test infrastructure only."""
+    global _emu
+    if _emu is None:
+        subprocess.check_call(["make", "-C", EMU_DIR, "-s", "libpveenv_emu.so"])
+        _emu = _capi._declare(C.CDLL(os.path.join(EMU_DIR, "libpveenv_emu.so")))
+    return _emu
+
+
+def make_batch(arrivals, n_envs=1, capacity=128, backend="emu", outputs=ALL_OUTPUTS, **cfg):
+    if backend == "emu":
+        return BatchedIntersections(n_envs, capacity, arrivals, device="cpu", outputs=outputs,
+                                    _lib=emulator_lib(), **cfg)
+    return BatchedIntersections(n_envs, capacity, arrivals, device="cuda", outputs=outputs, **cfg)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def decode_lanej(x):
+    x = np.asarray(x, np.int64)
+    out = np.stack([np.where(x < 0, -1, x >> 16), np.where(x < 0, -1, x & 0xFFFF)], axis=-1)
+    return out.astype(np.int32)
+
+
+def state_snapshot(b, env):
+    """(veh_i [N,15], veh_f [N,7]) of env from the persistent SoA state + header."""
+    info = b.read_env(env)
+    n = info.n_alive
+    counts = list(info.lane_count)
+    lane = np.repeat(np.arange(12), counts).astype(np.int32)
+    j = np.concatenate([np.arange(c) for c in counts]).astype(np.int32) if n else np.zeros(0, np.int32)
+    f = {k: _np(b.state_field(k)[env, :n]) for k in ("p", "v", "a", "jerk", "jerk_sum", "vir_dis", "closer_p")}
+    i = {k: _np(b.state_field(k)[env, :n]) for k in ("id", "seq", "vnum", "step", "count", "meta", "hdr")}
+    meta = i["meta"].astype(np.int64)
+    hdr = decode_lanej(i["hdr"])
+    lock_a = np.where(meta & 0x10, 1, np.where(meta & 0x20, -1, 0))
+    veh_i = np.stack([lane, j, i["id"], i["seq"], i["vnum"], meta & 1, (meta >> 1) & 1, (meta >> 2) & 1,
+                      (meta >> 8) & 0xFFFF, i["step"], i["count"], (meta >> 3) & 1, lock_a,
+                      hdr[:, 0] if n else np.zeros(0), hdr[:, 1] if n else np.zeros(0)], axis=1).astype(np.int32) \
+        if n else np.zeros((0, 15), np.int32)
+    veh_f = np.stack([f[k] for k in ("p", "v", "a", "jerk", "jerk_sum", "vir_dis", "closer_p")], axis=1) \
+        if n else np.zeros((0, 7))
+    return info, veh_i, veh_f
+
+
+class SplitEnv:
+    """One env of a batch driven through the split protocol (scene_update -> snapshot -> compact),
+    which reproduces the reference's call sequence and lets the pre-compaction state be compared."""
+
+    def __init__(self, batch, env=0):
+        self.b = batch
+        self.env = env
+        self.tick_no = 0
+        if not batch._is_reset:
+            batch.reset()
+
+    def alive_view(self):
+        b, e = self.b, self.env
+        n = b.read_env(e).n_alive
+        ids = _np(b.state_field("id")[e, :n]).astype(np.int64)
+        ctl = (_np(b.state_field("meta")[e, :n]) & 1).astype(np.int32)
+        obs0 = _np(b.obs[e, :n]).copy()
+        obs0[ctl == 0] = 0      # rows of uncontrolled slots are unspecified
+        return ids, ctl, obs0
+
+    def tick(self, actions, want_state=False, others=None):
+        b, e = self.b, self.env
+        acts = torch.zeros(b.n_envs, b.capacity, dtype=torch.float64)
+        if others is not None:
+            acts[:] = torch.as_tensor(others)
+        acts[e, :len(actions)] = torch.as_tensor(np.asarray(actions, np.float64))
+        out = b.scene_update(acts.to(b.device))
+        b.synchronize()
+        rec = self.record(out, want_state)
+        b.compact()
+        self.tick_no += 1
+        return rec
+
+    def record(self, out, want_state=False):
+        b, e = self.b, self.env
+        eo = _np(out["env_out"][e])
+        n_pre = int(eo[0])
+        flags = _np(out["flags"][e, :n_pre]).astype(np.int64)
+        ctl = (flags & _capi.F_CTL) != 0
+        lanej = decode_lanej(_np(out["lanej"][e, :n_pre]))
+        rec = dict(tick=self.tick_no)
+        rec["ids"] = lanej[ctl]
+        rec["nbr"] = decode_lanej(_np(out["nbr"][e, :n_pre]))[ctl].reshape(-1, 6, 2)
+        rec["reward"] = _np(out["reward"][e, :n_pre])[ctl].astype(np.float64)
+        rec["obs0"] = _np(out["obs_pre"][e, :n_pre])[ctl].astype(np.float64).reshape(-1, 28)
+        if want_state and "state_pre" in out:
+            st = _np(out["state_pre"][e, :n_pre])[ctl].astype(np.float64).reshape(-1, 7, 28)
+            rec["state"] = st
+            rec["act7"] = np.ascontiguousarray(st[:, :, 2])
+        else:
+            rec["state"] = None
+            rec["act7"] = None
+        rec["coll_pv"] = (flags[ctl] >> 8).astype(np.int32)
+        rec["collisions"] = int(eo[2])
+        rec["lock"] = int(eo[3])
+        rec["deleted"] = lanej[(flags & _capi.F_DELETED) != 0]
+        info, veh_i, veh_f = state_snapshot(b, e)
+        new_slot = _np(out["new_slot"][e, :n_pre])
+        fin = (flags & _capi.F_FINISHED) != 0
+        rec["jerks"] = veh_f[new_slot[fin], 4].astype(np.float64) if fin.any() else np.zeros(0)
+        rec["veh_i"], rec["veh_f"] = veh_i, veh_f
+        rec["time"] = float(info.current_time)
+        rec["id_seq"], rec["passed"], rec["passed_step_total"] = info.id_seq, info.passed_veh, info.passed_veh_step_total
+        rec["veh_num"] = np.array(list(info.lane_count), np.int32)
+        rec["veh_rec"] = np.array(list(info.veh_rec), np.int32)
+        rec["heads"] = np.stack([np.array(list(info.head_valid)), np.array(list(info.head_lane)),
+                                 np.array(list(info.head_j))], axis=1).astype(np.int32)
+        return rec
