@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the fused HIP tick at BASELINE.json's headline config
+(4096 parallel 12-lane intersections x 128 vehicle slots per GPU, synthetic Poisson arrivals at
+1100 veh/h/lane), weak-scaled env-parallel over N GPUs (one process per GPU, no data-path collective;
+one RCCL all-gather of the metrics vector after the timed region).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one fused tick (all step() calls + scene_update() + delete_vehicle()) of every env of the
+rank = one kernel launch.  Inputs (arrival streams, action pool) are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG_FP64 = 380.0      # algorithmic bytes per vehicle-slot-step, FP64 layout
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
+N_POOL = 16
+
+
+def action_pool(n_envs, cap, seed):
+    """Synthetic action tape resident in HBM: pool[k][env][slot] = float32(sin(0.37*u + 0.05*k*7))-like
+    values in [-1, 1] (the SURVEY §8d 'sin, A=1' pattern, indexed by slot so that it needs no feedback)."""
+    rng = np.random.default_rng(seed)
+    phase = rng.uniform(0, 2 * np.pi, size=(1, n_envs, cap))
+    k = np.arange(N_POOL, dtype=np.float64)[:, None, None]
+    a = np.sin(phase + 0.37 * np.arange(cap)[None, None, :] + 0.05 * 7 * k)
+    return a.astype(np.float32).astype(np.float64)
+
+
+def cpu_baseline(arr, pool, cap, warm, ticks):
+    """The CPU oracle (oracle/pve_oracle.c, a plain-C port of the reference algorithm) timed on this
+    host's cores on a bounded sample of the same workload: the first `n` envs of the same arrival
+    tensor with the same action pool, one env per thread-task, all cores busy."""
+    from oracle.oracle import OracleEnv
+    cores = os.cpu_count() or 1
+    n = min(arr.shape[0], max(cores * 8, 16))
+    envs = [OracleEnv(arr[e]) for e in range(n)]
+    res = [None] * n
+    nxt = [0]
+    lock = threading.Lock()
+
+    def worker(phase, nt, t0):
+        while True:
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= n:
+                return
+            res[i] = envs[i].run_pool(nt, pool[:, i, :], t0)
+
+    def run(nt, t0):
+        nxt[0] = 0
+        ths = [threading.Thread(target=worker, args=(0, nt, t0)) for _ in range(cores)]
+        t = time.perf_counter()
+        [x.start() for x in ths]
+        [x.join() for x in ths]
+        return time.perf_counter() - t
+
+    run(warm, 0)
+    dt = run(ticks, warm)
+    alive = sum(r[0] for r in res)
+    return dict(value=n * cap * ticks / dt, unit="env-steps/s", cores=cores, kind="port",
+                alive_steps_per_s=alive / dt,
+                sample="%d envs x %d ticks (after %d warm-up ticks) of the same synthetic workload, %d threads, "
+                       "%.2f s wall" % (n, ticks, warm, cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--capacity", type=int, default=128)
+    ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default 1100 at cap 128, 500 at cap 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import pve_mcc_amd
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    from pve_mcc_amd.distributed import gather_metrics
+
+    cap, n_envs = args.capacity, args.envs
+    rate = args.rate or (1100.0 if cap == 128 else 500.0)
+    K, W = args.steps, args.warmup
+    horizon = (K + W) * 0.1 + 20.0
+    # weak scaling: every rank owns its own n_envs environments (global env index = rank*n_envs + e)
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=horizon, seed=20250213 + rank * n_envs)
+    pool_np = action_pool(n_envs, cap, seed=99 + rank)
+    outputs = tuple(x for x in args.outputs.split(",") if x)
+    env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs)
+    pool = torch.as_tensor(pool_np, device=dev)
+    env.reset()
+    for t in range(W):
+        env.step(pool[t % N_POOL])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    m0 = env.metrics()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                      # same stream the kernels are launched on (torch current stream)
+    for t in range(W, W + K):
+        env.step(pool[t % N_POOL])
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    m1 = env.metrics()
+    delta = {k: m1[k] - m0[k] for k in m1}
+    per_rank, tot = gather_metrics(delta, dev)          # the single RCCL all-gather (metrics only)
+
+    if rank == 0:
+        slot_steps = float(cap) * n_envs * K * world
+        value = slot_steps / wall
+        kern_s = gpu_ms * 1e-3 / K
+        achieved = B_ALG_FP64 * cap * n_envs / kern_s / 1e9
+        line = {
+            "metric": "env-steps/sec (vehicles x envs x steps/s) at 128 veh x 4096 envs",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d parallel 12-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
+                                   "arrivals %.0f veh/h/lane, sin action pool, fused step+scene_update+delete tick"
+                                   % (n_envs, cap, rate),
+                       "envs_per_gpu": n_envs, "capacity": cap, "parallelism": "env-parallel x%d" % world,
+                       "outputs": list(outputs)},
+            "alive_steps_per_s": tot["alive_steps"] / wall,
+            "ctl_steps_per_s": tot["ctl_steps"] / wall,
+            "mean_alive_per_env": tot["alive_steps"] / (K * n_envs * world),
+            "overflow": tot["overflow"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_tick<%d>" % cap, "kernel_ms": kern_s * 1e3,
+                         "alg_bytes_per_slot_step": B_ALG_FP64},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, min(W, 300), min(K, 200))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,8 @@ def lib():
     L.pvo_get_virtual_distance.argtypes = [vp, C.c_int, C.c_int, C.c_double, dp]
     L.pvo_run.restype = C.c_long
     L.pvo_run.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_long)]
+    L.pvo_run_pool.restype = C.c_long
+    L.pvo_run_pool.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
     _lib = L
     return L
 
@@ -193,5 +195,14 @@ class OracleEnv:
         """Timing loop entirely in C (GIL released by ctypes). -> (alive_steps, ctl_steps)"""
         ctl = C.c_long(0)
         alive = self._L.pvo_run(self._h, int(ticks), int(policy), float(amp), int(tick0), C.byref(ctl))
+        self.tick_no += ticks
+        return int(alive), int(ctl.value)
+
+    def run_pool(self, ticks, pool, tick0=0):
+        """Timing loop with a per-slot action pool [n_pool, cap] (see pvo_run_pool)."""
+        pool = np.ascontiguousarray(pool, dtype=np.float64)
+        ctl = C.c_long(0)
+        alive = self._L.pvo_run_pool(self._h, int(ticks), pool.ctypes.data_as(C.POINTER(C.c_double)),
+                                     pool.shape[0], pool.shape[1], int(tick0), C.byref(ctl))
         self.tick_no += ticks
         return int(alive), int(ctl.value)

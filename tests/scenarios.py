@@ -1,0 +1,150 @@
+"""Parity scenarios shared by the CPU (emulated kernel) and GPU (real kernel) test files."""
+import numpy as np
+import torch
+
+from oracle.oracle import OracleEnv
+from oracle.record import close, compare_records, get_policy
+from pve_mcc_amd.arrivals import synthetic_arrivals
+from tests.hip_adapter import SplitEnv, _np, make_batch, state_snapshot
+
+STATE_F = ("p", "v", "a", "jerk", "jerk_sum", "vir_dis", "closer_p")
+STATE_I = ("id", "seq", "vnum", "step", "count", "meta", "hdr")
+
+
+def check_split_vs_oracle(case, backend, ticks, capacity=128, tol=1e-9):
+    orc = OracleEnv(case.arrive, **case.ctor)
+    b = make_batch(case.arrive, 1, capacity, backend, **case.ctor)
+    env = SplitEnv(b)
+    for t in range(min(ticks, case.ticks)):
+        va, ca, oa = orc.alive_view()
+        vb, cb, ob = env.alive_view()
+        assert np.array_equal(va, vb) and np.array_equal(ca, cb), "alive set differs at tick %d" % t
+        assert close(np.where(ca[:, None] != 0, oa, 0), ob, tol), "stored observation differs at tick %d" % t
+        acts = case.policy(t, va, ca, oa)
+        compare_records(orc.tick(acts), env.tick(acts), tol=tol, label=case.name)
+    assert b.metrics()["overflow"] == 0
+    return b
+
+
+def batches_equal(b1, b2, what):
+    """Persistent state + headers + observations of two batches are bit-identical."""
+    for e in range(b1.n_envs):
+        i1, i2 = b1.read_env(e), b2.read_env(e)
+        for f, _ in i1._fields_:
+            x, y = getattr(i1, f), getattr(i2, f)
+            x = list(x) if hasattr(x, "__len__") else x
+            y = list(y) if hasattr(y, "__len__") else y
+            assert x == y, "%s: env %d header field %s: %s vs %s" % (what, e, f, x, y)
+        n = i1.n_alive
+        for k in STATE_F + STATE_I:
+            x, y = _np(b1.state_field(k)[e, :n]), _np(b2.state_field(k)[e, :n])
+            assert np.array_equal(x, y), "%s: env %d state %s differs" % (what, e, k)
+        ctl = (_np(b1.state_field("meta")[e, :n]) & 1) != 0
+        assert np.array_equal(_np(b1.obs[e, :n])[ctl], _np(b2.obs[e, :n])[ctl]), "%s: env %d obs differs" % (what, e)
+
+
+def check_fused_equals_split(case, backend, ticks, capacity=128):
+    """pve_step_all == pve_scene_update + pve_compact, bit for bit (same kernels, one launch)."""
+    bs = make_batch(case.arrive, 1, capacity, backend, **case.ctor)
+    bf = make_batch(case.arrive, 1, capacity, backend, **case.ctor)
+    bs.reset(); bf.reset()
+    batches_equal(bs, bf, "after reset")
+    for t in range(min(ticks, case.ticks)):
+        n = bs.read_env(0).n_alive
+        ids = _np(bs.state_field("id")[0, :n]).astype(np.int64)
+        ctl = _np(bs.state_field("meta")[0, :n]) & 1
+        acts = torch.zeros(1, capacity, dtype=torch.float64)
+        acts[0, :n] = torch.as_tensor(case.policy(t, ids, ctl))
+        acts = acts.to(bs.device)
+        o1 = {k: v.clone() for k, v in bs.scene_update(acts).items()}
+        bs.compact()
+        o2 = bf.step(acts)
+        for k in ("reward", "flags", "lanej", "nbr", "obs_pre", "env_out"):
+            x, y = _np(o1[k]), _np(o2[k])
+            if k == "env_out":
+                x, y = x[:, :7], y[:, :7]       # n_post differs by design (split counts before compaction)
+            if k == "obs_pre":
+                c = (_np(o1["flags"]) & 2) != 0
+                x, y = x[c], y[c]
+            assert np.array_equal(x, y), "tick %d: output %s differs between fused and split" % (t, k)
+        batches_equal(bs, bf, "tick %d" % t)
+
+
+def check_batch_independent(backend, n_envs, capacity, ticks, rate=500.0):
+    """Every env of a batch (own arrival stream, own action tape) evolves exactly like a lone oracle."""
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=11)
+    b = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "reward", "flags", "env_out", "new_slot"))
+    b.reset()
+    oracles = [OracleEnv(arr[e]) for e in range(n_envs)]
+    pols = [get_policy(p) for p in ("sin1", "zero", "sin2", "sin0.5", "sin3")]
+    for t in range(ticks):
+        acts = np.zeros((n_envs, capacity))
+        for e, o in enumerate(oracles):
+            vid, ctl, _ = o.alive_view()
+            acts[e, :len(vid)] = pols[e % len(pols)](t, vid, ctl)
+        out = b.step(torch.as_tensor(acts).to(b.device))
+        rew, flags, eo = _np(out["reward"]), _np(out["flags"]), _np(out["env_out"])
+        for e, o in enumerate(oracles):
+            n = o.n_alive
+            rec = o.tick(acts[e, :n])
+            ctl = (flags[e, :n] & 2) != 0
+            assert int(eo[e, 0]) == n and int(eo[e, 1]) == len(rec["ids"]), (t, e)
+            assert close(rec["reward"], rew[e, :n][ctl], 1e-9), "reward: tick %d env %d" % (t, e)
+            assert int(eo[e, 2]) == rec["collisions"] and int(eo[e, 3]) == rec["lock"], (t, e)
+            assert np.array_equal((flags[e, :n][ctl] >> 8), rec["coll_pv"]), (t, e)
+    for e, o in enumerate(oracles):
+        info, vi, vf = state_snapshot(b, e)
+        ovi, ovf, _ = o.vehicles()
+        assert np.array_equal(vi[:, :13], ovi[:, :13]), "final state ints, env %d" % e   # hdr is pre-compaction, skip
+        assert close(ovf, vf, 1e-9), "final state floats, env %d" % e
+    m = b.metrics()
+    assert m["ticks"] == ticks * n_envs and m["overflow"] == 0
+    return b
+
+
+def check_overflow(backend):
+    """A full env defers spawns (cursor not advanced, overflow counted) instead of corrupting state."""
+    rows = 400
+    arr = np.full((rows, 12), np.inf)
+    arr[:rows - 1, :] = (np.arange(rows - 1)[:, None] * 1.0 + 1.0)      # one vehicle per lane per second
+    b = make_batch(arr, 1, 64, backend, outputs=("obs_post", "env_out", "flags"))
+    b.reset()
+    seen_over = False
+    for t in range(200):
+        out = b.step(None)
+        info = b.read_env(0)
+        assert 0 <= info.n_alive <= 64
+        assert sum(info.lane_count) == info.n_alive
+        seen_over = seen_over or info.overflow > 0
+    assert seen_over, "the scenario was meant to overflow a 64-slot env"
+    n = b.read_env(0).n_alive
+    ids = _np(b.state_field("id")[0, :n])
+    assert len(set(ids.tolist())) == n, "duplicate vehicle ids after overflow"
+    assert b.metrics()["overflow"] > 0
+
+
+def check_empty_and_exhausted(backend):
+    """No arrivals at all: reset leaves the env empty and ticks only advance the clock; a stream that
+    runs dry stops spawning (cursor == rows is not an error)."""
+    arr = np.full((4, 12), np.inf)
+    b = make_batch(arr, 2, 64, backend, outputs=("obs_post", "env_out"))
+    b.reset()
+    assert b.read_env(0).n_alive == 0
+    t0 = b.read_env(0).current_time
+    for _ in range(5):
+        out = b.step(None)
+    assert b.read_env(1).n_alive == 0 and abs(b.read_env(1).current_time - (t0 + 0.5)) < 1e-9
+    arr2 = np.full((2, 12), np.inf)
+    arr2[0, 4] = 0.35
+    arr2[1, 4] = 0.95
+    b2 = make_batch(arr2, 1, 64, backend, outputs=("obs_post", "env_out"))
+    b2.reset()
+    info = b2.read_env(0)
+    assert info.n_alive == 1 and list(info.lane_count)[4] == 1 and abs(info.current_time - 0.4) < 1e-9
+    orc = OracleEnv(np.vstack([arr2, np.full((1, 12), np.inf)]))
+    for t in range(420):
+        b2.step(None)
+        orc.tick(np.zeros(orc.n_alive))
+    info = b2.read_env(0)
+    assert list(info.veh_rec)[4] == 2 and info.id_seq == 2
+    assert info.n_alive == orc.n_alive and info.passed_veh == 2

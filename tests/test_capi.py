@@ -1,0 +1,88 @@
+"""C-ABI library checks that need no GPU: libpveenv.so loads, exports every symbol that
+include/pve_env.h declares, and fails loudly (no CPU fallback) without a device; argument
+validation and call-sequence errors (exercised through the emulator build of the same C-ABI source)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import pve_mcc_amd
+from pve_mcc_amd import _capi
+from pve_mcc_amd.batched import BatchedIntersections
+from tests.hip_adapter import emulator_lib
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "pve_env.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pve_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    lib = _capi.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 17
+    for s in syms:
+        assert hasattr(lib, s), "libpveenv.so does not export %s" % s
+    assert sorted(_capi.EXPORTS) == syms, "binding and header disagree"
+    assert lib.pve_abi_version() == _capi.ABI_VERSION
+    assert lib.pve_workspace_bytes(4096, 128) > 4096 * 128 * 84
+    assert lib.pve_workspace_bytes(10, 100) == 0
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(_capi.PveConfig) == 9 * 8 + 8
+    assert C.sizeof(_capi.PveOutputs) == 10 * 8
+    assert C.sizeof(_capi.PveVehicle) == 7 * 8 + 17 * 4 + 4   # padded to 8
+    assert C.sizeof(_capi.PveEnvInfo) == 8 + 4 * (1 + 12 + 12 + 3 + 36 + 1) + 4
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_gpu():
+    lib = _capi.load_library()
+    cfg = _capi.PveConfig()
+    lib.pve_default_config(C.byref(cfg))
+    h = C.c_void_p()
+    rc = lib.pve_create(C.byref(cfg), 4, 64, 0, None, None, C.byref(h))
+    assert rc == -2, "pve_create must fail with PVE_ERR_NO_DEVICE on a box without a GPU"
+    assert b"no CPU fallback" in lib.pve_last_error()
+    with pytest.raises(_capi.PveError):
+        BatchedIntersections(2, 64, np.full((4, 12), np.inf), device="cpu")
+
+
+def test_argument_validation_and_call_order():
+    lib = emulator_lib()
+    cfg = _capi.PveConfig()
+    lib.pve_default_config(C.byref(cfg))
+    assert (cfg.deltaT, cfg.vm, cfg.vM, cfg.am, cfg.aM, cfg.v0, cfg.lane_cw, cfg.dis_ctl, cfg.collision_thr,
+            cfg.lane_num) == (0.1, 5, 13, -3, 3, 10, 2.5, 150, 2, 12)          # ref :21-23, main.py:104
+    h = C.c_void_p()
+    assert lib.pve_create(C.byref(cfg), 4, 100, 0, None, None, C.byref(h)) == -1
+    assert b"capacity" in lib.pve_last_error()
+    assert lib.pve_create(C.byref(cfg), 0, 64, 0, None, None, C.byref(h)) == -1
+    bad = _capi.PveConfig.from_buffer_copy(cfg)
+    bad.lane_num = 4
+    assert lib.pve_create(C.byref(bad), 4, 64, 0, None, None, C.byref(h)) == -1
+    assert b"12-lane" in lib.pve_last_error()
+    assert lib.pve_create(C.byref(cfg), 2, 64, 0, None, None, C.byref(h)) == 0
+    assert lib.pve_reset(h) == -3 and b"pve_set_arrivals" in lib.pve_last_error()
+    assert lib.pve_step_all(h, None, None) == -3
+    arr = np.full((4, 12), np.inf)
+    assert lib.pve_set_arrivals(h, arr.ctypes.data_as(C.c_void_p), 4, 2) == -1
+    assert lib.pve_set_arrivals(h, arr.ctypes.data_as(C.c_void_p), 4, 0) == 0
+    assert lib.pve_reset(h) == 0
+    assert lib.pve_step_all(h, None, None) == 0          # NULL actions = zeros, NULL outputs = none
+    info = _capi.PveEnvInfo()
+    assert lib.pve_read_env(h, 5, C.byref(info)) == -1
+    assert lib.pve_read_env(h, 1, C.byref(info)) == 0 and abs(info.current_time - 0.1 * 200001) < 1e-3
+    p, eb = C.c_void_p(), C.c_int()
+    assert lib.pve_state_field(h, b"nope", C.byref(p), C.byref(eb)) == -1
+    assert lib.pve_state_field(h, b"meta", C.byref(p), C.byref(eb)) == 0 and eb.value == 4
+    assert lib.pve_destroy(h) == 0

@@ -1,0 +1,50 @@
+"""CPU tests of the *parallel formulation* of the tick: the phase bodies of the HIP kernel
+(csrc/pve_tick_core.h) are executed by the test emulator (tests/emu, same C ABI on host memory)
+and compared with the sequential oracle and the golden vectors. The `-m gpu` twin of this file
+(test_gpu_parity.py) runs the real kernels through libpveenv.so."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import OracleEnv
+from oracle.record import compare_records, get_policy
+from tests.hip_adapter import SplitEnv, make_batch, state_snapshot
+from tests.parity_util import CASE_NAMES, GoldenCase, replay_case
+from tests import scenarios
+
+BACKEND = "emu"
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_split_protocol_matches_golden(name):
+    case = GoldenCase(name)
+    b = make_batch(case.arrive, 1, 128, BACKEND, **case.ctor)
+    env = SplitEnv(b)
+    replay_case(case, env, ftol=1e-9, dtol=1e-9, want_state=False)
+    assert b.metrics()["overflow"] == 0
+
+
+@pytest.mark.parametrize("name", ["s1000_sin1", "s200_sin1", "s1000_sin3"])
+def test_split_protocol_matches_oracle_every_field(name):
+    scenarios.check_split_vs_oracle(GoldenCase(name), BACKEND, ticks=400)
+
+
+def test_capacity_64_on_sparse_stream():
+    scenarios.check_split_vs_oracle(GoldenCase("s400_sin2"), BACKEND, ticks=600, capacity=64)
+
+
+def test_fused_equals_split():
+    scenarios.check_fused_equals_split(GoldenCase("s1000_sin3"), BACKEND, ticks=300)
+    scenarios.check_fused_equals_split(GoldenCase("s200_sin1"), BACKEND, ticks=300, capacity=64)
+
+
+def test_batch_of_independent_envs():
+    scenarios.check_batch_independent(BACKEND, n_envs=5, capacity=64, ticks=150)
+
+
+def test_overflow_defers_spawns():
+    scenarios.check_overflow(BACKEND)
+
+
+def test_empty_env_and_exhausted_stream():
+    scenarios.check_empty_and_exhausted(BACKEND)
