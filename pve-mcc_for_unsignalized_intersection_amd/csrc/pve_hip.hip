@@ -40,6 +40,11 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
     T::ph_lock(c, t, sh, r);
     __syncthreads();
     T::ph_final(c, P, env, t, sh, r);
+    if (P.out.state_pre) {            // uniform branch: optional training output
+        __threadfence_block();
+        __syncthreads();
+        T::ph_state(P, env, t, sh, r);
+    }
 }
 
 template <int CAP>

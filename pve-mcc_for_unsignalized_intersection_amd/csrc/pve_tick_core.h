@@ -664,6 +664,28 @@ template <int CAP> struct Tick {
             }
         }
     }
+    // ============================================================== STATE: full 7x28 state (training outputs)
+    // rows 1..6 = the neighbour's own latest row 0 (ref :1332): already recomputed this tick if the
+    // neighbour precedes us in (lane, j) order ("fresh", read back from obs_pre written in FIN), else
+    // the row it stored last tick ("stale", obs_prev_post at the same slot); zeros when absent (ref :1335).
+    // Runs after a workgroup barrier + fence so that obs_pre rows of the other threads are visible.
+    static PVE_HD void ph_state(const Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        if (!P.out.state_pre || !(r.alive && r.ctl)) return;
+        const size_t base = (size_t)env * CAP;
+        double *dst = P.out.state_pre + (base + t) * (size_t)((NNB + 1) * OBSW);
+        const double *own = P.out.obs_pre + (base + t) * OBSW;
+        for (int k = 0; k < OBSW; k++) dst[k] = own[k];
+        for (int q = 0; q < NNB; q++) {
+            const int x = r.kr[q];
+            double *row = dst + (q + 1) * OBSW;
+            if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = 0.0; continue; }
+            const double *src = (x < t) ? (P.out.obs_pre + (base + x) * OBSW)
+                                        : (P.out.obs_prev_post + (base + x) * OBSW);
+            for (int k = 0; k < OBSW; k++) row[k] = src[k];
+        }
+    }
+
     // ============================================================== COMPACT (delete_vehicle only)
     static PVE_HD void ph_c_load(const Params &P, int env, int t, Sh &sh, CRegs &r)
     {

@@ -51,27 +51,20 @@ def default_args():
     return types.SimpleNamespace(collision_thr=2, o_agent_num=6, c_mode="closer")
 
 
-class RefRunner:
-    """One reference env + a policy; `tick()` performs one caller-protocol tick and returns
-    the canonical record (snapshot before delete_vehicle) and then compacts."""
+class ObjRunner:
+    """Drives ANY object that has the reference's public surface (the reference itself, or the
+    product's drop-in class) with the caller protocol of main.py:398-441; `tick()` returns the
+    canonical record (snapshot before delete_vehicle) and then compacts."""
 
-    def __init__(self, arrive_time, policy, want_state=False, **ctor_kw):
-        tis = import_reference()
-        self.env = tis.TrafficInteraction(arrive_time, 150, default_args(), show_col=False,
-                                          virtual_l=True, lane_num=12, **ctor_kw)
+    def __init__(self, env, policy, want_state=False, guard=False):
+        self.env = env
         self.policy = policy
         self.want_state = want_state
+        self.guard = guard
         self.tick_no = 0
         self.guard_hits = 0
         self.tape = []          # actions fed this tick, (lane, j) order, all alive vehicles
         self._nbr_log = []
-        env = self.env
-        orig = env.virtual_lane_search_closer
-
-        def spy(i, j, vl4, mode="front", veh_num=3):
-            orig(i, j, vl4, mode=mode, veh_num=veh_num)
-            self._nbr_log.append([list(c) for c in env.closer_cars])
-        env.virtual_lane_search_closer = spy
 
     def alive_view(self):
         env = self.env
@@ -100,7 +93,7 @@ class RefRunner:
         self._nbr_log.clear()
         guarded = False
         plain = None
-        if len(env.veh_info[0]) == 0 and len(env.virtual_lane_4[0]) > 0:
+        if self.guard and len(env.veh_info[0]) == 0 and len(env.virtual_lane_4[0]) > 0:
             plain = env.virtual_lane_4[0]
             env.virtual_lane_4[0] = _SilentIter(plain)
             guarded = True
@@ -122,7 +115,8 @@ class RefRunner:
         C = len(ids)
         rec = dict(tick=self.tick_no, time=float(env.current_time))
         rec["ids"] = np.array(ids, np.int32).reshape(C, 2)
-        rec["nbr"] = np.array(self._nbr_log, np.int32).reshape(C, 6, 2)
+        nbr_log = self._nbr_log if self.guard else getattr(env, "last_nbr", [])
+        rec["nbr"] = np.array(nbr_log, np.int32).reshape(C, 6, 2)
         rec["reward"] = np.array([float(r) for r in reward], np.float64)
         st = np.array(re_state, np.float64).reshape(C, 7, 28)
         rec["obs0"] = np.ascontiguousarray(st[:, 0, :])
@@ -159,3 +153,19 @@ class RefRunner:
                 heads[d] = (0, -1, -1)
         rec["heads"] = heads
         return rec
+
+
+class RefRunner(ObjRunner):
+    """ObjRunner over the unmodified reference class (+ crash guard + neighbour spy)."""
+
+    def __init__(self, arrive_time, policy, want_state=False, **ctor_kw):
+        tis = import_reference()
+        env = tis.TrafficInteraction(arrive_time, 150, default_args(), show_col=False,
+                                     virtual_l=True, lane_num=12, **ctor_kw)
+        ObjRunner.__init__(self, env, policy, want_state, guard=True)
+        orig = env.virtual_lane_search_closer
+
+        def spy(i, j, vl4, mode="front", veh_num=3):
+            orig(i, j, vl4, mode=mode, veh_num=veh_num)
+            self._nbr_log.append([list(c) for c in env.closer_cars])
+        env.virtual_lane_search_closer = spy
