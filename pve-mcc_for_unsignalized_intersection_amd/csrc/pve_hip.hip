@@ -29,9 +29,15 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
     T::ph_step1(c, P, env, t, sh, r);
     __syncthreads();
     T::ph_step2(c, t, sh, r);
+    T::ph_lists_a(c, t, sh);
     __syncthreads();
     T::ph_step3(c, t, sh, r);
     T::ph_step3_publish(t, sh, r);
+    T::ph_lists_b(t, sh);
+    __syncthreads();
+    T::ph_build(c, t, sh, r);
+    __syncthreads();
+    T::ph_rank(t, sh);
     __syncthreads();
     T::ph_scan(c, t, sh, r);
     __syncthreads();

@@ -124,6 +124,17 @@ template <int CAP> struct Shared {
     uint8_t rew_ovr[CAP];
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW];
     u64 m_spawn[NW];
+    // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
+    // lanes; U = unsorted (segment order), S = sorted by (vd, slot).  5*CAP bounds the total.
+    static constexpr int POOL = 5 * CAP;
+    double u_vd[POOL], s_vd[POOL];
+    int16_t u_slot[POOL], s_slot[POOL];
+    uint8_t u_list[POOL];
+    int16_t mypos[CAP];              // position of each controlled vehicle inside its own lane's list
+    int16_t lcnt[NL];                // controlled vehicles per lane
+    int16_t nl[NL];                  // entries of list d
+    int16_t loff[NL + 1];            // list d occupies [loff[d], loff[d+1])
+    int16_t segoff[NL][5];           // start of segment (own, conflict 0..3) inside list d
 };
 
 struct Regs {
@@ -308,7 +319,81 @@ template <int CAP> struct Tick {
         if (r.alive) { sh.p[t] = r.p; sh.v[t] = r.v; sh.a[t] = r.a; }
     }
 
-    // ============================================================== SCAN: virtual lane of own direction
+    // ============================================================== LISTS: offsets (runs beside S2 / S3)
+    // thread d < 12: size and segment layout of virtual-lane list d from the controlled-vehicle ballot.
+    static PVE_HD void ph_lists_a(const Const &c, int t, Sh &sh)
+    {
+        if (t < NL) {
+            const int d = t;
+            int own = mask_below<NW>(sh.m_ctl, sh.hd.lane_start[d + 1]) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[d]);
+            sh.lcnt[d] = (int16_t)own;
+            int n = own;
+            sh.segoff[d][0] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sh.segoff[d][k + 1] = (int16_t)n;
+                const int L = c.l2l[d][k];
+                if (L >= 0)
+                    n += mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L + 1]) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L]);
+            }
+            sh.nl[d] = (int16_t)n;
+        }
+    }
+    static PVE_HD void ph_lists_b(int t, Sh &sh)
+    {
+        if (t <= NL) {
+            int o = 0;
+            for (int d = 0; d < t; d++) o += sh.nl[d];
+            sh.loff[t] = (int16_t)o;
+        }
+    }
+
+    // ============================================================== BUILD: every controlled vehicle files
+    // itself into its own lane's list and into the lists of the lanes it conflicts with (ref :240-270)
+    static PVE_HD void ph_build(const Const &c, int t, Sh &sh, Regs &r)
+    {
+        if (!(r.alive && r.ctl)) return;
+        const int lane = r.lane;
+        const int q = mask_below<NW>(sh.m_ctl, t) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[lane]);
+        {
+            const int e = sh.loff[lane] + q;                  // own lane: vd = p (ref :242-249)
+            sh.u_vd[e] = r.p; sh.u_slot[e] = (int16_t)t; sh.u_list[e] = (uint8_t)lane;
+        }
+        if (lane % 3 == 2) return;                            // right turns conflict with nobody (ref :156)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int d = c.l2l[lane][k];                     // the relation is symmetric
+            const int kk = c.l2l_inv[lane][k];                // our position inside lane2lane[d]
+            const int m = d % 3;
+            const double delta = r.p - c.vdA[m][kk] + c.vdB[m][kk];      // ref :733-803
+            const double vd = (delta > 0) ? (c.vdC[m][kk] + delta) : INFINITY;   // not chosen -> sorts last
+            const int e = sh.loff[d] + sh.segoff[d][kk + 1] + q;
+            sh.u_vd[e] = vd; sh.u_slot[e] = (int16_t)t; sh.u_list[e] = (uint8_t)d;
+        }
+    }
+
+    // ============================================================== RANK: counting sort of every list by
+    // (vd, slot) = the reference's stable sort of the (lane, j)-ordered list by vd (ref :271)
+    static PVE_HD void ph_rank(int t, Sh &sh)
+    {
+        const int M = sh.loff[NL];
+        for (int e = t; e < M; e += CAP) {
+            const int d = sh.u_list[e];
+            const double vd = sh.u_vd[e];
+            const int slot = sh.u_slot[e];
+            const int lo = sh.loff[d], hi = sh.loff[d + 1];
+            int pos = 0;
+            for (int f = lo; f < hi; f++) {
+                const double w = sh.u_vd[f];
+                pos += (w < vd || (w == vd && sh.u_slot[f] < slot)) ? 1 : 0;
+            }
+            sh.s_vd[lo + pos] = vd;
+            sh.s_slot[lo + pos] = (int16_t)slot;
+            if (d == slot_lane(sh.hd, slot)) sh.mypos[slot] = (int16_t)pos;
+        }
+    }
+
+    // ============================================================== WALK: predecessor, 6 nearest, reward, hit
     static PVE_HD void ph_scan(const Const &c, int t, Sh &sh, Regs &r)
     {
         r.reward = 0; r.hit = 0; r.hdr = -1;
@@ -317,52 +402,12 @@ template <int CAP> struct Tick {
         const bool ctl = r.alive && r.ctl;
         const bool head_thread = r.alive && r.j == 0;     // lane non-empty -> its list is rebuilt (ref :234)
         if (!(ctl || head_thread)) return;
-        const int lane = r.lane, m = lane % 3;
+        const int lane = r.lane;
         const double ps = r.p;
-        double hvd = INFINITY; int hr = -1;               // list head = min (vd, slot)
-        double pvd = -INFINITY; int pr = -1;              // predecessor = max key < own key
-        double kd[NNB], kv[NNB]; int kr[NNB];
-#pragma unroll
-        for (int k = 0; k < NNB; k++) { kd[k] = INFINITY; kv[k] = INFINITY; kr[k] = 0x7fffffff; }
-        for (int q = 0; q < 5; q++) {
-            int L = lane; double A = 0, B = 0, Cc = 0;
-            const bool own = (q == 0);
-            if (!own) {
-                if (m == 2) break;                        // right turns conflict with nobody (ref :156)
-                L = c.l2l[lane][q - 1]; A = c.vdA[m][q - 1]; B = c.vdB[m][q - 1]; Cc = c.vdC[m][q - 1];
-            }
-            const int lo = sh.hd.lane_start[L], hi = sh.hd.lane_start[L + 1];
-            for (int x = lo; x < hi; x++) {
-                if (!mask_test(sh.m_ctl, x)) continue;    // only vehicles appended by step (ref :1539)
-                const double pp = sh.p[x];
-                double vd;
-                if (own) vd = pp;                         // ref :242-249
-                else {                                    // ref :259-270, :733-803
-                    double delta = pp - A + B;
-                    if (!(delta > 0)) continue;
-                    vd = Cc + delta;
-                }
-                if (vd < hvd || (vd == hvd && x < hr)) { hvd = vd; hr = x; }
-                if (ctl && x != t) {
-                    bool lt = vd < ps || (vd == ps && x < t);
-                    if (lt && (vd > pvd || (vd == pvd && x > pr))) { pvd = vd; pr = x; }
-                    double d = fabs(vd - ps);             // ref :1388
-                    if (key_less(d, vd, x, kd[NNB - 1], kv[NNB - 1], kr[NNB - 1])) {
-                        kd[NNB - 1] = d; kv[NNB - 1] = vd; kr[NNB - 1] = x;
-#pragma unroll
-                        for (int s = NNB - 1; s > 0; s--) {
-                            if (key_less(kd[s], kv[s], kr[s], kd[s - 1], kv[s - 1], kr[s - 1])) {
-                                double td = kd[s]; kd[s] = kd[s - 1]; kd[s - 1] = td;
-                                double tv = kv[s]; kv[s] = kv[s - 1]; kv[s - 1] = tv;
-                                int tr = kr[s]; kr[s] = kr[s - 1]; kr[s - 1] = tr;
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        const int base = sh.loff[lane], n = sh.loff[lane + 1] - base;
         if (head_thread) {                                // persisted for next tick's step (ref :1517)
-            if (hr >= 0) {
+            if (n > 0 && sh.s_vd[base] < INFINITY) {
+                const int hr = sh.s_slot[base];
                 lds_or(&sh.hd.head_valid, 1 << lane);
                 int hl = slot_lane(sh.hd, hr);
                 sh.hd.head_lane[lane] = (int16_t)hl;
@@ -372,10 +417,39 @@ template <int CAP> struct Tick {
             }
         }
         if (!ctl) return;
+        const int s = sh.mypos[t];
+        int pr = -1; double pvd = 0;
+        if (s > 0) { pr = sh.s_slot[base + s - 1]; pvd = sh.s_vd[base + s - 1]; }     // ref :1353-1354
+        // merge outwards from our own position: left = keys below ours, right = keys above; order of the
+        // reference's stable |vd - vd_self| sort = (|d|, vd, slot) (ref :1383-1397).  Equal |d| -> left first
+        // (smaller vd, or equal vd and smaller slot); a run of equal vd on the left is emitted in ascending slot.
+        int hi = s - 1, lo = hi, cur, rr = s + 1;
+        if (hi >= 0) { const double vh = sh.s_vd[base + hi]; while (lo > 0 && sh.s_vd[base + lo - 1] == vh) lo--; }
+        cur = lo;
 #pragma unroll
         for (int k = 0; k < NNB; k++) {
-            r.kr[k] = (kr[k] == 0x7fffffff) ? -1 : kr[k];
-            r.kv[k] = (kr[k] == 0x7fffffff) ? 0.0 : kv[k];
+            const bool hasL = hi >= 0;
+            double vR = INFINITY;
+            if (rr < n) vR = sh.s_vd[base + rr];
+            const bool hasR = vR < INFINITY;
+            if (hasL || hasR) {
+                double vL = 0;
+                if (hasL) vL = sh.s_vd[base + cur];
+                const double dL = fabs(vL - ps), dR = fabs(vR - ps);              // ref :1388
+                const bool takeL = hasL && (!hasR || dL <= dR);
+                if (takeL) {
+                    r.kr[k] = sh.s_slot[base + cur]; r.kv[k] = vL;
+                    cur++;
+                    if (cur > hi) {
+                        hi = lo - 1; lo = hi;
+                        if (hi >= 0) { const double vh = sh.s_vd[base + hi]; while (lo > 0 && sh.s_vd[base + lo - 1] == vh) lo--; }
+                        cur = lo;
+                    }
+                } else {
+                    r.kr[k] = sh.s_slot[base + rr]; r.kv[k] = vR;
+                    rr++;
+                }
+            }
         }
         // ref :1348-1354
         r.hdr = pr;

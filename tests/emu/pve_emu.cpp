@@ -26,8 +26,12 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_load(c, P, env, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_step1(c, P, env, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_step2(c, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_lists_a(c, t, sh);
         for (int t = 0; t < CAP; t++) T::ph_step3(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_step3_publish(t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_lists_b(t, sh);
+        for (int t = 0; t < CAP; t++) T::ph_build(c, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
         for (int t = 0; t < CAP; t++) T::ph_scan(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_effects(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_lock(c, t, sh, regs[t]);

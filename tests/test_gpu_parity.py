@@ -95,3 +95,27 @@ def test_gpu_full_size_invariants():
         assert abs(info.current_time - b.read_env(e + half).current_time) == 0
     m = b.metrics()
     assert m["ticks"] == 250 * 2 * half and m["overflow"] == 0
+
+
+@pytest.mark.parametrize("name,ticks", [("s1000_sin1", 200), ("s200_sin1", 1300)])
+def test_gpu_compat_class_reproduces_golden(name, ticks):
+    """The drop-in TrafficInteraction class on the real kernels, driven like main.py drives the reference."""
+    from tests.test_compat_class import run_compat
+    env = run_compat(name, ticks, "hip")
+    assert env.id_seq > 0
+
+
+@pytest.mark.parametrize("name", ["s1000_sin1", "s1000_sin3"])
+def test_gpu_full_state_rows_fresh_and_stale(name):
+    """state_pre (7x28, neighbour rows fresh/stale by order, ref :1332) and the 7-action vector."""
+    from oracle.oracle import OracleEnv
+    from oracle.record import compare_records
+    case = GoldenCase(name)
+    orc = OracleEnv(case.arrive, **case.ctor)
+    env = SplitEnv(make_batch(case.arrive, 1, 128, BACKEND, **case.ctor))
+    for t in range(300):
+        va, ca, oa = orc.alive_view()
+        acts = case.policy(t, va, ca, oa)
+        ra, rb = orc.tick(acts, want_state=True), env.tick(acts, want_state=True)
+        assert rb["state"] is not None
+        compare_records(ra, rb, tol=TOL, label=name)
