@@ -169,6 +169,11 @@ int pve_state_field(pve_handle h, const char *field, void **dev_ptr, int *elem_b
 
 int pve_synchronize(pve_handle h);
 
+/* Diagnostics: accumulate per-phase clock ticks of every wave of the tick kernel into a zeroed DEVICE
+ * buffer of uint64 [n_envs * capacity/64][16] (column = phase: load, step1, step2, step3, build, rank,
+ * walk, effects, lock, final, state); NULL disables. Used by tools/phase_profile.py; no effect on results. */
+int pve_debug_phase_cycles(pve_handle h, uint64_t *dev_counters16);
+
 #ifdef __cplusplus
 }
 #endif

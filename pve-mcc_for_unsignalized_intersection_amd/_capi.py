@@ -57,7 +57,7 @@ class PveEnvInfo(C.Structure):
 EXPORTS = ("pve_abi_version", "pve_last_error", "pve_default_config", "pve_workspace_bytes", "pve_create",
            "pve_destroy", "pve_set_stream", "pve_set_arrivals", "pve_reset", "pve_step_all",
            "pve_scene_update", "pve_compact", "pve_read_env", "pve_read_vehicles", "pve_get_metrics",
-           "pve_state_field", "pve_synchronize")
+           "pve_state_field", "pve_synchronize", "pve_debug_phase_cycles")
 
 
 def _declare(L):
@@ -80,6 +80,7 @@ def _declare(L):
     L.pve_get_metrics.argtypes = [vp, C.POINTER(C.c_double)]
     L.pve_state_field.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int)]
     L.pve_synchronize.argtypes = [vp]
+    L.pve_debug_phase_cycles.argtypes = [vp, vp]
     for name in EXPORTS:
         if name not in ("pve_last_error", "pve_workspace_bytes", "pve_default_config"):
             getattr(L, name).restype = C.c_int

@@ -16,6 +16,16 @@
 
 using namespace pve;
 
+// diagnostics (pve_debug_phase_cycles): every wave keeps the clock ticks it spent in each phase (incl. the
+// wait at the closing barrier) in registers and adds them to its private row of a [n_waves][16] device
+// buffer at the end of the kernel (no shared atomics, no extra memory traffic inside the phases)
+#define PVE_PHASE_MARK(idx)                                                              \
+    if (P.phase_cycles) {                                                                \
+        unsigned long long now_ = wall_clock64();                                        \
+        pc_[idx] = now_ - tprev_;                                                        \
+        tprev_ = now_;                                                                   \
+    }
+
 template <int CAP>
 __global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
 {
@@ -24,32 +34,50 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
     const int env = blockIdx.x;
     Regs r;
     typedef Tick<CAP> T;
+    unsigned long long pc_[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = P.phase_cycles ? wall_clock64() : 0ull;
     T::ph_load(c, P, env, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(0)
     T::ph_step1(c, P, env, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(1)
     T::ph_step2(c, t, sh, r);
     T::ph_lists_a(c, t, sh);
     __syncthreads();
+    PVE_PHASE_MARK(2)
     T::ph_step3(c, t, sh, r);
     T::ph_step3_publish(t, sh, r);
     T::ph_lists_b(t, sh);
     __syncthreads();
+    PVE_PHASE_MARK(3)
     T::ph_build(c, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(4)
     T::ph_rank(t, sh);
     __syncthreads();
+    PVE_PHASE_MARK(5)
     T::ph_scan(c, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(6)
     T::ph_effects(c, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(7)
     T::ph_lock(c, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(8)
     T::ph_final(c, P, env, t, sh, r);
+    PVE_PHASE_MARK(9)
     if (P.out.state_pre) {            // uniform branch: optional training output
         __threadfence_block();
         __syncthreads();
         T::ph_state(P, env, t, sh, r);
+        PVE_PHASE_MARK(10)
+    }
+    if (P.phase_cycles && (t & 63) == 0) {
+        unsigned long long *row = P.phase_cycles + ((size_t)env * (CAP / 64) + (t >> 6)) * 16;
+#pragma unroll
+        for (int k = 0; k < 11; k++) row[k] += pc_[k];
     }
 }
 

@@ -93,4 +93,5 @@ struct pve_handle_s {
     void *stream;
     bool has_arrivals, is_reset;
     long long ticks_since_reset;
+    unsigned long long *phase_cycles;
 };

@@ -87,6 +87,7 @@ struct Params {
     int32_t n_envs;
     int32_t mode;
     int32_t mask_uncontrolled;   // 1: actions of uncontrolled slots are forced to 0 (main.py:401)
+    unsigned long long *phase_cycles;   // diagnostics: 16 counters of wave-cycles per phase, or null
     Outputs out;
 };
 

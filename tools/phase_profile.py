@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Per-phase wave-cycle breakdown of k_tick at the bench workload (diagnostics, GPU only).
+Usage: python tools/phase_profile.py [--capacity 128] [--envs 4096] [--ticks 200]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+import pve_mcc_amd  # noqa: E402
+from pve_mcc_amd.arrivals import synthetic_arrivals  # noqa: E402
+
+PHASES = ("load", "step1", "step2+listsA", "step3+listsB", "build", "rank", "walk+reward", "effects", "lock",
+          "final", "state")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--capacity", type=int, default=128)
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--ticks", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    rate = 1100.0 if a.capacity == 128 else 500.0
+    arr = synthetic_arrivals(a.envs, rate=rate, horizon_s=(a.ticks + a.warmup) * 0.1 + 20)
+    env = pve_mcc_amd.BatchedIntersections(a.envs, a.capacity, arr, device=dev,
+                                           outputs=tuple(x for x in a.outputs.split(",") if x))
+    pool = torch.as_tensor(bench.action_pool(a.envs, a.capacity, 99), device=dev)
+    env.reset()
+    for t in range(a.warmup):
+        env.step(pool[t % bench.N_POOL])
+    buf = torch.zeros(a.envs * (a.capacity // 64), 16, dtype=torch.int64, device=dev)
+    env.lib.pve_debug_phase_cycles(env._h, C.c_void_p(buf.data_ptr()))
+    for t in range(a.warmup, a.warmup + a.ticks):
+        env.step(pool[t % bench.N_POOL])
+    torch.cuda.synchronize()
+    env.lib.pve_debug_phase_cycles(env._h, None)
+    cyc = buf.sum(0).cpu().numpy().astype(float)
+    waves = a.envs * (a.capacity // 64) * a.ticks
+    tot = cyc.sum()
+    print("phase                cycles/wave   share")
+    for k, name in enumerate(PHASES):
+        if cyc[k] > 0:
+            print("%-18s %12.0f  %6.1f%%" % (name, cyc[k] / waves, 100 * cyc[k] / tot))
+    print("%-18s %12.0f  (wall_clock64 ticks, 100 MHz constant clock => x10 ns)" % ("total", tot / waves))
+
+
+if __name__ == "__main__":
+    main()
