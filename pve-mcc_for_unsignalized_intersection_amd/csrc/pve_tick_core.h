@@ -111,7 +111,11 @@ template <int CAP> struct Shared {
     static constexpr int NW = CAP / 64;
     EnvHeader hd;
     double p[CAP], v[CAP], a[CAP];   // post-step kinematics of every slot
-    double p1[CAP], v1[CAP];         // step outcome "if braking" (S1-S3 only)
+    static constexpr int POOL = 5 * CAP;
+    union {                          // p1/v1 die at the barrier after S3, the lists are born after it
+        struct { double p1[CAP], v1[CAP]; };   // step outcome "if braking" (S1-S3 only)
+        double u_vd[POOL];           // virtual distance of every list entry (segment order)
+    };
     double virdis[CAP];
     double next_arr[NL];
     double red_reward[NW], red_jerk[NW];
@@ -125,10 +129,9 @@ template <int CAP> struct Shared {
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW];
     u64 m_spawn[NW];
     // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
-    // lanes; U = unsorted (segment order), S = sorted by (vd, slot).  5*CAP bounds the total.
-    static constexpr int POOL = 5 * CAP;
-    double u_vd[POOL], s_vd[POOL];
-    int16_t u_slot[POOL], s_slot[POOL];
+    // lanes; u_* = entries in segment order, s_idx = entry indices sorted by (vd, slot). 5*CAP bounds the total.
+    int16_t s_idx[POOL];
+    uint8_t u_slot[POOL];
     uint8_t u_list[POOL];
     int16_t mypos[CAP];              // position of each controlled vehicle inside its own lane's list
     int16_t lcnt[NL];                // controlled vehicles per lane
@@ -357,7 +360,7 @@ template <int CAP> struct Tick {
         const int q = mask_below<NW>(sh.m_ctl, t) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[lane]);
         {
             const int e = sh.loff[lane] + q;                  // own lane: vd = p (ref :242-249)
-            sh.u_vd[e] = r.p; sh.u_slot[e] = (int16_t)t; sh.u_list[e] = (uint8_t)lane;
+            sh.u_vd[e] = r.p; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)lane;
         }
         if (lane % 3 == 2) return;                            // right turns conflict with nobody (ref :156)
 #pragma unroll
@@ -368,7 +371,7 @@ template <int CAP> struct Tick {
             const double delta = r.p - c.vdA[m][kk] + c.vdB[m][kk];      // ref :733-803
             const double vd = (delta > 0) ? (c.vdC[m][kk] + delta) : INFINITY;   // not chosen -> sorts last
             const int e = sh.loff[d] + sh.segoff[d][kk + 1] + q;
-            sh.u_vd[e] = vd; sh.u_slot[e] = (int16_t)t; sh.u_list[e] = (uint8_t)d;
+            sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)d;
         }
     }
 
@@ -380,16 +383,21 @@ template <int CAP> struct Tick {
         for (int e = t; e < M; e += CAP) {
             const int d = sh.u_list[e];
             const double vd = sh.u_vd[e];
-            const int slot = sh.u_slot[e];
             const int lo = sh.loff[d], hi = sh.loff[d + 1];
-            int pos = 0;
-            for (int f = lo; f < hi; f++) {
-                const double w = sh.u_vd[f];
-                pos += (w < vd || (w == vd && sh.u_slot[f] < slot)) ? 1 : 0;
+            int pos = 0, eq = 0;
+            int f = lo;
+            for (; f + 4 <= hi; f += 4) {                 // 4 independent LDS reads per round
+                const double w0 = sh.u_vd[f], w1 = sh.u_vd[f + 1], w2 = sh.u_vd[f + 2], w3 = sh.u_vd[f + 3];
+                pos += (w0 < vd) + (w1 < vd) + (w2 < vd) + (w3 < vd);
+                eq += (w0 == vd) + (w1 == vd) + (w2 == vd) + (w3 == vd);
             }
-            sh.s_vd[lo + pos] = vd;
-            sh.s_slot[lo + pos] = (int16_t)slot;
-            if (d == slot_lane(sh.hd, slot)) sh.mypos[slot] = (int16_t)pos;
+            for (; f < hi; f++) { const double w = sh.u_vd[f]; pos += (w < vd); eq += (w == vd); }
+            if (eq > 1) {                                 // exact vd ties (rare): lower slot first
+                const int slot = sh.u_slot[e];
+                for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
+            }
+            sh.s_idx[lo + pos] = (int16_t)e;
+            if (e - lo < sh.lcnt[d]) sh.mypos[sh.u_slot[e]] = (int16_t)pos;   // own-lane segment comes first
         }
     }
 
@@ -406,8 +414,9 @@ template <int CAP> struct Tick {
         const double ps = r.p;
         const int base = sh.loff[lane], n = sh.loff[lane + 1] - base;
         if (head_thread) {                                // persisted for next tick's step (ref :1517)
-            if (n > 0 && sh.s_vd[base] < INFINITY) {
-                const int hr = sh.s_slot[base];
+            const int e0 = (n > 0) ? sh.s_idx[base] : 0;
+            if (n > 0 && sh.u_vd[e0] < INFINITY) {
+                const int hr = sh.u_slot[e0];
                 lds_or(&sh.hd.head_valid, 1 << lane);
                 int hl = slot_lane(sh.hd, hr);
                 sh.hd.head_lane[lane] = (int16_t)hl;
@@ -419,34 +428,40 @@ template <int CAP> struct Tick {
         if (!ctl) return;
         const int s = sh.mypos[t];
         int pr = -1; double pvd = 0;
-        if (s > 0) { pr = sh.s_slot[base + s - 1]; pvd = sh.s_vd[base + s - 1]; }     // ref :1353-1354
+        if (s > 0) { const int e = sh.s_idx[base + s - 1]; pr = sh.u_slot[e]; pvd = sh.u_vd[e]; }   // ref :1353-1354
         // merge outwards from our own position: left = keys below ours, right = keys above; order of the
         // reference's stable |vd - vd_self| sort = (|d|, vd, slot) (ref :1383-1397).  Equal |d| -> left first
         // (smaller vd, or equal vd and smaller slot); a run of equal vd on the left is emitted in ascending slot.
         int hi = s - 1, lo = hi, cur, rr = s + 1;
-        if (hi >= 0) { const double vh = sh.s_vd[base + hi]; while (lo > 0 && sh.s_vd[base + lo - 1] == vh) lo--; }
+        if (hi >= 0) {
+            const double vh = sh.u_vd[sh.s_idx[base + hi]];
+            while (lo > 0 && sh.u_vd[sh.s_idx[base + lo - 1]] == vh) lo--;
+        }
         cur = lo;
 #pragma unroll
         for (int k = 0; k < NNB; k++) {
             const bool hasL = hi >= 0;
-            double vR = INFINITY;
-            if (rr < n) vR = sh.s_vd[base + rr];
+            double vR = INFINITY; int eR = 0;
+            if (rr < n) { eR = sh.s_idx[base + rr]; vR = sh.u_vd[eR]; }
             const bool hasR = vR < INFINITY;
             if (hasL || hasR) {
-                double vL = 0;
-                if (hasL) vL = sh.s_vd[base + cur];
+                double vL = 0; int eL = 0;
+                if (hasL) { eL = sh.s_idx[base + cur]; vL = sh.u_vd[eL]; }
                 const double dL = fabs(vL - ps), dR = fabs(vR - ps);              // ref :1388
                 const bool takeL = hasL && (!hasR || dL <= dR);
                 if (takeL) {
-                    r.kr[k] = sh.s_slot[base + cur]; r.kv[k] = vL;
+                    r.kr[k] = sh.u_slot[eL]; r.kv[k] = vL;
                     cur++;
                     if (cur > hi) {
                         hi = lo - 1; lo = hi;
-                        if (hi >= 0) { const double vh = sh.s_vd[base + hi]; while (lo > 0 && sh.s_vd[base + lo - 1] == vh) lo--; }
+                        if (hi >= 0) {
+                            const double vh = sh.u_vd[sh.s_idx[base + hi]];
+                            while (lo > 0 && sh.u_vd[sh.s_idx[base + lo - 1]] == vh) lo--;
+                        }
                         cur = lo;
                     }
                 } else {
-                    r.kr[k] = sh.s_slot[base + rr]; r.kv[k] = vR;
+                    r.kr[k] = sh.u_slot[eR]; r.kv[k] = vR;
                     rr++;
                 }
             }
