@@ -78,6 +78,14 @@ PVE_HD void lds_add(int *p, int v)
     *p += v;
 #endif
 }
+PVE_HD int lds_claim(int *p)        // returns a distinct small integer per caller
+{
+#if PVE_DEVICE_CODE
+    return atomicAdd(p, 1);
+#else
+    return (*p)++;
+#endif
+}
 PVE_HD void lds_or(int *p, int v)
 {
 #if PVE_DEVICE_CODE
@@ -138,6 +146,10 @@ template <int CAP> struct Shared {
     int16_t nl[NL];                  // entries of list d
     int16_t loff[NL + 1];            // list d occupies [loff[d], loff[d+1])
     int16_t segoff[NL][5];           // start of segment (own, conflict 0..3) inside list d
+    uint8_t lane_of[CAP];            // lane of every alive slot
+    double tabA[2][4], tabB[2][4], tabC[2][4];   // get_virtual_distance table (copy of Const, lane-indexed reads)
+    int8_t l2l[NL][4], l2l_inv[NL][4];
+    int lead_n;                      // dead-lock leaders that claimed a scratch chunk
 };
 
 struct Regs {
@@ -159,30 +171,57 @@ struct CRegs {                       // MODE_COMPACT moves every persistent fiel
 };
 
 // ------------------------------------------------------------------ geometry: ref :1250-1289
+// sin/cos on [0, pi/2] (the arc angle r_a of a vehicle inside the box) by Taylor polynomials about 0
+// after folding to [0, pi/4]: |error| < 2e-16.  They only feed the XY collision distance, whose decision
+// margin in the golden tapes is >= 4e-4, never an exact-IEEE decision.
+PVE_HD void sincos_q1(double x, double &sn, double &cs)
+{
+    const double hp = 1.5707963267948966;            // pi/2
+    const bool fold = x > 0.7853981633974483;        // > pi/4: sin(x) = cos(pi/2 - x), cos(x) = sin(pi/2 - x)
+    const double y = fold ? (hp - x) : x;
+    const double z = y * y;
+    double ps = -7.6471637318198164759e-13;          // -1/15!
+    ps = ps * z + 1.6059043836821614599e-10;         //  1/13!
+    ps = ps * z - 2.5052108385441718775e-08;         // -1/11!
+    ps = ps * z + 2.7557319223985890653e-06;         //  1/9!
+    ps = ps * z - 1.9841269841269841270e-04;         // -1/7!
+    ps = ps * z + 8.3333333333333333333e-03;         //  1/5!
+    ps = ps * z - 1.6666666666666666667e-01;         // -1/3!
+    const double s1 = y + y * z * ps;
+    double pc = 4.7794773323873852974e-14;           //  1/16!
+    pc = pc * z - 1.1470745597729724714e-11;         // -1/14!
+    pc = pc * z + 2.0876756987868098979e-09;         //  1/12!
+    pc = pc * z - 2.7557319223985890653e-07;         // -1/10!
+    pc = pc * z + 2.4801587301587301587e-05;         //  1/8!
+    pc = pc * z - 1.3888888888888888889e-03;         // -1/6!
+    pc = pc * z + 4.1666666666666666667e-02;         //  1/4!
+    const double c1 = 1.0 - 0.5 * z + z * z * pc;
+    sn = fold ? c1 : s1;
+    cs = fold ? s1 : c1;
+}
+
 PVE_HD void get_xy(const Const &c, double p, int lane, double &X, double &Y)
 {
     const double cw = c.cw;
     const int m = lane % 3;
+    const double Lb = c.inbox[m == 2 ? 2 : 0];
+    const bool arc = (m != 1) && (p > 0) && !(p > Lb);
+    double sn = 0, cs = 1;
+    if (arc) sincos_q1((Lb - p) / Lb * c.arc_k / 2, sn, cs);      // r_a, ref :1259, :1277
     double x, y;
     if (m == 0) {
-        const double L0 = c.inbox[0];
-        if (p > L0) { x = p - L0 + 6 * cw; y = cw; }
+        if (p > Lb) { x = p - Lb + 6 * cw; y = cw; }
         else if (p > 0) {
-            double r_a = (L0 - p) / L0 * c.arc_k / 2;
             double p0x = 6 * cw, p0y = cw, prx = 6 * cw, pry = -6 * cw;
-            double cs = cos(r_a), sn = sin(r_a);
             x = prx + (p0x - prx) * cs - (p0y - pry) * sn;
             y = pry + (p0y - pry) * cs + (p0x - prx) * sn;
         } else { x = -cw; y = -6 * cw + p; }
     } else if (m == 1) {
         x = p - 6 * cw; y = 3 * cw;
     } else {
-        const double L2 = c.inbox[2];
-        if (p > L2) { x = p - L2 + 6 * cw; y = 5 * cw; }
+        if (p > Lb) { x = p - Lb + 6 * cw; y = 5 * cw; }
         else if (p > 0) {
-            double r_a = (L2 - p) / L2 * c.arc_k / 2;
             double p0x = 6 * cw, p0y = 5 * cw, prx = 6 * cw, pry = 6 * cw;
-            double cs = cos(r_a), sn = sin(r_a);
             x = prx + (p0x - prx) * cs + (p0y - pry) * sn;
             y = pry + (p0y - pry) * cs - (p0x - prx) * sn;
         } else { x = 5 * cw; y = 6 * cw - p; }
@@ -199,11 +238,9 @@ PVE_HD bool key_less(double d1, double v1, int r1, double d2, double v2, int r2)
 
 PVE_HD int brake_needed(const Const &c, double p, double v, double fp, double fv)
 {   // ref :1509-1516 (front = vehicle j-1 AFTER its own update)
-    if (fv < v) {
-        double d_safe = v * 0.4 + (v * v - fv * fv) / c.two_abs_am - (v - fv) * c.vm / c.abs_am;
-        if (p - fp < d_safe) return 1;
-    }
-    return 0;
+    // straight-line (no branch) so that the divisions of both outcomes overlap
+    const double d_safe = v * 0.4 + (v * v - fv * fv) / c.two_abs_am - (v - fv) * c.vm / c.abs_am;
+    return ((fv < v) & (p - fp < d_safe)) ? 1 : 0;
 }
 
 PVE_HD int slot_lane(const EnvHeader &hd, int t)
@@ -246,7 +283,16 @@ template <int CAP> struct Tick {
             if (rec < P.rows) nxt = P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec * NL + t];
             sh.next_arr[t] = nxt;
         }
-        if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; }
+        if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
+        if (t < 8) {
+            sh.tabA[t >> 2][t & 3] = c.vdA[t >> 2][t & 3];
+            sh.tabB[t >> 2][t & 3] = c.vdB[t >> 2][t & 3];
+            sh.tabC[t >> 2][t & 3] = c.vdC[t >> 2][t & 3];
+        }
+        if (t < NL * 4) {
+            sh.l2l[t >> 2][t & 3] = c.l2l[t >> 2][t & 3];
+            sh.l2l_inv[t >> 2][t & 3] = c.l2l_inv[t >> 2][t & 3];
+        }
     }
 
     // ============================================================== S1: step, both outcomes
@@ -270,6 +316,7 @@ template <int CAP> struct Tick {
         if (r.alive) {
             const int lane = slot_lane(sh.hd, t);
             r.lane = lane; r.j = t - sh.hd.lane_start[lane];
+            sh.lane_of[t] = (uint8_t)lane;
             r.ctl = (r.meta & M_CONTROL) ? 1 : 0;
             double act = P.actions ? P.actions[(size_t)env * CAP + t] : 0.0;
             if (P.mask_uncontrolled && !r.ctl) act = 0.0;   // main.py:401
@@ -335,7 +382,7 @@ template <int CAP> struct Tick {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 sh.segoff[d][k + 1] = (int16_t)n;
-                const int L = c.l2l[d][k];
+                const int L = sh.l2l[d][k];
                 if (L >= 0)
                     n += mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L + 1]) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L]);
             }
@@ -365,11 +412,11 @@ template <int CAP> struct Tick {
         if (lane % 3 == 2) return;                            // right turns conflict with nobody (ref :156)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int d = c.l2l[lane][k];                     // the relation is symmetric
-            const int kk = c.l2l_inv[lane][k];                // our position inside lane2lane[d]
+            const int d = sh.l2l[lane][k];                    // the relation is symmetric
+            const int kk = sh.l2l_inv[lane][k];               // our position inside lane2lane[d]
             const int m = d % 3;
-            const double delta = r.p - c.vdA[m][kk] + c.vdB[m][kk];      // ref :733-803
-            const double vd = (delta > 0) ? (c.vdC[m][kk] + delta) : INFINITY;   // not chosen -> sorts last
+            const double delta = r.p - sh.tabA[m][kk] + sh.tabB[m][kk];  // ref :733-803
+            const double vd = (delta > 0) ? (sh.tabC[m][kk] + delta) : INFINITY;   // not chosen -> sorts last
             const int e = sh.loff[d] + sh.segoff[d][kk + 1] + q;
             sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)d;
         }
@@ -418,7 +465,7 @@ template <int CAP> struct Tick {
             if (n > 0 && sh.u_vd[e0] < INFINITY) {
                 const int hr = sh.u_slot[e0];
                 lds_or(&sh.hd.head_valid, 1 << lane);
-                int hl = slot_lane(sh.hd, hr);
+                int hl = sh.lane_of[hr];
                 sh.hd.head_lane[lane] = (int16_t)hl;
                 sh.hd.head_j[lane] = (int16_t)(hr - sh.hd.lane_start[hl]);
             } else {
@@ -502,7 +549,7 @@ template <int CAP> struct Tick {
         if (n0 >= 0) {
             double ax, ay, bx, by;
             get_xy(c, ps, lane, ax, ay);
-            get_xy(c, sh.p[n0], slot_lane(sh.hd, n0), bx, by);
+            get_xy(c, sh.p[n0], sh.lane_of[n0], bx, by);
             double dx = bx - ax, dy = by - ay;
             double dxy = sqrt(dx * dx + dy * dy);
             if (fabs(dxy) < c.collision_thr) {
@@ -570,25 +617,28 @@ template <int CAP> struct Tick {
                 lead = (mn == t);                         // the first member in order discovers the cycle
             }
             if (lead) {
-                // records [vir_dis(o), o, header(o)] sorted ascending (ref :1486-1493); members are
-                // distinct so (vir_dis, slot) is a strict order.  Selection sort by repeated walks.
+                // records [vir_dis(o), o, header(o)] sorted ascending (ref :1486-1493); members are distinct
+                // so (vir_dis, slot) is a strict order.  The <= 10 members are first copied to a private
+                // scratch chunk (u_vd / s_idx are dead after the walk phase), then selected in sorted order
+                // with independent LDS reads; the running sum follows python's left-to-right sum().
+                const int chunk = lds_claim(&sh.lead_n);          // any distinct chunk will do
+                double *sd = sh.u_vd + chunk * 10;
+                int16_t *so = sh.s_idx + chunk * 10;
+                cur = t;
+                for (int q = 0; q < len; q++) { sd[q] = sh.virdis[cur]; so[q] = (int16_t)cur; sh.lockf[cur] = 1; cur = sh.hdr[cur]; }   // ref :1482
                 double last_d = -INFINITY; int last_o = -1;
                 double sum = 0, best_d = 0; int best_o = -1;
-                for (int s = 0; s < len; s++) {
+                for (int s2 = 0; s2 < len; s2++) {
                     double md = INFINITY; int mo = 0x7fffffff;
-                    cur = t;
                     for (int q = 0; q < len; q++) {
-                        double d = sh.virdis[cur];
-                        bool gt_last = d > last_d || (d == last_d && cur > last_o);
-                        if (gt_last && (d < md || (d == md && cur < mo))) { md = d; mo = cur; }
-                        cur = sh.hdr[cur];
+                        const double d = sd[q]; const int o = so[q];
+                        const bool gt_last = d > last_d || (d == last_d && o > last_o);
+                        if (gt_last && (d < md || (d == md && o < mo))) { md = d; mo = o; }
                     }
                     sum = sum + md;
-                    if (s == 0) { best_d = md; best_o = mo; }
+                    if (s2 == 0) { best_d = md; best_o = mo; }
                     last_d = md; last_o = mo;
                 }
-                cur = t;
-                for (int q = 0; q < len; q++) { sh.lockf[cur] = 1; cur = sh.hdr[cur]; }   // ref :1482
                 if (best_d < c.collision_thr || sum / (double)len < c.lock_mean_thr) {    // ref :1495-1497
                     sh.locka[best_o] = 1;
                     sh.locka[sh.hdr[best_o]] = -1;
@@ -609,11 +659,11 @@ template <int CAP> struct Tick {
         P.i32[I_STEP][g] = r.step; P.i32[I_COUNT][g] = r.count; P.i32[I_META][g] = meta;
         P.i32[I_HDR][g] = hdr_word;
     }
-    static PVE_HD int pack_lanej(const EnvHeader &hd, int slot)
+    static PVE_HD int pack_lanej(const Sh &sh, int slot)
     {
         if (slot < 0) return -1;
-        int l = slot_lane(hd, slot);
-        return (l << 16) | (slot - hd.lane_start[l]);
+        int l = sh.lane_of[slot];
+        return (l << 16) | (slot - sh.hd.lane_start[l]);
     }
 
     static PVE_HD void ph_final(const Const &c, const Params &P, int env, int t, Sh &sh, Regs &r)
@@ -641,7 +691,7 @@ template <int CAP> struct Tick {
             if (sh.locka[t] > 0) meta |= M_LOCKA_POS;
             if (sh.locka[t] < 0) meta |= M_LOCKA_NEG;
             if (r.del) meta |= M_DEL;
-            hdr_word = pack_lanej(sh.hd, r.hdr);
+            hdr_word = pack_lanej(sh, r.hdr);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
                 store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word);
@@ -725,7 +775,7 @@ template <int CAP> struct Tick {
         if (P.out.nbr) {
             int *nb = P.out.nbr + gpre * NNB;
 #pragma unroll
-            for (int k = 0; k < NNB; k++) nb[k] = (r.alive && r.ctl) ? pack_lanej(sh.hd, r.kr[k]) : -1;
+            for (int k = 0; k < NNB; k++) nb[k] = (r.alive && r.ctl) ? pack_lanej(sh, r.kr[k]) : -1;
         }
         if (r.alive && r.ctl && (P.out.obs_pre || (P.out.obs_post && new_slot >= 0))) {
             // row 0 of the state, ref :1325-1337
@@ -736,7 +786,7 @@ template <int CAP> struct Tick {
                 const int x = r.kr[k];
                 if (x >= 0) {
                     row[4 + 4 * k] = r.kv[k]; row[5 + 4 * k] = sh.v[x]; row[6 + 4 * k] = sh.a[x];
-                    row[7 + 4 * k] = (double)slot_lane(sh.hd, x);
+                    row[7 + 4 * k] = (double)sh.lane_of[x];
                 } else {
                     row[4 + 4 * k] = 0; row[5 + 4 * k] = 0; row[6 + 4 * k] = 0; row[7 + 4 * k] = 0;
                 }
