@@ -102,13 +102,28 @@ PVE_HD void lds_and(int *p, int v)
     *p &= v;
 #endif
 }
-// deterministic block sum: wave shuffle tree, one partial per wave (red[] summed by thread 0 later)
+// deterministic block sum: wave-level tree, one partial per wave (red[] summed by thread 0 later).
+// Device: DPP row shifts / row broadcasts (no LDS crossbar traffic); the total lands in lane 63.
+#if PVE_DEVICE_CODE
+template <int CTRL, int ROW_MASK> PVE_HD double dpp_add_f64(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    // lanes without a valid source keep old = +0.0 (bound_ctrl off, old operand 0): adding 0 is exact
+    return x + __hiloint2double(shi, slo);
+}
+#endif
 PVE_HD void block_sum(double *red, int t, double x)
 {
 #if PVE_DEVICE_CODE
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    if ((t & 63) == 0) red[t >> 6] = x;
+    x = dpp_add_f64<0x111, 0xf>(x);      // row_shr:1
+    x = dpp_add_f64<0x112, 0xf>(x);      // row_shr:2
+    x = dpp_add_f64<0x114, 0xf>(x);      // row_shr:4
+    x = dpp_add_f64<0x118, 0xf>(x);      // row_shr:8   -> lane 15 of every row holds the row sum
+    x = dpp_add_f64<0x142, 0xa>(x);      // row_bcast:15 into rows 1 and 3
+    x = dpp_add_f64<0x143, 0xc>(x);      // row_bcast:31 into rows 2 and 3 -> lane 63 = wave sum
+    if ((t & 63) == 63) red[t >> 6] = x;
 #else
     red[0] += x;
 #endif
@@ -137,8 +152,10 @@ template <int CAP> struct Shared {
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW];
     u64 m_spawn[NW];
     // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
-    // lanes; u_* = entries in segment order, s_idx = entry indices sorted by (vd, slot). 5*CAP bounds the total.
-    int16_t s_idx[POOL];
+    // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
+    double s_vd[POOL];               // the same entries sorted by (vd, slot)
+    int16_t s_idx[POOL];             // scratch of the dead-lock leaders (LOCK phase)
+    uint8_t s_slot[POOL];
     uint8_t u_slot[POOL];
     uint8_t u_list[POOL];
     int16_t mypos[CAP];              // position of each controlled vehicle inside its own lane's list
@@ -262,14 +279,15 @@ template <int CAP> struct Tick {
         {
             const int *src = (const int *)&gh;
             int *dst = (int *)&sh.hd;
-            for (int w = t; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];
+            for (int w = t + 2; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];   // words 0-1 = clock
         }
+        if (t == 0) sh.hd.current_time = gh.current_time + c.deltaT;      // ref :223 (repeated +=, not tick*dt)
         const int N = gh.n_alive;
         const size_t g = (size_t)env * CAP + t;
         r.alive = t < N;
-        r.p = r.v = r.a = r.jerk = r.jerk_sum = 0; r.vir_dis = 100; r.closer_p = 150;
-        r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
-        if (r.alive) {
+        r.jerk = 0;
+        {   // unconditional (slots >= N hold zeros / stale values that are never used): the loads do not
+            // wait for n_alive, one memory latency instead of two
             r.p = P.f64[F_P][g]; r.v = P.f64[F_V][g]; r.a = P.f64[F_A][g];
             r.jerk_sum = P.f64[F_JERK_SUM][g]; r.vir_dis = P.f64[F_VIR_DIS][g];
             r.closer_p = P.f64[F_CLOSER_P][g];
@@ -312,7 +330,6 @@ template <int CAP> struct Tick {
     static PVE_HD void ph_step1(const Const &c, const Params &P, int env, int t, Sh &sh, Regs &r)
     {
         r.ctl = 0; r.lane = 0; r.j = 0; r.a0 = r.a1 = 0;
-        if (t == 0) sh.hd.current_time += c.deltaT;      // ref :223 (repeated +=, not tick*dt)
         if (r.alive) {
             const int lane = slot_lane(sh.hd, t);
             r.lane = lane; r.j = t - sh.hd.lane_start[lane];
@@ -433,18 +450,21 @@ template <int CAP> struct Tick {
             const int lo = sh.loff[d], hi = sh.loff[d + 1];
             int pos = 0, eq = 0;
             int f = lo;
-            for (; f + 4 <= hi; f += 4) {                 // 4 independent LDS reads per round
+            for (; f + 8 <= hi; f += 8) {                 // 8 independent LDS reads per round
                 const double w0 = sh.u_vd[f], w1 = sh.u_vd[f + 1], w2 = sh.u_vd[f + 2], w3 = sh.u_vd[f + 3];
-                pos += (w0 < vd) + (w1 < vd) + (w2 < vd) + (w3 < vd);
-                eq += (w0 == vd) + (w1 == vd) + (w2 == vd) + (w3 == vd);
+                const double w4 = sh.u_vd[f + 4], w5 = sh.u_vd[f + 5], w6 = sh.u_vd[f + 6], w7 = sh.u_vd[f + 7];
+                pos += (w0 < vd) + (w1 < vd) + (w2 < vd) + (w3 < vd) + (w4 < vd) + (w5 < vd) + (w6 < vd) + (w7 < vd);
+                eq += (w0 == vd) + (w1 == vd) + (w2 == vd) + (w3 == vd) + (w4 == vd) + (w5 == vd) + (w6 == vd) + (w7 == vd);
             }
             for (; f < hi; f++) { const double w = sh.u_vd[f]; pos += (w < vd); eq += (w == vd); }
             if (eq > 1) {                                 // exact vd ties (rare): lower slot first
                 const int slot = sh.u_slot[e];
                 for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
             }
-            sh.s_idx[lo + pos] = (int16_t)e;
-            if (e - lo < sh.lcnt[d]) sh.mypos[sh.u_slot[e]] = (int16_t)pos;   // own-lane segment comes first
+            const int myslot = sh.u_slot[e];
+            sh.s_vd[lo + pos] = vd;
+            sh.s_slot[lo + pos] = (uint8_t)myslot;
+            if (e - lo < sh.lcnt[d]) sh.mypos[myslot] = (int16_t)pos;   // own-lane segment comes first
         }
     }
 
@@ -461,54 +481,49 @@ template <int CAP> struct Tick {
         const double ps = r.p;
         const int base = sh.loff[lane], n = sh.loff[lane + 1] - base;
         if (head_thread) {                                // persisted for next tick's step (ref :1517)
-            const int e0 = (n > 0) ? sh.s_idx[base] : 0;
-            if (n > 0 && sh.u_vd[e0] < INFINITY) {
-                const int hr = sh.u_slot[e0];
+            if (n > 0 && sh.s_vd[base] < INFINITY) {
+                const int hr = sh.s_slot[base];
                 lds_or(&sh.hd.head_valid, 1 << lane);
                 int hl = sh.lane_of[hr];
-                sh.hd.head_lane[lane] = (int16_t)hl;
-                sh.hd.head_j[lane] = (int16_t)(hr - sh.hd.lane_start[hl]);
+                sh.hd.head_lane[lane] = hl;
+                sh.hd.head_j[lane] = hr - sh.hd.lane_start[hl];
             } else {
                 lds_and(&sh.hd.head_valid, ~(1 << lane));
             }
         }
         if (!ctl) return;
         const int s = sh.mypos[t];
+        const double *sv = sh.s_vd + base;
+        const uint8_t *ss = sh.s_slot + base;
         int pr = -1; double pvd = 0;
-        if (s > 0) { const int e = sh.s_idx[base + s - 1]; pr = sh.u_slot[e]; pvd = sh.u_vd[e]; }   // ref :1353-1354
+        if (s > 0) { pr = ss[s - 1]; pvd = sv[s - 1]; }                             // ref :1353-1354
         // merge outwards from our own position: left = keys below ours, right = keys above; order of the
         // reference's stable |vd - vd_self| sort = (|d|, vd, slot) (ref :1383-1397).  Equal |d| -> left first
         // (smaller vd, or equal vd and smaller slot); a run of equal vd on the left is emitted in ascending slot.
         int hi = s - 1, lo = hi, cur, rr = s + 1;
-        if (hi >= 0) {
-            const double vh = sh.u_vd[sh.s_idx[base + hi]];
-            while (lo > 0 && sh.u_vd[sh.s_idx[base + lo - 1]] == vh) lo--;
-        }
+        if (hi >= 0) { const double vh = pvd; while (lo > 0 && sv[lo - 1] == vh) lo--; }
         cur = lo;
 #pragma unroll
         for (int k = 0; k < NNB; k++) {
             const bool hasL = hi >= 0;
-            double vR = INFINITY; int eR = 0;
-            if (rr < n) { eR = sh.s_idx[base + rr]; vR = sh.u_vd[eR]; }
+            double vR = INFINITY;
+            if (rr < n) vR = sv[rr];
             const bool hasR = vR < INFINITY;
             if (hasL || hasR) {
-                double vL = 0; int eL = 0;
-                if (hasL) { eL = sh.s_idx[base + cur]; vL = sh.u_vd[eL]; }
+                double vL = 0;
+                if (hasL) vL = sv[cur];
                 const double dL = fabs(vL - ps), dR = fabs(vR - ps);              // ref :1388
                 const bool takeL = hasL && (!hasR || dL <= dR);
                 if (takeL) {
-                    r.kr[k] = sh.u_slot[eL]; r.kv[k] = vL;
+                    r.kr[k] = ss[cur]; r.kv[k] = vL;
                     cur++;
                     if (cur > hi) {
                         hi = lo - 1; lo = hi;
-                        if (hi >= 0) {
-                            const double vh = sh.u_vd[sh.s_idx[base + hi]];
-                            while (lo > 0 && sh.u_vd[sh.s_idx[base + lo - 1]] == vh) lo--;
-                        }
+                        if (hi >= 0) { const double vh = sv[hi]; while (lo > 0 && sv[lo - 1] == vh) lo--; }
                         cur = lo;
                     }
                 } else {
-                    r.kr[k] = sh.u_slot[eR]; r.kv[k] = vR;
+                    r.kr[k] = ss[rr]; r.kv[k] = vR;
                     rr++;
                 }
             }

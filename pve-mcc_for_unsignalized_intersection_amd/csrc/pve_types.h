@@ -60,7 +60,7 @@ struct EnvHeader {
     int32_t veh_rec[NL];           // arrival cursors (ref :207)
     int32_t id_seq, passed, passed_step_total;   // ref :212, 197, 198
     int32_t head_valid;            // bit d: len(virtual_lane_4[d]) > 0 at its last rebuild (ref :1517)
-    int16_t head_lane[NL], head_j[NL];           // virtual_lane_4[d][0][1:3] (stale by design)
+    int32_t head_lane[NL], head_j[NL];           // virtual_lane_4[d][0][1:3] (stale by design); dwords -> scalar loads
     int32_t collided, locks, overflow;
     int32_t pad_;
 };
