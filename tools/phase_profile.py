@@ -48,6 +48,21 @@ def main():
         if cyc[k] > 0:
             print("%-18s %12.0f  %6.1f%%" % (name, cyc[k] / waves, 100 * cyc[k] / tot))
     print("%-18s %12.0f  (wall_clock64 ticks, 100 MHz constant clock => x10 ns)" % ("total", tot / waves))
+    import numpy as np
+    per_wave = buf.sum(1).cpu().numpy().astype(float) / a.ticks
+    per_env = per_wave.reshape(a.envs, -1).max(1)
+    n_alive = env.state_field("meta").ne(0).sum(1).cpu().numpy()
+    q = np.percentile(per_env, [0, 10, 50, 90, 99, 100])
+    print("per-env wave time (avg over ticks), ticks of 10ns: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(q))
+    ph = buf.cpu().numpy().astype(float).reshape(a.envs, -1, 16).max(1) / a.ticks
+    slow = per_env >= np.percentile(per_env, 99)
+    mid = (per_env >= np.percentile(per_env, 40)) & (per_env <= np.percentile(per_env, 60))
+    print("phase means  (slowest 1%% | middle 20%%):")
+    for k, name in enumerate(PHASES):
+        if ph[:, k].sum() > 0:
+            print("   %-16s %7.0f | %7.0f" % (name, ph[slow, k].mean(), ph[mid, k].mean()))
+    print("corr(time, n_alive) = %.3f ; n_alive min/mean/max = %d / %.1f / %d" % (
+        np.corrcoef(per_env, n_alive)[0, 1], n_alive.min(), n_alive.mean(), n_alive.max()))
 
 
 if __name__ == "__main__":
