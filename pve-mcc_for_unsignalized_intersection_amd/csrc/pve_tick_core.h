@@ -457,7 +457,9 @@ template <int CAP> struct Tick {
                 eq += (w0 == vd) + (w1 == vd) + (w2 == vd) + (w3 == vd) + (w4 == vd) + (w5 == vd) + (w6 == vd) + (w7 == vd);
             }
             for (; f < hi; f++) { const double w = sh.u_vd[f]; pos += (w < vd); eq += (w == vd); }
-            if (eq > 1) {                                 // exact vd ties (rare): lower slot first
+            // unchosen entries (vd = +inf) all land on the slot right after the finite ones: one shared
+            // sentinel that ends the walks; their mutual order is irrelevant, so no tie-break for them
+            if (eq > 1 && vd < INFINITY) {                // exact vd ties (rare): lower slot first
                 const int slot = sh.u_slot[e];
                 for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
             }
@@ -631,7 +633,20 @@ template <int CAP> struct Tick {
                 for (int q = 0; q < len; q++) { cur = sh.hdr[cur]; mn = cur < mn ? cur : mn; }
                 lead = (mn == t);                         // the first member in order discovers the cycle
             }
-            if (lead) {
+            if (lead && len == 2) {
+                // the common dead-lock: two vehicles that are each other's predecessor.  Two records need no
+                // sort: min() is the tightest, and python's sum([a, b]) = a + b is order-independent.
+                const int u = sh.hdr[t];
+                const double d0 = sh.virdis[t], d1 = sh.virdis[u];
+                sh.lockf[t] = 1; sh.lockf[u] = 1;                                  // ref :1482
+                const bool t_first = d0 < d1 || (d0 == d1 && t < u);
+                const double best_d = t_first ? d0 : d1;
+                const int best_o = t_first ? t : u;
+                if (best_d < c.collision_thr || (d0 + d1) / 2.0 < c.lock_mean_thr) {   // ref :1495-1497
+                    sh.locka[best_o] = 1;
+                    sh.locka[best_o == t ? u : t] = -1;
+                }
+            } else if (lead) {
                 // records [vir_dis(o), o, header(o)] sorted ascending (ref :1486-1493); members are distinct
                 // so (vir_dis, slot) is a strict order.  The <= 10 members are first copied to a private
                 // scratch chunk (u_vd / s_idx are dead after the walk phase), then selected in sorted order
@@ -641,11 +656,13 @@ template <int CAP> struct Tick {
                 int16_t *so = sh.s_idx + chunk * 10;
                 cur = t;
                 for (int q = 0; q < len; q++) { sd[q] = sh.virdis[cur]; so[q] = (int16_t)cur; sh.lockf[cur] = 1; cur = sh.hdr[cur]; }   // ref :1482
+                for (int q = len; q < 10; q++) { sd[q] = INFINITY; so[q] = 0x7fff; }   // padding never selected
                 double last_d = -INFINITY; int last_o = -1;
                 double sum = 0, best_d = 0; int best_o = -1;
                 for (int s2 = 0; s2 < len; s2++) {
                     double md = INFINITY; int mo = 0x7fffffff;
-                    for (int q = 0; q < len; q++) {
+#pragma unroll
+                    for (int q = 0; q < 10; q++) {            // 10 independent LDS reads per selection
                         const double d = sd[q]; const int o = so[q];
                         const bool gt_last = d > last_d || (d == last_d && o > last_o);
                         if (gt_last && (d < md || (d == md && o < mo))) { md = d; mo = o; }
