@@ -96,7 +96,7 @@ def load_library(path=None):
     global _cached
     if path is None and _cached is not None:
         return _cached
-    p = path or LIB_PATH
+    p = path or os.environ.get("PVE_LIBRARY_PATH") or LIB_PATH   # env override: profiling builds
     if not os.path.isfile(p):
         raise PveError("%s not found: build the HIP library first (python -c 'import __graft_entry__ as g; "
                        "g.build()' or make -C %s/csrc). There is no CPU fallback." % (p, _HERE))

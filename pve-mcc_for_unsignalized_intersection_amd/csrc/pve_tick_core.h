@@ -656,14 +656,13 @@ template <int CAP> struct Tick {
                 int16_t *so = sh.s_idx + chunk * 10;
                 cur = t;
                 for (int q = 0; q < len; q++) { sd[q] = sh.virdis[cur]; so[q] = (int16_t)cur; sh.lockf[cur] = 1; cur = sh.hdr[cur]; }   // ref :1482
-                for (int q = len; q < 10; q++) { sd[q] = INFINITY; so[q] = 0x7fff; }   // padding never selected
                 double last_d = -INFINITY; int last_o = -1;
                 double sum = 0, best_d = 0; int best_o = -1;
                 for (int s2 = 0; s2 < len; s2++) {
                     double md = INFINITY; int mo = 0x7fffffff;
 #pragma unroll
                     for (int q = 0; q < 10; q++) {            // 10 independent LDS reads per selection
-                        const double d = sd[q]; const int o = so[q];
+                        const double d = (q < len) ? sd[q] : INFINITY; const int o = (q < len) ? (int)so[q] : 0x7fffffff;
                         const bool gt_last = d > last_d || (d == last_d && o > last_o);
                         if (gt_last && (d < md || (d == md && o < mo))) { md = d; mo = o; }
                     }
