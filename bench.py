@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default 1100 at cap 128, 500 at cap 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
+    ap.add_argument("--actor", action="store_true",
+                    help="BASELINE config 5: close the loop on the device (k_actor -> k_tick per step) instead of the action pool")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,8 +121,19 @@ def main():
     env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs)
     pool = torch.as_tensor(pool_np, device=dev)
     env.reset()
+    if args.actor:
+        wpath = os.path.join(ROOT, "tests", "golden", "actor_66.npz")
+        z = np.load(wpath)
+        env.set_actor({k: z[k] for k in z.files})       # the reference's pretrained actor (model_data/baseline/66.cptk)
+
+    def one_step(t):
+        if args.actor:
+            env.step_with_actor()
+        else:
+            env.step(pool[t % N_POOL])
+
     for t in range(W):
-        env.step(pool[t % N_POOL])
+        one_step(t)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -130,7 +143,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()                      # same stream the kernels are launched on (torch current stream)
     for t in range(W, W + K):
-        env.step(pool[t % N_POOL])
+        one_step(t)
     ev1.record()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -157,8 +170,9 @@ def main():
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d parallel 12-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
-                                   "arrivals %.0f veh/h/lane, sin action pool, fused step+scene_update+delete tick"
-                                   % (n_envs, cap, rate),
+                                   "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
+                                   % (n_envs, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
+                                      if args.actor else "sin action pool"),
                        "envs_per_gpu": n_envs, "capacity": cap, "parallelism": "env-parallel x%d" % world,
                        "outputs": list(outputs)},
             "alive_steps_per_s": tot["alive_steps"] / wall,
@@ -170,7 +184,9 @@ def main():
                          "kernel": "k_tick<%d>" % cap, "kernel_ms": kern_s * 1e3,
                          "alg_bytes_per_slot_step": B_ALG_FP64},
         }
-        if not args.no_cpu_baseline:
+        if args.actor:
+            line["roofline"]["note"] = "kernel_ms = k_actor + k_tick per step; achieved uses the tick's algorithmic bytes only"
+        if not args.no_cpu_baseline and not args.actor:
             line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, min(W, 300), min(K, 200))
         print(json.dumps(line))
     if world > 1:

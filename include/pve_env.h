@@ -153,6 +153,22 @@ int pve_step_all(pve_handle h, const double *actions, const pve_outputs *out);
 int pve_scene_update(pve_handle h, const double *actions, const pve_outputs *out);
 int pve_compact(pve_handle h, double *obs_post /* optional: rows are moved with the vehicles */);
 
+/* MADDPG actor inference on the device (reference model_agent_maddpg.py:23-49 `actor_network`, called per
+ * vehicle with batch 1 from main.py:36-45, 404): for every controlled vehicle
+ *   actions[env][slot] = 3*tanh(Dense1(relu(LN(Dense64(relu(LN(Dense64(LN(obs[env][slot]))))))))   (float32),
+ * 0 for every other slot (main.py:401).  weights: DEVICE float32[PVE_ACTOR_N_WEIGHTS] in the order
+ * LayerNorm{gamma[28],beta[28]}, dense{kernel[28][64],bias[64]}, LayerNorm_1{gamma,beta}[64],
+ * dense_1{kernel[64][64],bias[64]}, LayerNorm_2{gamma,beta}[64], dense_2{kernel[64],bias[1]} (TF variable
+ * layouts, checkpoint names `agent1actor/...`).  obs: [n_envs][cap][28] float64 (= obs_post of the previous
+ * tick, zeros after reset); actions: [n_envs][cap] float64 out. */
+#define PVE_ACTOR_N_WEIGHTS 6393
+int pve_actor_forward(pve_handle h, const float *weights, const double *obs, double *actions);
+
+/* Closed loop on the device, no host round trip: pve_actor_forward(obs_in -> actions) followed by
+ * pve_step_all(actions, out) on the same stream (BASELINE config 5). out->obs_post must not alias obs_in. */
+int pve_step_all_actor(pve_handle h, const float *weights, const double *obs_in, double *actions,
+                       const pve_outputs *out);
+
 /* Host read-back (synchronises the stream). */
 int pve_read_env(pve_handle h, int env, pve_env_info *out);
 int pve_read_vehicles(pve_handle h, int env, pve_vehicle *out, int max_n, int *n_out);

@@ -15,6 +15,7 @@ PVE_OBS_WIDTH = 28
 PVE_NBR = 6
 PVE_N_METRICS = 12
 PVE_ENV_OUT_N = 8
+PVE_ACTOR_N_WEIGHTS = 6393
 ABI_VERSION = 1
 
 F_ALIVE, F_CTL, F_DONE, F_DELETED, F_FINISHED, F_LOCK = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
@@ -57,7 +58,8 @@ class PveEnvInfo(C.Structure):
 EXPORTS = ("pve_abi_version", "pve_last_error", "pve_default_config", "pve_workspace_bytes", "pve_create",
            "pve_destroy", "pve_set_stream", "pve_set_arrivals", "pve_reset", "pve_step_all",
            "pve_scene_update", "pve_compact", "pve_read_env", "pve_read_vehicles", "pve_get_metrics",
-           "pve_state_field", "pve_synchronize", "pve_debug_phase_cycles")
+           "pve_state_field", "pve_synchronize", "pve_debug_phase_cycles", "pve_actor_forward",
+           "pve_step_all_actor")
 
 
 def _declare(L):
@@ -81,6 +83,8 @@ def _declare(L):
     L.pve_state_field.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int)]
     L.pve_synchronize.argtypes = [vp]
     L.pve_debug_phase_cycles.argtypes = [vp, vp]
+    L.pve_actor_forward.argtypes = [vp, vp, vp, vp]
+    L.pve_step_all_actor.argtypes = [vp, vp, vp, vp, C.POINTER(PveOutputs)]
     for name in EXPORTS:
         if name not in ("pve_last_error", "pve_workspace_bytes", "pve_default_config"):
             getattr(L, name).restype = C.c_int

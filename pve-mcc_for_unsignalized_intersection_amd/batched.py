@@ -173,6 +173,43 @@ class BatchedIntersections:
         self.ticks += 1
         return self.outputs()
 
+    # ------------------------------------------------------------------ on-device MADDPG actor
+    ACTOR_KEYS = ("ln0_gamma", "ln0_beta", "w1", "b1", "ln1_gamma", "ln1_beta", "w2", "b2", "ln2_gamma",
+                  "ln2_beta", "w3", "b3")
+
+    def set_actor(self, weights):
+        """Pin the actor weights on the device. weights: flat float32[6393] tensor/array, or a dict with the
+        TF variables LayerNorm{,_1,_2}/{gamma,beta} as ln{0,1,2}_{gamma,beta} and dense{,_1,_2}/{kernel,bias}
+        as w{1,2,3}/b{1,2,3} (kernels in TF layout [in][out])."""
+        if isinstance(weights, dict):
+            weights = np.concatenate([np.asarray(weights[k], np.float32).ravel() for k in self.ACTOR_KEYS])
+        w = torch.as_tensor(weights, dtype=torch.float32).contiguous()
+        if w.numel() != _capi.PVE_ACTOR_N_WEIGHTS:
+            raise PveError("actor needs %d float32 weights, got %d" % (_capi.PVE_ACTOR_N_WEIGHTS, w.numel()))
+        self._actor_w = w.to(self.device)
+        self._actor_actions = torch.zeros(self.n_envs, self.capacity, dtype=torch.float64, device=self.device)
+
+    def act(self):
+        """actions [n_envs, capacity] = actor(obs) for the controlled slots, 0 elsewhere (device tensor)."""
+        self.lib.pve_set_stream(self._h, self._stream_ptr())
+        check(self.lib, self.lib.pve_actor_forward(self._h, C.c_void_p(self._actor_w.data_ptr()),
+                                                   C.c_void_p(self.obs.data_ptr()),
+                                                   C.c_void_p(self._actor_actions.data_ptr())), "pve_actor_forward")
+        return self._actor_actions
+
+    def step_with_actor(self):
+        """One closed-loop tick entirely on the device: actor(obs) -> fused tick (two launches, no host
+        round trip; main.py:398-441 with the actor of model_agent_maddpg.py)."""
+        self.lib.pve_set_stream(self._h, self._stream_ptr())
+        obs_in = self._obs[self._obs_cur]
+        o = self._outputs_struct(flip_obs=True)
+        check(self.lib, self.lib.pve_step_all_actor(self._h, C.c_void_p(self._actor_w.data_ptr()),
+                                                    C.c_void_p(obs_in.data_ptr()),
+                                                    C.c_void_p(self._actor_actions.data_ptr()), C.byref(o)),
+              "pve_step_all_actor")
+        self.ticks += 1
+        return self.outputs()
+
     def scene_update(self, actions=None):
         """Split protocol, part 1: all step() calls + scene_update(); Done vehicles stay in place."""
         a = self._zero_actions if actions is None else actions

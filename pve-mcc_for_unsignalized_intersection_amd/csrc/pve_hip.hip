@@ -13,6 +13,7 @@
 
 #include "pve_host.h"
 #include "pve_tick_core.h"
+#include "pve_actor.h"
 
 using namespace pve;
 
@@ -154,6 +155,14 @@ struct Backend {
         hipStream_t s = (hipStream_t)stream;
         if (cap == 64) hipLaunchKernelGGL(k_compact<64>, dim3(P.n_envs), dim3(64), 0, s, P);
         else hipLaunchKernelGGL(k_compact<128>, dim3(P.n_envs), dim3(128), 0, s, P);
+        return check_launch(err);
+    }
+    static int launch_actor(const float *W, const double *obs, const int32_t *meta, double *actions, int n_envs,
+                            int cap, void *stream, std::string &err)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        if (cap == 64) hipLaunchKernelGGL(k_actor<64>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+        else hipLaunchKernelGGL(k_actor<128>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
         return check_launch(err);
     }
     static int launch_reset(const Const &c, const Params &P, int cap, void *stream, std::string &err)

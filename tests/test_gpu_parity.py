@@ -119,3 +119,16 @@ def test_gpu_full_state_rows_fresh_and_stale(name):
         ra, rb = orc.tick(acts, want_state=True), env.tick(acts, want_state=True)
         assert rb["state"] is not None
         compare_records(ra, rb, tol=TOL, label=name)
+
+
+def test_gpu_actor_matches_numpy_restatement():
+    """k_actor (float32, scalar-broadcast weights) vs the pinned NumPy actor on the states of the oracle's
+    closed loop: action-level tolerance 5e-4 on a in [-3, 3] (float32 round-off through 3 LayerNorms)."""
+    from tests import actor_scenarios as A
+    worst = A.check_actions_on_oracle_states("hip", ticks=300)
+    assert worst <= A.ACTION_TOL
+
+
+def test_gpu_closed_loop_actor_plus_tick():
+    from tests import actor_scenarios as A
+    A.check_closed_loop_on_device("hip", ticks=1000)
