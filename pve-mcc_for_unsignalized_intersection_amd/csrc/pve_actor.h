@@ -25,8 +25,7 @@ static_assert(AW_TOTAL == 6393, "actor weight count (SURVEY 8f-1)");
 #if defined(__HIPCC__)
 
 template <int N>
-__device__ __forceinline__ void layer_norm_relu(float (&h)[N], const float *__restrict__ gamma,
-                                                const float *__restrict__ beta, bool relu)
+__device__ __forceinline__ void layer_norm_relu(float (&h)[N], const float *gamma, const float *beta, bool relu)
 {   // tc.layers.layer_norm: biased variance over the last axis, eps = 1e-12; y = x*inv + (beta - mean*inv)
     float s = 0.f;
 #pragma unroll
@@ -44,12 +43,20 @@ __device__ __forceinline__ void layer_norm_relu(float (&h)[N], const float *__re
     }
 }
 
+// acc[0..63] += x_i * row_i[0..63] for NROWS staged inputs; the row is wave-uniform (scalar loads)
+#define PVE_ACTOR_DENSE(ACC, NROWS, WBASE, STAGE_ROW0)                                        \
+    for (int i = 0; i < (NROWS); i++) {                                                       \
+        const float xi = stage[(STAGE_ROW0) + i][lane];                                       \
+        const float *__restrict__ wr = W + (WBASE) + i * ACT_H;                               \
+        _Pragma("unroll") for (int j = 0; j < ACT_H; j++) ACC[j] = fmaf(xi, wr[j], ACC[j]);   \
+    }
+
 template <int CAP>
 __global__ __launch_bounds__(64) void k_actor(const float *__restrict__ W, const double *__restrict__ obs,
                                               const int32_t *__restrict__ meta, double *__restrict__ actions,
                                               int n_envs)
 {
-    __shared__ float stage[ACT_H][64];        // activations of the previous layer, [k][lane]
+    __shared__ float stage[32][64];           // 32 activations of the previous layer at a time, [k][lane]
     __shared__ unsigned char slot_of[CAP];
     const int env = blockIdx.x, lane = threadIdx.x;
     const size_t base = (size_t)env * CAP;
@@ -83,25 +90,19 @@ __global__ __launch_bounds__(64) void k_actor(const float *__restrict__ W, const
         float h[ACT_H];
 #pragma unroll
         for (int j = 0; j < ACT_H; j++) h[j] = W[AW_B1 + j];
-        for (int i = 0; i < ACT_IN; i++) {
-            const float xi = stage[i][lane];
-            const float *__restrict__ wr = W + AW_W1 + i * ACT_H;       // wave-uniform row -> scalar loads
-#pragma unroll
-            for (int j = 0; j < ACT_H; j++) h[j] = fmaf(xi, wr[j], h[j]);
-        }
+        PVE_ACTOR_DENSE(h, ACT_IN, AW_W1, 0)
         layer_norm_relu<ACT_H>(h, W + AW_LN1_G, W + AW_LN1_B, true);
-#pragma unroll
-        for (int k = 0; k < ACT_H; k++) stage[k][lane] = h[k];
-        // ---- dense 64 -> 64
+        // ---- dense 64 -> 64, the 64 inputs staged 32 at a time (the lane's LDS column is private: DS
+        //      operations of one wave execute in order, no barrier needed)
         float g[ACT_H];
 #pragma unroll
         for (int j = 0; j < ACT_H; j++) g[j] = W[AW_B2 + j];
-        for (int i = 0; i < ACT_H; i++) {
-            const float hi = stage[i][lane];
-            const float *__restrict__ wr = W + AW_W2 + i * ACT_H;
 #pragma unroll
-            for (int j = 0; j < ACT_H; j++) g[j] = fmaf(hi, wr[j], g[j]);
-        }
+        for (int k = 0; k < 32; k++) stage[k][lane] = h[k];
+        PVE_ACTOR_DENSE(g, 32, AW_W2, 0)
+#pragma unroll
+        for (int k = 0; k < 32; k++) stage[k][lane] = h[32 + k];
+        PVE_ACTOR_DENSE(g, 32, AW_W2 + 32 * ACT_H, 0)
         layer_norm_relu<ACT_H>(g, W + AW_LN2_G, W + AW_LN2_B, true);
         // ---- dense 64 -> 1, 3*tanh
         float y = W[AW_B3];
@@ -109,7 +110,6 @@ __global__ __launch_bounds__(64) void k_actor(const float *__restrict__ W, const
         for (int j = 0; j < ACT_H; j++) y = fmaf(g[j], W[AW_W3 + j], y);
         const float a = 3.0f * tanhf(y);
         if (active) actions[base + slot] = (double)a;
-        // (stage[][lane] is private to the lane: no barrier needed between batches)
     }
 }
 
