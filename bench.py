@@ -77,6 +77,21 @@ def cpu_baseline(arr, pool, cap, warm, ticks):
                        "%.2f s wall" % (n, ticks, warm, cores, dt))
 
 
+def pmc_traffic(n_envs, cap, outputs, actor):
+    """HBM bytes per k_tick launch from the PMC counters (FETCH_SIZE x gfx950 correction + WRITE_SIZE). Counters
+    cannot be read from inside the process, so they come from the committed rocprofv3 passes of this very
+    command (tools/collect_profiles.sh -> profiles/r*_traffic.json); null when the config differs."""
+    import glob
+    default_outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
+    if actor or n_envs != 4096 or cap != 128 or tuple(outputs) != default_outputs:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    t = json.load(open(files[-1]))
+    return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +179,7 @@ def main():
         value = slot_steps / wall
         kern_s = gpu_ms * 1e-3 / K
         achieved = B_ALG_FP64 * cap * n_envs / kern_s / 1e9
+        traffic, traffic_src = pmc_traffic(n_envs, cap, outputs, args.actor)
         line = {
             "metric": "env-steps/sec (vehicles x envs x steps/s) at 128 veh x 4096 envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -180,7 +196,8 @@ def main():
             "mean_alive_per_env": tot["alive_steps"] / (K * n_envs * world),
             "overflow": tot["overflow"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "kernel": "k_tick<%d>" % cap, "kernel_ms": kern_s * 1e3,
                          "alg_bytes_per_slot_step": B_ALG_FP64},
         }

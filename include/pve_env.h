@@ -190,6 +190,11 @@ int pve_synchronize(pve_handle h);
  * walk, effects, lock, final, state); NULL disables. Used by tools/phase_profile.py; no effect on results. */
 int pve_debug_phase_cycles(pve_handle h, uint64_t *dev_counters16);
 
+/* Diagnostics: launch a kernel that performs exactly the tick's state-load pattern over every slot
+ * (72 B per slot read: 6 x f64 + 6 x i32) and stores one int per env into dev_sink[n_envs]; a known byte
+ * count for calibrating rocprofv3 FETCH_SIZE on this access width. */
+int pve_debug_traffic_probe(pve_handle h, int32_t *dev_sink);
+
 #ifdef __cplusplus
 }
 #endif

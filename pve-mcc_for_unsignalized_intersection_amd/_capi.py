@@ -59,7 +59,7 @@ EXPORTS = ("pve_abi_version", "pve_last_error", "pve_default_config", "pve_works
            "pve_destroy", "pve_set_stream", "pve_set_arrivals", "pve_reset", "pve_step_all",
            "pve_scene_update", "pve_compact", "pve_read_env", "pve_read_vehicles", "pve_get_metrics",
            "pve_state_field", "pve_synchronize", "pve_debug_phase_cycles", "pve_actor_forward",
-           "pve_step_all_actor")
+           "pve_step_all_actor", "pve_debug_traffic_probe")
 
 
 def _declare(L):
@@ -83,6 +83,7 @@ def _declare(L):
     L.pve_state_field.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int)]
     L.pve_synchronize.argtypes = [vp]
     L.pve_debug_phase_cycles.argtypes = [vp, vp]
+    L.pve_debug_traffic_probe.argtypes = [vp, vp]
     L.pve_actor_forward.argtypes = [vp, vp, vp, vp]
     L.pve_step_all_actor.argtypes = [vp, vp, vp, vp, C.POINTER(PveOutputs)]
     for name in EXPORTS:

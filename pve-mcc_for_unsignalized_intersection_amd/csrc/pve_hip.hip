@@ -94,6 +94,21 @@ __global__ __launch_bounds__(CAP) void k_compact(const Params P)
     Tick<CAP>::ph_c_store(P, env, t, sh, r);
 }
 
+// diagnostics (pve_debug_traffic_probe): exactly the load pattern of the tick's load phase (6 f64 + 6 i32
+// SoA rows per env, 8 B / 4 B per lane, every slot) and one dword store per workgroup -- a kernel with a KNOWN
+// byte count to calibrate rocprofv3's FETCH_SIZE for this access width (MI355X_MICROARCH.md, HBM section)
+template <int CAP>
+__global__ __launch_bounds__(CAP) void k_probe(const Params P, int *sink)
+{
+    const size_t g = (size_t)blockIdx.x * CAP + threadIdx.x;
+    double a = P.f64[F_P][g] + P.f64[F_V][g] + P.f64[F_A][g] + P.f64[F_JERK_SUM][g] + P.f64[F_VIR_DIS][g] +
+               P.f64[F_CLOSER_P][g];
+    int b = P.i32[I_ID][g] + P.i32[I_SEQ][g] + P.i32[I_VNUM][g] + P.i32[I_STEP][g] + P.i32[I_COUNT][g] +
+            P.i32[I_META][g];
+    unsigned long long m = __ballot(a + (double)b == 12345.678);
+    if (threadIdx.x == 0) sink[blockIdx.x] = (int)m;
+}
+
 template <int CAP>
 __global__ __launch_bounds__(64) void k_reset(const Const c, const Params P, int cap_ticks)
 {
@@ -163,6 +178,13 @@ struct Backend {
         hipStream_t s = (hipStream_t)stream;
         if (cap == 64) hipLaunchKernelGGL(k_actor<64>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
         else hipLaunchKernelGGL(k_actor<128>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+        return check_launch(err);
+    }
+    static int launch_probe(const Params &P, int cap, int *sink, void *stream, std::string &err)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        if (cap == 64) hipLaunchKernelGGL(k_probe<64>, dim3(P.n_envs), dim3(64), 0, s, P, sink);
+        else hipLaunchKernelGGL(k_probe<128>, dim3(P.n_envs), dim3(128), 0, s, P, sink);
         return check_launch(err);
     }
     static int launch_reset(const Const &c, const Params &P, int cap, void *stream, std::string &err)

@@ -107,6 +107,7 @@ struct Backend {
         }
         return 0;
     }
+    static int launch_probe(const Params &, int, int *, void *, std::string &) { return 0; }
     static int launch_reset(const Const &c, const Params &P, int cap, void *, std::string &)
     {
         for (int env = 0; env < P.n_envs; env++) {
