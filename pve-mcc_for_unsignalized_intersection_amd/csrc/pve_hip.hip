@@ -66,6 +66,8 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
     PVE_PHASE_MARK(7)
     T::ph_lock(c, t, sh, r);
     __syncthreads();
+    T::ph_lock2(t, sh, r);
+    __syncthreads();
     PVE_PHASE_MARK(8)
     T::ph_final(c, P, env, t, sh, r);
     PVE_PHASE_MARK(9)

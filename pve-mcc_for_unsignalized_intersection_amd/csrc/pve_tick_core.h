@@ -78,12 +78,12 @@ PVE_HD void lds_add(int *p, int v)
     *p += v;
 #endif
 }
-PVE_HD int lds_claim(int *p)        // returns a distinct small integer per caller
+PVE_HD int lds_claim(int *p, int n)  // reserves n consecutive units, returns the first (any order is fine)
 {
 #if PVE_DEVICE_CODE
-    return atomicAdd(p, 1);
+    return atomicAdd(p, n);
 #else
-    return (*p)++;
+    int o = *p; *p += n; return o;
 #endif
 }
 PVE_HD void lds_or(int *p, int v)
@@ -146,8 +146,6 @@ template <int CAP> struct Shared {
     int acc_passed_steps, acc_collisions;
     int16_t hdr[CAP];                // slot of the virtual header (predecessor) or -1
     uint8_t bb[CAP];                 // brake bits: bit0 if front did not brake, bit1 if it did
-    uint8_t lockf[CAP];
-    int8_t locka[CAP];
     uint8_t rew_ovr[CAP];
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW];
     u64 m_spawn[NW];
@@ -166,7 +164,8 @@ template <int CAP> struct Shared {
     uint8_t lane_of[CAP];            // lane of every alive slot
     double tabA[2][4], tabB[2][4], tabC[2][4];   // get_virtual_distance table (copy of Const, lane-indexed reads)
     int8_t l2l[NL][4], l2l_inv[NL][4];
-    int lead_n;                      // dead-lock leaders that claimed a scratch chunk
+    int lead_n;                      // scratch units claimed by the dead-lock cycles
+    int16_t cyc_off[CAP];            // scratch offset of the cycle led by slot t
 };
 
 struct Regs {
@@ -180,6 +179,7 @@ struct Regs {
     int hdr;
     int hit, coll_seen, coll_fin;
     int alive, ctl, del, fin;
+    int cyc;                         // dead-lock cycle membership: bit0 | len << 1 | rank << 5 | leader slot << 9
 };
 struct CRegs {                       // MODE_COMPACT moves every persistent field verbatim
     double p, v, a, jerk, jerk_sum, vir_dis, closer_p;
@@ -294,7 +294,7 @@ template <int CAP> struct Tick {
             r.id = P.i32[I_ID][g]; r.seq = P.i32[I_SEQ][g]; r.vnum = P.i32[I_VNUM][g];
             r.step = P.i32[I_STEP][g]; r.count = P.i32[I_COUNT][g]; r.meta = P.i32[I_META][g];
         }
-        sh.cnt[t] = 0; sh.lockf[t] = 0; sh.locka[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
+        sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
         if (t < NL) {
             int rec = gh.veh_rec[t];
             double nxt = INFINITY;
@@ -619,64 +619,42 @@ template <int CAP> struct Tick {
         if (r.alive && r.ctl && sh.rew_ovr[t]) r.reward = -10;                    // ref :346 via reward[-1]
         block_sum(sh.red_reward, t, (r.alive && r.ctl) ? r.reward : 0.0);
         block_sum(sh.red_jerk, t, r.fin ? r.jerk_sum : 0.0);                      // ref :358
+        // Dead-lock scan (ref :365-370, :1469-1499), member-parallel: every controlled vehicle follows the
+        // virtual-header pointers for <= 10 hops; if the walk returns to itself it is on a cycle and has, on the
+        // way, seen every other member: it knows the cycle length, the smallest slot (= the member that discovers
+        // the cycle in the reference's (lane, j) scan order) and its own rank in the reference's sorted record
+        // list [vir_dis, lane, j, ...] (ref :1486-1492).  The first member reserves a scratch range for the cycle.
         bool lead = false;
-        if (r.alive && !r.del && (r.meta & M_CONTROL)) {                          // ref :365-370
-            int cur = t, len = 0;
+        r.cyc = 0;
+        if (r.alive && !r.del && (r.meta & M_CONTROL)) {
+            const double dv = sh.virdis[t];
+            int cur = t, len = 0, mn = t, rank = 0;
             bool found = false;
             for (int hop = 0; hop < 10; hop++) {                                  // ref :1470-1478
                 cur = sh.hdr[cur];
                 if (cur < 0) break;
                 if (cur == t) { found = true; len = hop + 1; break; }
+                const double d = sh.virdis[cur];
+                rank += (d < dv || (d == dv && cur < t)) ? 1 : 0;
+                mn = cur < mn ? cur : mn;
             }
             if (found) {
-                int mn = t; cur = t;
-                for (int q = 0; q < len; q++) { cur = sh.hdr[cur]; mn = cur < mn ? cur : mn; }
-                lead = (mn == t);                         // the first member in order discovers the cycle
-            }
-            if (lead && len == 2) {
-                // the common dead-lock: two vehicles that are each other's predecessor.  Two records need no
-                // sort: min() is the tightest, and python's sum([a, b]) = a + b is order-independent.
-                const int u = sh.hdr[t];
-                const double d0 = sh.virdis[t], d1 = sh.virdis[u];
-                sh.lockf[t] = 1; sh.lockf[u] = 1;                                  // ref :1482
-                const bool t_first = d0 < d1 || (d0 == d1 && t < u);
-                const double best_d = t_first ? d0 : d1;
-                const int best_o = t_first ? t : u;
-                if (best_d < c.collision_thr || (d0 + d1) / 2.0 < c.lock_mean_thr) {   // ref :1495-1497
-                    sh.locka[best_o] = 1;
-                    sh.locka[best_o == t ? u : t] = -1;
-                }
-            } else if (lead) {
-                // records [vir_dis(o), o, header(o)] sorted ascending (ref :1486-1493); members are distinct
-                // so (vir_dis, slot) is a strict order.  The <= 10 members are first copied to a private
-                // scratch chunk (u_vd / s_idx are dead after the walk phase), then selected in sorted order
-                // with independent LDS reads; the running sum follows python's left-to-right sum().
-                const int chunk = lds_claim(&sh.lead_n);          // any distinct chunk will do
-                double *sd = sh.u_vd + chunk * 10;
-                int16_t *so = sh.s_idx + chunk * 10;
-                cur = t;
-                for (int q = 0; q < len; q++) { sd[q] = sh.virdis[cur]; so[q] = (int16_t)cur; sh.lockf[cur] = 1; cur = sh.hdr[cur]; }   // ref :1482
-                double last_d = -INFINITY; int last_o = -1;
-                double sum = 0, best_d = 0; int best_o = -1;
-                for (int s2 = 0; s2 < len; s2++) {
-                    double md = INFINITY; int mo = 0x7fffffff;
-#pragma unroll
-                    for (int q = 0; q < 10; q++) {            // 10 independent LDS reads per selection
-                        const double d = (q < len) ? sd[q] : INFINITY; const int o = (q < len) ? (int)so[q] : 0x7fffffff;
-                        const bool gt_last = d > last_d || (d == last_d && o > last_o);
-                        if (gt_last && (d < md || (d == md && o < mo))) { md = d; mo = o; }
-                    }
-                    sum = sum + md;
-                    if (s2 == 0) { best_d = md; best_o = mo; }
-                    last_d = md; last_o = mo;
-                }
-                if (best_d < c.collision_thr || sum / (double)len < c.lock_mean_thr) {    // ref :1495-1497
-                    sh.locka[best_o] = 1;
-                    sh.locka[sh.hdr[best_o]] = -1;
-                }
+                r.cyc = 1 | (len << 1) | (rank << 5) | (mn << 9);
+                lead = (mn == t);
+                if (lead) sh.cyc_off[t] = (int16_t)lds_claim(&sh.lead_n, len);
             }
         }
         vote<NW>(sh.m_lead, t, lead);
+    }
+    // LOCK2 (after a barrier): every cycle member files its record at its rank inside the cycle's scratch range
+    // (u_vd / s_idx are dead after the walk phase) = the reference's record_.sort() (ref :1492)
+    static PVE_HD void ph_lock2(int t, Sh &sh, Regs &r)
+    {
+        if (r.cyc & 1) {
+            const int e = sh.cyc_off[r.cyc >> 9] + ((r.cyc >> 5) & 15);
+            sh.u_vd[e] = sh.virdis[t];
+            sh.s_idx[e] = (int16_t)t;
+        }
     }
     // NOTE: if the tightest record's header is the tightest vehicle itself (1-cycle) the reference
     // writes +1 then -1; a vehicle is never its own predecessor, so cycles have length >= 2.
@@ -714,13 +692,25 @@ template <int CAP> struct Tick {
 #pragma unroll
         for (int k = 0; k < NW; k++) keep[k] = fused ? (sh.m_alive[k] & ~sh.m_del[k]) : sh.m_alive[k];
         // ---- per-slot meta
-        int meta = 0, hdr_word = -1, new_slot = -1;
+        int meta = 0, hdr_word = -1, new_slot = -1, lockf = 0;
         if (r.alive) {
             int coll = r.coll_fin > M_COLL_MASK ? M_COLL_MASK : r.coll_fin;
             meta = (r.meta & (M_CONTROL | M_FINISH | M_DONE)) | M_ALIVE | (coll << M_COLL_SHIFT);
-            if (sh.lockf[t]) meta |= M_LOCK;
-            if (sh.locka[t] > 0) meta |= M_LOCKA_POS;
-            if (sh.locka[t] < 0) meta |= M_LOCKA_NEG;
+            if (r.cyc & 1) {
+                // every member evaluates its cycle's verdict itself: records sorted by rank, python's left-to-right
+                // sum(), tightest record first (ref :1493-1497); +1 for the tightest vehicle, -1 for its header
+                const int len = (r.cyc >> 1) & 15, off = sh.cyc_off[r.cyc >> 9];
+                double sum = 0;
+#pragma unroll
+                for (int q = 0; q < 10; q++) if (q < len) sum = sum + sh.u_vd[off + q];
+                const int best_o = sh.s_idx[off];
+                meta |= M_LOCK;                                                    // ref :1482
+                lockf = 1;
+                if (sh.u_vd[off] < c.collision_thr || sum / (double)len < c.lock_mean_thr) {
+                    if (best_o == t) meta |= M_LOCKA_POS;
+                    else if (sh.hdr[best_o] == t) meta |= M_LOCKA_NEG;
+                }
+            }
             if (r.del) meta |= M_DEL;
             hdr_word = pack_lanej(sh, r.hdr);
             if (mask_test(keep, t)) {
@@ -796,7 +786,7 @@ template <int CAP> struct Tick {
             int f = 0;
             if (r.alive) {
                 f = 0x01 | (r.ctl ? 0x02 : 0) | ((r.meta & M_DONE) ? 0x04 : 0) | (r.del ? 0x08 : 0) |
-                    (r.fin ? 0x10 : 0) | (sh.lockf[t] ? 0x20 : 0) | (r.ctl ? (r.coll_seen << 8) : 0);
+                    (r.fin ? 0x10 : 0) | (lockf ? 0x20 : 0) | (r.ctl ? (r.coll_seen << 8) : 0);
             }
             P.out.flags[gpre] = f;
         }
