@@ -158,7 +158,7 @@ template <int CAP> struct Shared {
     uint8_t u_list[POOL];
     int16_t mypos[CAP];              // position of each controlled vehicle inside its own lane's list
     int16_t lcnt[NL];                // controlled vehicles per lane
-    int16_t nl[NL];                  // entries of list d
+    int16_t segcnt[NL][5];           // controlled vehicles of segment k (own lane, conflict lanes 0..3) of list d
     int16_t loff[NL + 1];            // list d occupies [loff[d], loff[d+1])
     int16_t segoff[NL][5];           // start of segment (own, conflict 0..3) inside list d
     uint8_t lane_of[CAP];            // lane of every alive slot
@@ -218,31 +218,26 @@ PVE_HD void sincos_q1(double x, double &sn, double &cs)
 }
 
 PVE_HD void get_xy(const Const &c, double p, int lane, double &X, double &Y)
-{
+{   // straight-line (select-based) so that the two evaluations per vehicle pair overlap in the pipeline
     const double cw = c.cw;
     const int m = lane % 3;
     const double Lb = c.inbox[m == 2 ? 2 : 0];
-    const bool arc = (m != 1) && (p > 0) && !(p > Lb);
-    double sn = 0, cs = 1;
-    if (arc) sincos_q1((Lb - p) / Lb * c.arc_k / 2, sn, cs);      // r_a, ref :1259, :1277
-    double x, y;
-    if (m == 0) {
-        if (p > Lb) { x = p - Lb + 6 * cw; y = cw; }
-        else if (p > 0) {
-            double p0x = 6 * cw, p0y = cw, prx = 6 * cw, pry = -6 * cw;
-            x = prx + (p0x - prx) * cs - (p0y - pry) * sn;
-            y = pry + (p0y - pry) * cs + (p0x - prx) * sn;
-        } else { x = -cw; y = -6 * cw + p; }
-    } else if (m == 1) {
-        x = p - 6 * cw; y = 3 * cw;
-    } else {
-        if (p > Lb) { x = p - Lb + 6 * cw; y = 5 * cw; }
-        else if (p > 0) {
-            double p0x = 6 * cw, p0y = 5 * cw, prx = 6 * cw, pry = 6 * cw;
-            x = prx + (p0x - prx) * cs + (p0y - pry) * sn;
-            y = pry + (p0y - pry) * cs - (p0x - prx) * sn;
-        } else { x = 5 * cw; y = 6 * cw - p; }
-    }
+    const bool before = p > Lb, inside = !before && p > 0;
+    const bool arc = (m != 1) && inside;
+    double sn, cs;
+    sincos_q1(arc ? ((Lb - p) / Lb * c.arc_k / 2) : 0.0, sn, cs);   // r_a, ref :1259, :1277
+    // left turn (ref :1253-1267): approach y = cw, arc about (6cw, -6cw), exit x = -cw
+    // right turn (ref :1271-1286): approach y = 5cw, arc about (6cw, 6cw) clockwise, exit x = 5cw
+    const double p0y = (m == 0) ? cw : 5 * cw, pry = (m == 0) ? -6 * cw : 6 * cw;
+    const double p0x = 6 * cw, prx = 6 * cw;
+    const double ax = (m == 0) ? (prx + (p0x - prx) * cs - (p0y - pry) * sn) : (prx + (p0x - prx) * cs + (p0y - pry) * sn);
+    const double ay = (m == 0) ? (pry + (p0y - pry) * cs + (p0x - prx) * sn) : (pry + (p0y - pry) * cs - (p0x - prx) * sn);
+    const double bx = p - Lb + 6 * cw, by = p0y;                       // before the box
+    const double ex = (m == 0) ? -cw : 5 * cw;                          // after the box
+    const double ey = (m == 0) ? (-6 * cw + p) : (6 * cw - p);
+    double x = before ? bx : (inside ? ax : ex);
+    double y = before ? by : (inside ? ay : ey);
+    if (m == 1) { x = p - 6 * cw; y = 3 * cw; }                         // straight (ref :1268-1270)
     const double rc = c.rot_cos[lane / 3], rs = c.rot_sin[lane / 3];
     X = x * rc - y * rs;
     Y = y * rc + x * rs;
@@ -390,27 +385,29 @@ template <int CAP> struct Tick {
     // thread d < 12: size and segment layout of virtual-lane list d from the controlled-vehicle ballot.
     static PVE_HD void ph_lists_a(const Const &c, int t, Sh &sh)
     {
-        if (t < NL) {
-            const int d = t;
-            int own = mask_below<NW>(sh.m_ctl, sh.hd.lane_start[d + 1]) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[d]);
-            sh.lcnt[d] = (int16_t)own;
-            int n = own;
-            sh.segoff[d][0] = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                sh.segoff[d][k + 1] = (int16_t)n;
-                const int L = sh.l2l[d][k];
-                if (L >= 0)
-                    n += mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L + 1]) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L]);
-            }
-            sh.nl[d] = (int16_t)n;
+        if (t < NL * 5) {                                 // lane t: segment k of list d
+            const int d = t / 5, k = t - d * 5;
+            const int L = (k == 0) ? d : (int)sh.l2l[d][k - 1];
+            int cnt = 0;
+            if (L >= 0)
+                cnt = mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L + 1]) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L]);
+            sh.segcnt[d][k] = (int16_t)cnt;
         }
     }
     static PVE_HD void ph_lists_b(int t, Sh &sh)
     {
-        if (t <= NL) {
+        if (t < NL) {                                     // segment layout of list t
+            int n = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) { sh.segoff[t][k] = (int16_t)n; n += sh.segcnt[t][k]; }
+            sh.lcnt[t] = sh.segcnt[t][0];
+        }
+        if (t <= NL) {                                    // list offsets (prefix over the lists before t)
             int o = 0;
-            for (int d = 0; d < t; d++) o += sh.nl[d];
+            for (int d = 0; d < t; d++) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) o += sh.segcnt[d][k];
+            }
             sh.loff[t] = (int16_t)o;
         }
     }
