@@ -102,6 +102,21 @@ PVE_HD void lds_and(int *p, int v)
     *p &= v;
 #endif
 }
+// inclusive prefix sum over the lanes of one wave (emulator: lanes run in increasing order -> running sum)
+PVE_HD int wave_incl_scan(int t, int x, int *emu_acc)
+{
+#if PVE_DEVICE_CODE
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if ((t & 63) >= o) x += y;
+    }
+    return x;
+#else
+    *emu_acc += x;
+    return *emu_acc;
+#endif
+}
 // deterministic block sum: wave-level tree, one partial per wave (red[] summed by thread 0 later).
 // Device: DPP row shifts / row broadcasts (no LDS crossbar traffic); the total lands in lane 63.
 #if PVE_DEVICE_CODE
@@ -140,7 +155,6 @@ template <int CAP> struct Shared {
         double u_vd[POOL];           // virtual distance of every list entry (segment order)
     };
     double virdis[CAP];
-    double next_arr[NL];
     double red_reward[NW], red_jerk[NW];
     int cnt[CAP];                    // collision hits received: early | late << 16
     int acc_passed_steps, acc_collisions;
@@ -158,7 +172,8 @@ template <int CAP> struct Shared {
     uint8_t u_list[POOL];
     int16_t mypos[CAP];              // position of each controlled vehicle inside its own lane's list
     int16_t lcnt[NL];                // controlled vehicles per lane
-    int16_t segcnt[NL][5];           // controlled vehicles of segment k (own lane, conflict lanes 0..3) of list d
+    int16_t pref[NL * 5];            // inclusive prefix of the 60 segment sizes (list-major)
+    int emu_scan;                    // emulator-only accumulator of wave_incl_scan
     int16_t loff[NL + 1];            // list d occupies [loff[d], loff[d+1])
     int16_t segoff[NL][5];           // start of segment (own, conflict 0..3) inside list d
     uint8_t lane_of[CAP];            // lane of every alive slot
@@ -290,12 +305,6 @@ template <int CAP> struct Tick {
             r.step = P.i32[I_STEP][g]; r.count = P.i32[I_COUNT][g]; r.meta = P.i32[I_META][g];
         }
         sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
-        if (t < NL) {
-            int rec = gh.veh_rec[t];
-            double nxt = INFINITY;
-            if (rec < P.rows) nxt = P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec * NL + t];
-            sh.next_arr[t] = nxt;
-        }
         if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
         if (t < 8) {
             sh.tabA[t >> 2][t & 3] = c.vdA[t >> 2][t & 3];
@@ -385,31 +394,26 @@ template <int CAP> struct Tick {
     // thread d < 12: size and segment layout of virtual-lane list d from the controlled-vehicle ballot.
     static PVE_HD void ph_lists_a(const Const &c, int t, Sh &sh)
     {
+        int cnt = 0;
         if (t < NL * 5) {                                 // lane t: segment k of list d
             const int d = t / 5, k = t - d * 5;
             const int L = (k == 0) ? d : (int)sh.l2l[d][k - 1];
-            int cnt = 0;
             if (L >= 0)
                 cnt = mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L + 1]) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L]);
-            sh.segcnt[d][k] = (int16_t)cnt;
         }
+        const int incl = wave_incl_scan(t, cnt, &sh.emu_scan);      // all 60 segments live in wave 0
+        if (t < NL * 5) sh.pref[t] = (int16_t)incl;
     }
     static PVE_HD void ph_lists_b(int t, Sh &sh)
     {
-        if (t < NL) {                                     // segment layout of list t
-            int n = 0;
-#pragma unroll
-            for (int k = 0; k < 5; k++) { sh.segoff[t][k] = (int16_t)n; n += sh.segcnt[t][k]; }
-            sh.lcnt[t] = sh.segcnt[t][0];
+        if (t < NL * 5) {
+            const int d = t / 5, k = t - d * 5;
+            const int base = d ? sh.pref[5 * d - 1] : 0;
+            const int mine = t ? sh.pref[t - 1] : 0;
+            sh.segoff[d][k] = (int16_t)(mine - base);
+            if (k == 0) { sh.loff[d] = (int16_t)base; sh.lcnt[d] = (int16_t)(sh.pref[t] - base); }
         }
-        if (t <= NL) {                                    // list offsets (prefix over the lists before t)
-            int o = 0;
-            for (int d = 0; d < t; d++) {
-#pragma unroll
-                for (int k = 0; k < 5; k++) o += sh.segcnt[d][k];
-            }
-            sh.loff[t] = (int16_t)o;
-        }
+        if (t == NL * 5) sh.loff[NL] = sh.pref[NL * 5 - 1];
     }
 
     // ============================================================== BUILD: every controlled vehicle files
@@ -607,7 +611,7 @@ template <int CAP> struct Tick {
         vote<NW>(sh.m_fin, t, r.fin);
         vote<NW>(sh.m_ctlnow, t, r.alive && !r.del && (r.meta & M_CONTROL));
         vote<NW>(sh.m_coll, t, r.alive && r.ctl && r.coll_seen > 0);              // main.py:410-412
-        vote<NW>(sh.m_spawn, t, t < NL && sh.hd.current_time >= sh.next_arr[t < NL ? t : 0]);   // ref :379
+        vote<NW>(sh.m_spawn, t, t < NL && sh.hd.current_time >= sh.hd.next_arr[t < NL ? t : 0]);   // ref :379
     }
 
     // ============================================================== LOCK: dead-lock scan + reductions
@@ -741,7 +745,9 @@ template <int CAP> struct Tick {
                 double *o = P.out.obs_post + gs * OBSW;
                 for (int k = 0; k < OBSW; k++) o[k] = 0.0;
             }
-            gh.veh_rec[t] = sh.hd.veh_rec[t] + 1;
+            const int rec1 = sh.hd.veh_rec[t] + 1;
+            gh.veh_rec[t] = rec1;
+            gh.next_arr[t] = (rec1 < P.rows) ? P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec1 * NL + t] : INFINITY;
         }
         // ---- clear the tail so stale slots never look alive
         if (t >= n_post) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
@@ -935,6 +941,8 @@ PVE_HD void reset_env(const Const &c, const Params &P, int env, int cap_ticks)
             while (s < n && l < NL && lane_of[s] == l) s++;
         }
     }
+    for (int l = 0; l < NL; l++)
+        h.next_arr[l] = (h.veh_rec[l] < P.rows) ? arr[(size_t)h.veh_rec[l] * NL + l] : INFINITY;
     h.n_alive = n;
     h.id_seq = n;
     P.headers[env] = h;

@@ -54,6 +54,8 @@ struct Const {
 struct EnvHeader {
     double current_time;           // ref :196, 223
     double sum_reward, sum_jerk;   // metrics
+    double next_arr[NL];           // arrive_time[veh_rec[l]][l] (+inf past the stream): cached so that the
+                                   // spawn test (ref :379) needs no dependent load on the tick's critical path
     long long alive_steps, ctl_steps, ticks;
     int32_t n_alive;
     int32_t lane_start[NL + 1];    // slot range of each lane; lane counts = veh_num (ref :206)
