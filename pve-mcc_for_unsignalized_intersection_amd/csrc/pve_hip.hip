@@ -35,7 +35,7 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
     const int env = blockIdx.x;
     Regs r;
     typedef Tick<CAP> T;
-    unsigned long long pc_[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev_ = P.phase_cycles ? wall_clock64() : 0ull;
     T::ph_load(c, P, env, t, sh, r);
     __syncthreads();
@@ -59,6 +59,8 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
     __syncthreads();
     PVE_PHASE_MARK(5)
     T::ph_scan(c, t, sh, r);
+    PVE_PHASE_MARK(11)
+    T::ph_reward(c, t, sh, r);
     __syncthreads();
     PVE_PHASE_MARK(6)
     T::ph_effects(c, t, sh, r);
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
     if (P.phase_cycles && (t & 63) == 0) {
         unsigned long long *row = P.phase_cycles + ((size_t)env * (CAP / 64) + (t >> 6)) * 16;
 #pragma unroll
-        for (int k = 0; k < 11; k++) row[k] += pc_[k];
+        for (int k = 0; k < 12; k++) row[k] += pc_[k];
     }
 }
 

@@ -500,25 +500,83 @@ template <int CAP> struct Tick {
         const uint8_t *ss = sh.s_slot + base;
         int pr = -1; double pvd = 0;
         if (s > 0) { pr = ss[s - 1]; pvd = sv[s - 1]; }                             // ref :1353-1354
-        // merge outwards from our own position: left = keys below ours, right = keys above; order of the
-        // reference's stable |vd - vd_self| sort = (|d|, vd, slot) (ref :1383-1397).  Equal |d| -> left first
-        // (smaller vd, or equal vd and smaller slot); a run of equal vd on the left is emitted in ascending slot.
-        int hi = s - 1, lo = hi, cur, rr = s + 1;
-        if (hi >= 0) { const double vh = pvd; while (lo > 0 && sv[lo - 1] == vh) lo--; }
-        cur = lo;
+        // The 6 nearest in the reference's stable |vd - vd_self| sort = the 6 smallest keys (|d|, vd, slot) (ref
+        // :1383-1397).  Both sides of our own position are already sorted by |d|: left = keys below ours (walking
+        // left), right = keys above (walking right); on equal |d| the left entry comes first (smaller vd, or equal
+        // vd and smaller slot).  FAST PATH: prefetch the 6+6 window with independent LDS reads and merge in
+        // registers (first half of a bitonic merge + a 6-input sorting network).  It is exact unless two LEFT
+        // neighbours (incl. the first one beyond the window) share the same vd: such a run must be emitted in
+        // ascending slot, i.e. against the walking direction; then the general pointer walk below is used.
+        double lv[NNB + 1]; int lsl[NNB];
+        double rv[NNB]; int rsl[NNB];
+        bool tie = false;
 #pragma unroll
-        for (int k = 0; k < NNB; k++) {
-            const bool hasL = hi >= 0;
-            double vR = INFINITY;
-            if (rr < n) vR = sv[rr];
-            const bool hasR = vR < INFINITY;
-            if (hasL || hasR) {
+        for (int i = 0; i < NNB + 1; i++) {
+            const int pos = s - 1 - i;
+            lv[i] = (pos >= 0) ? sv[pos] : -INFINITY;
+            if (i < NNB) lsl[i] = (pos >= 0) ? (int)ss[pos] : -1;
+            if (i > 0) tie = tie || (pos >= 0 && lv[i] == lv[i - 1]);
+        }
+        bool rvalid = true;                                            // everything after the +inf sentinel is stale
+#pragma unroll
+        for (int i = 0; i < NNB; i++) {
+            const int pos = s + 1 + i;
+            const double w = (pos < n) ? sv[pos] : INFINITY;
+            rvalid = rvalid && (w < INFINITY);
+            rv[i] = rvalid ? w : INFINITY;
+            rsl[i] = rvalid ? (int)ss[pos < n ? pos : 0] : -1;
+        }
+        if (!tie) {
+            // candidate = (d, code, vd, slot); code orders equal d: left before right, then walking order
+            double cd[NNB], cv[NNB]; int cc[NNB], cs[NNB];
+#pragma unroll
+            for (int i = 0; i < NNB; i++) {
+                const double dl = (lsl[i] >= 0) ? fabs(lv[i] - ps) : INFINITY;                  // ref :1388
+                const int j = NNB - 1 - i;
+                const double dr = (rsl[j] >= 0 && rv[j] < INFINITY) ? fabs(rv[j] - ps) : INFINITY;
+                const bool takeL = dl <= dr;                            // min(L_i, R_{5-i}): the 6 smallest overall
+                cd[i] = takeL ? dl : dr; cv[i] = takeL ? lv[i] : rv[j];
+                cs[i] = takeL ? lsl[i] : rsl[j]; cc[i] = takeL ? i : (8 + j);
+            }
+#define PVE_CE(A, B)                                                                            \
+            {                                                                                   \
+                const bool sw = cd[B] < cd[A] || (cd[B] == cd[A] && cc[B] < cc[A]);             \
+                const double td = sw ? cd[A] : cd[B], tv = sw ? cv[A] : cv[B];                  \
+                const int tc = sw ? cc[A] : cc[B], ts = sw ? cs[A] : cs[B];                     \
+                cd[A] = sw ? cd[B] : cd[A]; cv[A] = sw ? cv[B] : cv[A];                         \
+                cc[A] = sw ? cc[B] : cc[A]; cs[A] = sw ? cs[B] : cs[A];                         \
+                cd[B] = td; cv[B] = tv; cc[B] = tc; cs[B] = ts;                                 \
+            }
+            // optimal 12-comparator network for 6 inputs
+            PVE_CE(0, 5) PVE_CE(1, 3) PVE_CE(2, 4)
+            PVE_CE(1, 2) PVE_CE(3, 4)
+            PVE_CE(0, 3) PVE_CE(2, 5)
+            PVE_CE(0, 1) PVE_CE(2, 3) PVE_CE(4, 5)
+            PVE_CE(1, 2) PVE_CE(3, 4)
+#undef PVE_CE
+#pragma unroll
+            for (int k = 0; k < NNB; k++) {
+                const bool ok = cd[k] < INFINITY;
+                r.kr[k] = ok ? cs[k] : -1; r.kv[k] = ok ? cv[k] : 0.0;
+            }
+        } else {
+            // GENERAL PATH: pointer walk; a run of equal vd on the left is emitted in ascending slot
+            int hi = s - 1, lo = hi, cur, rr = s + 1;
+            if (hi >= 0) { const double vh = pvd; while (lo > 0 && sv[lo - 1] == vh) lo--; }
+            cur = lo;
+            for (int k = 0; k < NNB; k++) {
+                const bool hasL = hi >= 0;
+                double vR = INFINITY;
+                if (rr < n) vR = sv[rr];
+                const bool hasR = vR < INFINITY;
+                if (!(hasL || hasR)) break;
                 double vL = 0;
                 if (hasL) vL = sv[cur];
                 const double dL = fabs(vL - ps), dR = fabs(vR - ps);              // ref :1388
                 const bool takeL = hasL && (!hasR || dL <= dR);
+                int slot; double vv;
                 if (takeL) {
-                    r.kr[k] = ss[cur]; r.kv[k] = vL;
+                    slot = ss[cur]; vv = vL;
                     cur++;
                     if (cur > hi) {
                         hi = lo - 1; lo = hi;
@@ -526,9 +584,12 @@ template <int CAP> struct Tick {
                         cur = lo;
                     }
                 } else {
-                    r.kr[k] = ss[rr]; r.kv[k] = vR;
+                    slot = ss[rr]; vv = vR;
                     rr++;
                 }
+                // static register indices only (no scratch): select the destination by k
+#pragma unroll
+                for (int q = 0; q < NNB; q++) if (q == k) { r.kr[q] = slot; r.kv[q] = vv; }
             }
         }
         // ref :1348-1354
@@ -537,6 +598,14 @@ template <int CAP> struct Tick {
         sh.hdr[t] = (int16_t)pr;
         sh.virdis[t] = r.vir_dis;
         r.count += 1;                                                             // ref :292
+    }
+
+    // ============================================================== REWARD: reward terms + XY collision test
+    static PVE_HD void ph_reward(const Const &c, int t, Sh &sh, Regs &r)
+    {
+        if (!(r.alive && r.ctl)) return;
+        const int lane = r.lane;
+        const double ps = r.p;
         // ref :280-310
         double t_distance = 2, d_distance = 10;
         const int n0 = r.kr[0];

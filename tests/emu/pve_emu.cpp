@@ -34,6 +34,7 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_build(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
         for (int t = 0; t < CAP; t++) T::ph_scan(c, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_reward(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_effects(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_lock(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t]);

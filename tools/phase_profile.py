@@ -13,8 +13,8 @@ import bench  # noqa: E402
 import pve_mcc_amd  # noqa: E402
 from pve_mcc_amd.arrivals import synthetic_arrivals  # noqa: E402
 
-PHASES = ("load", "step1", "step2+listsA", "step3+listsB", "build", "rank", "walk+reward", "effects", "lock",
-          "final", "state")
+PHASES = ("load", "step1", "step2+listsA", "step3+listsB", "build", "rank", "reward+xy", "effects", "lock",
+          "final", "state", "walk(merge)")
 
 
 def main():
