@@ -148,3 +148,45 @@ def check_empty_and_exhausted(backend):
     info = b2.read_env(0)
     assert list(info.veh_rec)[4] == 2 and info.id_seq == 2
     assert info.n_alive == orc.n_alive and info.passed_veh == 2
+
+
+def check_fuzz_vs_oracle(backend, n_envs, capacity, ticks, rate, seed, action_scale=3.0, quantize=None):
+    """Random action tapes (uniform in [-scale, scale], optionally quantised to provoke exact ties), every env
+    compared with its own oracle every tick: controlled set, rewards, collision counters, lock counts, and the
+    full persistent state at the end. Exercises vd ties, long dead-lock cycles, collisions, mid-lane deletions."""
+    rng = np.random.default_rng(seed)
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed)
+    b = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "reward", "flags", "nbr",
+                                                            "env_out", "new_slot", "lanej"))
+    b.reset()
+    oracles = [OracleEnv(arr[e]) for e in range(n_envs)]
+    tot_coll = tot_lock = 0
+    for t in range(ticks):
+        acts = rng.uniform(-action_scale, action_scale, size=(n_envs, capacity)).astype(np.float32).astype(np.float64)
+        if quantize:
+            acts = np.round(acts / quantize) * quantize
+        out = b.step(torch.as_tensor(acts).to(b.device))
+        rew, flags, eo = _np(out["reward"]), _np(out["flags"]), _np(out["env_out"])
+        nbr, obs = _np(out["nbr"]), _np(out["obs_pre"])
+        for e, o in enumerate(oracles):
+            n = o.n_alive
+            _vid, ctlm, _ = o.alive_view()
+            rec = o.tick(np.where(ctlm != 0, acts[e, :n], 0.0))
+            ctl = (flags[e, :n] & 2) != 0
+            assert int(eo[e, 0]) == n and int(ctl.sum()) == len(rec["ids"]), "controlled set: tick %d env %d" % (t, e)
+            assert int(eo[e, 2]) == rec["collisions"] and int(eo[e, 3]) == rec["lock"], "counters: tick %d env %d" % (t, e)
+            assert np.array_equal(flags[e, :n][ctl] >> 8, rec["coll_pv"]), "coll_pv: tick %d env %d" % (t, e)
+            nb = nbr[e, :n][ctl].astype(np.int64)
+            nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)
+            assert np.array_equal(nb, rec["nbr"]), "neighbours: tick %d env %d" % (t, e)
+            assert close(rec["reward"], rew[e, :n][ctl], 1e-9), "reward: tick %d env %d" % (t, e)
+            assert close(rec["obs0"], obs[e, :n][ctl], 1e-9), "obs: tick %d env %d" % (t, e)
+            tot_coll += rec["collisions"]
+            tot_lock += rec["lock"]
+    for e, o in enumerate(oracles):
+        info, vi, vf = state_snapshot(b, e)
+        ovi, ovf, _ = o.vehicles()
+        assert np.array_equal(vi[:, :13], ovi[:, :13]), "final state ints, env %d" % e
+        assert close(ovf[:, :5], vf[:, :5], 1e-9), "final state floats, env %d" % e
+    assert b.metrics()["overflow"] == 0
+    return tot_coll, tot_lock

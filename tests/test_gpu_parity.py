@@ -132,3 +132,11 @@ def test_gpu_actor_matches_numpy_restatement():
 def test_gpu_closed_loop_actor_plus_tick():
     from tests import actor_scenarios as A
     A.check_closed_loop_on_device("hip", ticks=1000)
+
+
+@pytest.mark.parametrize("seed,rate,cap,quant", [(11, 1000.0, 128, None), (12, 500.0, 64, 1.0), (13, 1100.0, 128, 3.0)])
+def test_gpu_fuzz_random_tapes(seed, rate, cap, quant):
+    """Random / quantised action tapes (ties, long dead-lock cycles, collisions) on 16 envs vs 16 oracles."""
+    coll, lock = scenarios.check_fuzz_vs_oracle(BACKEND, n_envs=16, capacity=cap, ticks=500, rate=rate, seed=seed,
+                                                quantize=quant)
+    assert coll > 0 and lock > 0
