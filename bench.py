@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default 1100 at cap 128, 500 at cap 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
+    ap.add_argument("--emulate", action="store_true",
+                    help="TEST HOOK (CPU, gloo): run the rank plumbing and the JSON contract on the kernel emulator of "
+                         "tests/emu; the numbers it prints are meaningless and marked as such")
     ap.add_argument("--actor", action="store_true",
                     help="BASELINE config 5: close the loop on the device (k_actor -> k_tick per step) instead of the action pool")
     args = ap.parse_args()
@@ -113,13 +116,22 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     import torch.distributed as dist
+    emu = args.emulate
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if emu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cpu") if emu else torch.device("cuda", local_rank)
+    if not emu:
+        torch.cuda.set_device(dev)
+
+    def sync():
+        if not emu:
+            torch.cuda.synchronize(dev)
 
     import pve_mcc_amd
     from pve_mcc_amd.arrivals import synthetic_arrivals
@@ -133,7 +145,11 @@ def main():
     arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=horizon, seed=20250213 + rank * n_envs)
     pool_np = action_pool(n_envs, cap, seed=99 + rank)
     outputs = tuple(x for x in args.outputs.split(",") if x)
-    env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs)
+    if emu:
+        from tests.hip_adapter import emulator_lib
+        env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs, _lib=emulator_lib())
+    else:
+        env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs)
     pool = torch.as_tensor(pool_np, device=dev)
     env.reset()
     if args.actor:
@@ -149,23 +165,26 @@ def main():
 
     for t in range(W):
         one_step(t)
-    torch.cuda.synchronize(dev)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     m0 = env.metrics()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if not emu:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()                      # same stream the kernels are launched on (torch current stream)
+    if not emu:
+        ev0.record()                  # same stream the kernels are launched on (torch current stream)
     for t in range(W, W + K):
         one_step(t)
-    ev1.record()
-    torch.cuda.synchronize(dev)
+    if not emu:
+        ev1.record()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
+    gpu_ms = ev0.elapsed_time(ev1) if not emu else wall * 1e3
     if world > 1:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -184,7 +203,7 @@ def main():
             "metric": "env-steps/sec (vehicles x envs x steps/s) at 128 veh x 4096 envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "synthetic (CPU EMULATOR TEST HOOK: timings meaningless)",
             "config": {"workload": "%d parallel 12-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"

@@ -1,0 +1,52 @@
+"""bench.py contract on CPU: one JSON line with the required keys, single process and world_size 2 (gloo) through
+the `--emulate` test hook (kernel emulator; the multi-rank plumbing, barrier/max-over-ranks timing and the metrics
+all-gather are the real code paths)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def check_line(out, n):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == n and d["steps"] == 6 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - 64 * 12 * 6 * n / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6
+    return d
+
+
+def test_bench_single_process_emulated():
+    out = subprocess.check_output([sys.executable, "bench.py", "--emulate", "--envs", "12", "--capacity", "64",
+                                   "--steps", "6", "--warmup", "3"], cwd=ROOT, text=True, timeout=600)
+    check_line(out, 1)
+
+
+def test_bench_two_ranks_gloo_emulated():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--emulate",
+           "--envs", "12", "--capacity", "64", "--steps", "6", "--warmup", "3"]
+    out = subprocess.check_output(cmd, cwd=ROOT, text=True, timeout=900, stderr=subprocess.DEVNULL)
+    d = check_line(out, 2)
+    assert d["config"]["parallelism"] == "env-parallel x2"
