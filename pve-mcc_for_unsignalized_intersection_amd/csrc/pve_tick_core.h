@@ -166,7 +166,6 @@ template <int CAP> struct Shared {
     // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
     // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
     double s_vd[POOL];               // the same entries sorted by (vd, slot)
-    int16_t s_idx[POOL];             // scratch of the dead-lock leaders (LOCK phase)
     uint8_t s_slot[POOL];
     uint8_t u_slot[POOL];
     uint8_t u_list[POOL];
@@ -717,13 +716,13 @@ template <int CAP> struct Tick {
         vote<NW>(sh.m_lead, t, lead);
     }
     // LOCK2 (after a barrier): every cycle member files its record at its rank inside the cycle's scratch range
-    // (u_vd / s_idx are dead after the walk phase) = the reference's record_.sort() (ref :1492)
+    // (u_vd / s_slot are dead after the walk phase) = the reference's record_.sort() (ref :1492)
     static PVE_HD void ph_lock2(int t, Sh &sh, Regs &r)
     {
         if (r.cyc & 1) {
             const int e = sh.cyc_off[r.cyc >> 9] + ((r.cyc >> 5) & 15);
             sh.u_vd[e] = sh.virdis[t];
-            sh.s_idx[e] = (int16_t)t;
+            sh.s_slot[e] = (uint8_t)t;
         }
     }
     // NOTE: if the tightest record's header is the tightest vehicle itself (1-cycle) the reference
@@ -773,7 +772,7 @@ template <int CAP> struct Tick {
                 double sum = 0;
 #pragma unroll
                 for (int q = 0; q < 10; q++) if (q < len) sum = sum + sh.u_vd[off + q];
-                const int best_o = sh.s_idx[off];
+                const int best_o = sh.s_slot[off];
                 meta |= M_LOCK;                                                    // ref :1482
                 lockf = 1;
                 if (sh.u_vd[off] < c.collision_thr || sum / (double)len < c.lock_mean_thr) {
