@@ -176,6 +176,7 @@ template <int CAP> struct Shared {
     int16_t loff[NL + 1];            // list d occupies [loff[d], loff[d+1])
     int16_t segoff[NL][5];           // start of segment (own, conflict 0..3) inside list d
     uint8_t lane_of[CAP];            // lane of every alive slot
+    float xy32[CAP][2];              // single-precision position of every controlled vehicle (collision pre-filter)
     double tabA[2][4], tabB[2][4], tabC[2][4];   // get_virtual_distance table (copy of Const, lane-indexed reads)
     int8_t l2l[NL][4], l2l_inv[NL][4];
     int lead_n;                      // scratch units claimed by the dead-lock cycles
@@ -253,6 +254,30 @@ PVE_HD void get_xy(const Const &c, double p, int lane, double &X, double &Y)
     double y = before ? by : (inside ? ay : ey);
     if (m == 1) { x = p - 6 * cw; y = 3 * cw; }                         // straight (ref :1268-1270)
     const double rc = c.rot_cos[lane / 3], rs = c.rot_sin[lane / 3];
+    X = x * rc - y * rs;
+    Y = y * rc + x * rs;
+}
+
+// single-precision position for the collision PRE-FILTER only (never for a decision): |error| < 1e-3 m
+PVE_HD void get_xy_f32(const Const &c, double pd, int lane, float &X, float &Y)
+{
+    const float cw = (float)c.cw, p = (float)pd;
+    const int m = lane % 3;
+    const float Lb = (float)c.inbox[m == 2 ? 2 : 0];
+    const bool before = p > Lb, inside = !before && p > 0.f;
+    float ra = (m != 1 && inside) ? ((Lb - p) / Lb * 1.5707965f) : 0.f;     // 3.141593 / 2
+    const bool fold = ra > 0.78539816f;
+    const float y0 = fold ? (1.5707964f - ra) : ra, z = y0 * y0;
+    const float s1 = y0 + y0 * z * (-1.6666667e-1f + z * (8.3333338e-3f + z * (-1.9841270e-4f + z * 2.7557319e-6f)));
+    const float c1 = 1.f + z * (-0.5f + z * (4.1666668e-2f + z * (-1.3888889e-3f + z * 2.4801587e-5f)));
+    const float sn = fold ? c1 : s1, cs = fold ? s1 : c1;
+    const float p0y = (m == 0) ? cw : 5.f * cw, pry = (m == 0) ? -6.f * cw : 6.f * cw, prx = 6.f * cw;
+    const float ax = (m == 0) ? (prx - (p0y - pry) * sn) : (prx + (p0y - pry) * sn);
+    const float ay = pry + (p0y - pry) * cs;
+    float x = before ? (p - Lb + 6.f * cw) : (inside ? ax : ((m == 0) ? -cw : 5.f * cw));
+    float y = before ? p0y : (inside ? ay : ((m == 0) ? (-6.f * cw + p) : (6.f * cw - p)));
+    if (m == 1) { x = p - 6.f * cw; y = 3.f * cw; }
+    const float rc = (float)c.rot_cos[lane / 3], rs = (float)c.rot_sin[lane / 3];
     X = x * rc - y * rs;
     Y = y * rc + x * rs;
 }
@@ -421,6 +446,7 @@ template <int CAP> struct Tick {
     {
         if (!(r.alive && r.ctl)) return;
         const int lane = r.lane;
+        get_xy_f32(c, r.p, lane, sh.xy32[t][0], sh.xy32[t][1]);
         const int q = mask_below<NW>(sh.m_ctl, t) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[lane]);
         {
             const int e = sh.loff[lane] + q;                  // own lane: vd = p (ref :242-249)
@@ -632,7 +658,15 @@ template <int CAP> struct Tick {
         r.reward = (r_ < 20) ? r_ : 20;
         r.jerk_sum += fabs(r.jerk / c.deltaT);                                    // ref :321
         // ref :322-334
+        // pre-filter in single precision: the exact FP64 positions (two divisions + polynomials each) are only
+        // evaluated when the pair is within 5 cm of the threshold band -- the decision itself is always FP64
+        bool near = false;
         if (n0 >= 0) {
+            const float fx = sh.xy32[n0][0] - sh.xy32[t][0], fy = sh.xy32[n0][1] - sh.xy32[t][1];
+            const float lim = (float)c.collision_thr + 0.05f;
+            near = fx * fx + fy * fy < lim * lim;
+        }
+        if (near) {
             double ax, ay, bx, by;
             get_xy(c, ps, lane, ax, ay);
             get_xy(c, sh.p[n0], sh.lane_of[n0], bx, by);
