@@ -92,7 +92,9 @@ def pmc_traffic(n_envs, cap, outputs, actor):
     return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
 
 
-def main():
+def main(argv=None, env_factory=None):
+    """env_factory: tests inject a factory (device, backend, builder) to exercise the rank plumbing and the
+    JSON contract without a GPU; the product run never passes it."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -102,12 +104,9 @@ def main():
     ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default 1100 at cap 128, 500 at cap 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
-    ap.add_argument("--emulate", action="store_true",
-                    help="TEST HOOK (CPU, gloo): run the rank plumbing and the JSON contract on the kernel emulator of "
-                         "tests/emu; the numbers it prints are meaningless and marked as such")
     ap.add_argument("--actor", action="store_true",
                     help="BASELINE config 5: close the loop on the device (k_actor -> k_tick per step) instead of the action pool")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,7 +115,7 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     import torch.distributed as dist
-    emu = args.emulate
+    emu = env_factory is not None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if emu:
@@ -146,8 +145,7 @@ def main():
     pool_np = action_pool(n_envs, cap, seed=99 + rank)
     outputs = tuple(x for x in args.outputs.split(",") if x)
     if emu:
-        from tests.hip_adapter import emulator_lib
-        env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs, _lib=emulator_lib())
+        env = env_factory(n_envs, cap, arr, outputs)
     else:
         env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs)
     pool = torch.as_tensor(pool_np, device=dev)
@@ -203,7 +201,7 @@ def main():
             "metric": "env-steps/sec (vehicles x envs x steps/s) at 128 veh x 4096 envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "synthetic (CPU EMULATOR TEST HOOK: timings meaningless)",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "synthetic (injected test environment: timings meaningless)",
             "config": {"workload": "%d parallel 12-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"

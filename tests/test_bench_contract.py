@@ -1,5 +1,5 @@
 """bench.py contract on CPU: one JSON line with the required keys, single process and world_size 2 (gloo) through
-the `--emulate` test hook (kernel emulator; the multi-rank plumbing, barrier/max-over-ranks timing and the metrics
+tests/bench_emulated_launcher.py (bench.main with the kernel emulator injected; the multi-rank plumbing, barrier/max-over-ranks timing and the metrics
 all-gather are the real code paths)."""
 import json
 import os
@@ -38,14 +38,14 @@ def check_line(out, n):
 
 
 def test_bench_single_process_emulated():
-    out = subprocess.check_output([sys.executable, "bench.py", "--emulate", "--envs", "12", "--capacity", "64",
+    out = subprocess.check_output([sys.executable, "tests/bench_emulated_launcher.py", "--envs", "12", "--capacity", "64",
                                    "--steps", "6", "--warmup", "3"], cwd=ROOT, text=True, timeout=600)
     check_line(out, 1)
 
 
 def test_bench_two_ranks_gloo_emulated():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--emulate",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "tests/bench_emulated_launcher.py", "--gpus", "2",
            "--envs", "12", "--capacity", "64", "--steps", "6", "--warmup", "3"]
     out = subprocess.check_output(cmd, cwd=ROOT, text=True, timeout=900, stderr=subprocess.DEVNULL)
     d = check_line(out, 2)
