@@ -551,38 +551,42 @@ template <int CAP> struct Tick {
             rv[i] = rvalid ? w : INFINITY;
             rsl[i] = rvalid ? (int)ss[pos < n ? pos : 0] : -1;
         }
-        if (!tie) {
-            // candidate = (d, code, vd, slot); code orders equal d: left before right, then walking order
-            double cd[NNB], cv[NNB]; int cc[NNB], cs[NNB];
+        // candidate = (d, code): code = walking index on the left (0..5) or 8 + index on the right.  min(L_i, R_5-i)
+        // (left wins equal d) are the 6 smallest overall; they are then sorted by d alone with a 12-comparator
+        // network.  If two of the 6 winners still share the same d (exact |d| ties, quantised states) the order
+        // would need the (side, index) tie-break: that case also takes the general path.
+        double cd[NNB]; int cc[NNB];
 #pragma unroll
-            for (int i = 0; i < NNB; i++) {
-                const double dl = (lsl[i] >= 0) ? fabs(lv[i] - ps) : INFINITY;                  // ref :1388
-                const int j = NNB - 1 - i;
-                const double dr = (rsl[j] >= 0 && rv[j] < INFINITY) ? fabs(rv[j] - ps) : INFINITY;
-                const bool takeL = dl <= dr;                            // min(L_i, R_{5-i}): the 6 smallest overall
-                cd[i] = takeL ? dl : dr; cv[i] = takeL ? lv[i] : rv[j];
-                cs[i] = takeL ? lsl[i] : rsl[j]; cc[i] = takeL ? i : (8 + j);
-            }
+        for (int i = 0; i < NNB; i++) {
+            const double dl = (lsl[i] >= 0) ? fabs(lv[i] - ps) : INFINITY;                      // ref :1388
+            const int j = NNB - 1 - i;
+            const double dr = (rsl[j] >= 0) ? fabs(rv[j] - ps) : INFINITY;
+            const bool takeL = dl <= dr;
+            cd[i] = takeL ? dl : dr; cc[i] = takeL ? i : (8 + j);
+        }
 #define PVE_CE(A, B)                                                                            \
-            {                                                                                   \
-                const bool sw = cd[B] < cd[A] || (cd[B] == cd[A] && cc[B] < cc[A]);             \
-                const double td = sw ? cd[A] : cd[B], tv = sw ? cv[A] : cv[B];                  \
-                const int tc = sw ? cc[A] : cc[B], ts = sw ? cs[A] : cs[B];                     \
-                cd[A] = sw ? cd[B] : cd[A]; cv[A] = sw ? cv[B] : cv[A];                         \
-                cc[A] = sw ? cc[B] : cc[A]; cs[A] = sw ? cs[B] : cs[A];                         \
-                cd[B] = td; cv[B] = tv; cc[B] = tc; cs[B] = ts;                                 \
-            }
-            // optimal 12-comparator network for 6 inputs
-            PVE_CE(0, 5) PVE_CE(1, 3) PVE_CE(2, 4)
-            PVE_CE(1, 2) PVE_CE(3, 4)
-            PVE_CE(0, 3) PVE_CE(2, 5)
-            PVE_CE(0, 1) PVE_CE(2, 3) PVE_CE(4, 5)
-            PVE_CE(1, 2) PVE_CE(3, 4)
+        {                                                                                       \
+            const bool sw = cd[B] < cd[A];                                                      \
+            const double td = sw ? cd[A] : cd[B]; const int tc = sw ? cc[A] : cc[B];            \
+            cd[A] = sw ? cd[B] : cd[A]; cc[A] = sw ? cc[B] : cc[A];                             \
+            cd[B] = td; cc[B] = tc;                                                             \
+        }
+        PVE_CE(0, 5) PVE_CE(1, 3) PVE_CE(2, 4)
+        PVE_CE(1, 2) PVE_CE(3, 4)
+        PVE_CE(0, 3) PVE_CE(2, 5)
+        PVE_CE(0, 1) PVE_CE(2, 3) PVE_CE(4, 5)
+        PVE_CE(1, 2) PVE_CE(3, 4)
 #undef PVE_CE
+#pragma unroll
+        for (int k = 1; k < NNB; k++) tie = tie || (cd[k] == cd[k - 1] && cd[k] < INFINITY);
+        if (!tie) {
 #pragma unroll
             for (int k = 0; k < NNB; k++) {
                 const bool ok = cd[k] < INFINITY;
-                r.kr[k] = ok ? cs[k] : -1; r.kv[k] = ok ? cv[k] : 0.0;
+                const int code = cc[k];
+                const int pos = (code < 8) ? (s - 1 - code) : (s + 1 + (code - 8));
+                r.kr[k] = ok ? (int)ss[ok ? pos : 0] : -1;
+                r.kv[k] = ok ? sv[ok ? pos : 0] : 0.0;
             }
         } else {
             // GENERAL PATH: pointer walk; a run of equal vd on the left is emitted in ascending slot
