@@ -222,8 +222,9 @@ def main(argv=None, env_factory=None):
             line["roofline"]["note"] = "kernel_ms = k_actor + k_tick per step; achieved uses the tick's algorithmic bytes only"
         if not args.no_cpu_baseline and not args.actor:
             line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, min(W, 300), min(K, 200))
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                # every rank leaves together (rank 0 may still be timing the CPU baseline)
         dist.destroy_process_group()
 
 
