@@ -847,13 +847,18 @@ template <int CAP> struct Tick {
             nv.step = 0; nv.count = 0;
             size_t gs = (size_t)env * CAP + slot;
             store_slot(P, gs, nv, M_CONTROL | M_ALIVE, -1);
-            if (P.out.obs_post) {
-                double *o = P.out.obs_post + gs * OBSW;
-                for (int k = 0; k < OBSW; k++) o[k] = 0.0;
-            }
             const int rec1 = sh.hd.veh_rec[t] + 1;
             gh.veh_rec[t] = rec1;
             gh.next_arr[t] = (rec1 < P.rows) ? P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec1 * NL + t] : INFINITY;
+        }
+        if (P.out.obs_post && sp) {
+            // zero observation rows of the spawned vehicles (ref :380, :420): one coalesced 224-B store per spawn
+            // by 28 lanes instead of 28 stores by the spawning lane; the loop over the set bits is wave-uniform
+            for (unsigned rem = sp; rem; rem &= rem - 1) {
+                const int l = __builtin_ctz(rem);
+                const int slot = mask_below<NW>(keep, sh.hd.lane_start[l + 1]) + __builtin_popcount(sp & ((1u << l) - 1u));
+                if (t < OBSW) P.out.obs_post[((size_t)env * CAP + slot) * OBSW + t] = 0.0;
+            }
         }
         // ---- clear the tail so stale slots never look alive
         if (t >= n_post) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
