@@ -113,5 +113,154 @@ __global__ __launch_bounds__(64) void k_actor(const float *__restrict__ W, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_actor_mfma: the same network on the matrix cores.  v_mfma_f32_32x32x2_f32 is an exact float32 FMA chain
+// (k-ordered, one rounding per product: bitwise the order of the VALU kernel above), at the f32 vector rate,
+// but it takes its operands per lane: A[i = lane & 31][k = lane >> 5] and B[k = lane >> 5][j = lane & 31].
+// That removes every wave-uniform operand: the 28x64 + 64x64 weights live in 92 VGPRs per lane for the whole
+// kernel (loaded once, coalesced), activations are exchanged between the C layout (column per lane) and the A
+// layout (row per lane) through a padded 64x65 LDS tile, and the LayerNorm statistics of a vehicle are a sum
+// over the 14 / 32 features its two lanes (lane, lane ^ 32) hold plus one cross-lane exchange.
+// One wave64 per intersection; 64 controlled vehicles (2 row tiles of 32) per pass; 184 MFMAs per pass.
+typedef float pve_v16f __attribute__((ext_vector_type(16)));
+
+template <int CAP>
+__global__ __launch_bounds__(64) void k_actor_mfma(const float *__restrict__ W, const double *__restrict__ obs,
+                                                   const int32_t *__restrict__ meta, double *__restrict__ actions,
+                                                   int n_envs)
+{
+    __shared__ float Hs[32][65];               // activations of 32 vehicles x 64 features (+1 pad: conflict-free)
+    __shared__ float lnp[2 * ACT_IN + 4 * ACT_H + ACT_H];   // g0,b0 | g1,b1 | g2,b2 | w3
+    __shared__ unsigned char slot_of[CAP];
+    const int lane = threadIdx.x, lo = lane & 31, hi = lane >> 5;
+    for (int k = lane; k < 2 * ACT_IN; k += 64) lnp[k] = W[AW_LN0_G + k];
+    for (int k = lane; k < 2 * ACT_H; k += 64) {
+        lnp[2 * ACT_IN + k] = W[AW_LN1_G + k];
+        lnp[2 * ACT_IN + 2 * ACT_H + k] = W[AW_LN2_G + k];
+    }
+    lnp[2 * ACT_IN + 4 * ACT_H + lane] = W[AW_W3 + lane];
+    // weight fragments, loaded once per (persistent) wave: B[k = 2s + hi][j = 32nt + lo]
+    float B1[ACT_IN / 2][2], B2[ACT_H / 2][2], b1c[2], b2c[2];
+#pragma unroll
+    for (int s = 0; s < ACT_IN / 2; s++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) B1[s][nt] = W[AW_W1 + (2 * s + hi) * ACT_H + 32 * nt + lo];
+#pragma unroll
+    for (int s = 0; s < ACT_H / 2; s++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) B2[s][nt] = W[AW_W2 + (2 * s + hi) * ACT_H + 32 * nt + lo];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) { b1c[nt] = W[AW_B1 + 32 * nt + lo]; b2c[nt] = W[AW_B2 + 32 * nt + lo]; }
+    const float b3 = W[AW_B3];
+    const float *g0 = lnp, *be0 = lnp + ACT_IN, *g1 = lnp + 2 * ACT_IN, *be1 = g1 + ACT_H, *g2 = be1 + ACT_H,
+                *be2 = g2 + ACT_H, *w3 = be2 + ACT_H;
+    __syncthreads();
+    for (int env = blockIdx.x; env < n_envs; env += gridDim.x) {
+        const size_t base = (size_t)env * CAP;
+        // controlled-vehicle compaction
+        int nctl = 0;
+#pragma unroll
+        for (int sub = 0; sub < CAP / 64; sub++) {
+            const int s = sub * 64 + lane;
+            const int m = meta[base + s];
+            const bool c = (m & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
+            const unsigned long long b = __ballot(c);
+            const int rank = nctl + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+            if (c) slot_of[rank] = (unsigned char)s;
+            else actions[base + s] = 0.0;                 // main.py:401: uncontrolled vehicles get 0
+            nctl += __builtin_popcountll(b);
+        }
+        __syncthreads();
+        for (int v0 = 0; v0 < nctl; v0 += 32) {           // one row tile = 32 vehicles per pass
+            const int v = v0 + lo;
+            const bool valid = v < nctl;
+            const int slot = slot_of[valid ? v : v0];
+            pve_v16f acc[2];
+            // ---- layer 1: LayerNorm(28) -> dense 28x64.  Lane holds features k = 2s + hi of vehicle v0 + lo.
+            {
+                const double *row = obs + (base + slot) * OBSW;
+                float x[ACT_IN / 2], sum = 0.f;
+#pragma unroll
+                for (int s = 0; s < ACT_IN / 2; s++) { x[s] = (float)row[2 * s + hi]; sum += x[s]; }
+                const float mean = (sum + __shfl_xor(sum, 32)) / (float)ACT_IN;
+                float var = 0.f;
+#pragma unroll
+                for (int s = 0; s < ACT_IN / 2; s++) { const float d = x[s] - mean; var = fmaf(d, d, var); }
+                const float rstd = 1.0f / sqrtf((var + __shfl_xor(var, 32)) / (float)ACT_IN + 1e-12f);
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++) acc[nt][q] = b1c[nt];
+#pragma unroll
+                for (int s = 0; s < ACT_IN / 2; s++) {
+                    const float inv = rstd * g0[2 * s + hi];
+                    const float a = fmaf(x[s], inv, be0[2 * s + hi] - mean * inv);
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B1[s][nt], acc[nt], 0, 0, 0);
+                }
+            }
+            // ---- C layout -> LDS [vehicle][feature]: lane holds column 32nt + lo, rows (q&3) + 8(q>>2) + 4hi
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) Hs[(q & 3) + 8 * (q >> 2) + 4 * hi][32 * nt + lo] = acc[nt][q];
+            __syncthreads();
+            // ---- layer 2: LayerNorm_1 -> ReLU -> dense 64x64
+            {
+                float raw[ACT_H / 2], sum = 0.f;
+#pragma unroll
+                for (int s = 0; s < ACT_H / 2; s++) { raw[s] = Hs[lo][2 * s + hi]; sum += raw[s]; }
+                const float mean = (sum + __shfl_xor(sum, 32)) / (float)ACT_H;
+                float var = 0.f;
+#pragma unroll
+                for (int s = 0; s < ACT_H / 2; s++) { const float d = raw[s] - mean; var = fmaf(d, d, var); }
+                const float rstd = 1.0f / sqrtf((var + __shfl_xor(var, 32)) / (float)ACT_H + 1e-12f);
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++) acc[nt][q] = b2c[nt];
+#pragma unroll
+                for (int s = 0; s < ACT_H / 2; s++) {
+                    const float inv = rstd * g1[2 * s + hi];
+                    const float a = fmaxf(fmaf(raw[s], inv, be1[2 * s + hi] - mean * inv), 0.f);
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B2[s][nt], acc[nt], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) Hs[(q & 3) + 8 * (q >> 2) + 4 * hi][32 * nt + lo] = acc[nt][q];
+            __syncthreads();
+            // ---- layer 3: LayerNorm_2 -> ReLU -> dense 64x1 -> 3*tanh
+            {
+                float raw[ACT_H / 2], sum = 0.f;
+#pragma unroll
+                for (int s = 0; s < ACT_H / 2; s++) { raw[s] = Hs[lo][2 * s + hi]; sum += raw[s]; }
+                const float mean = (sum + __shfl_xor(sum, 32)) / (float)ACT_H;
+                float var = 0.f;
+#pragma unroll
+                for (int s = 0; s < ACT_H / 2; s++) { const float d = raw[s] - mean; var = fmaf(d, d, var); }
+                const float rstd = 1.0f / sqrtf((var + __shfl_xor(var, 32)) / (float)ACT_H + 1e-12f);
+                float part = 0.f;
+#pragma unroll
+                for (int s = 0; s < ACT_H / 2; s++) {
+                    const float inv = rstd * g2[2 * s + hi];
+                    const float y = fmaxf(fmaf(raw[s], inv, be2[2 * s + hi] - mean * inv), 0.f);
+                    part = fmaf(y, w3[2 * s + hi], part);
+                }
+                const float y = part + __shfl_xor(part, 32) + b3;
+                const float a = 3.0f * tanhf(y);
+                if (hi == 0 && valid) actions[base + slot] = (double)a;
+            }
+            __syncthreads();                    // Hs is rewritten by the next pass
+        }
+        __syncthreads();                        // slot_of is rewritten for the next environment
+    }
+}
+
 #endif  // __HIPCC__
 }  // namespace pve

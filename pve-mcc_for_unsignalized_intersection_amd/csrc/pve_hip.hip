@@ -125,6 +125,8 @@ static std::string hip_err(const char *what, hipError_t e)
     return std::string(what) + ": " + hipGetErrorString(e);
 }
 
+static int actor_grid = 2048;   // PVE_ACTOR_GRID env var (tuning knob): persistent workgroups of k_actor_mfma
+
 struct Backend {
     static int set_device(int dev, std::string &err)
     {
@@ -132,6 +134,7 @@ struct Backend {
         hipError_t e = hipGetDeviceCount(&n);
         if (e != hipSuccess || n <= 0) { err = "no HIP device visible (libpveenv.so needs an AMD GPU; there is no CPU fallback)"; return -1; }
         if (dev < 0 || dev >= n) { err = "device_id out of range"; return -1; }
+        if (const char *g = getenv("PVE_ACTOR_GRID")) { int v = atoi(g); if (v > 0) actor_grid = v; }
         e = hipSetDevice(dev);
         if (e != hipSuccess) { err = hip_err("hipSetDevice", e); return -1; }
         return 0;
@@ -180,8 +183,16 @@ struct Backend {
                             int cap, void *stream, std::string &err)
     {
         hipStream_t s = (hipStream_t)stream;
-        if (cap == 64) hipLaunchKernelGGL(k_actor<64>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
-        else hipLaunchKernelGGL(k_actor<128>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+        static const bool valu = getenv("PVE_ACTOR_VALU") != nullptr;    // A/B knob: the scalar-broadcast VALU kernel
+        if (valu) {
+            if (cap == 64) hipLaunchKernelGGL(k_actor<64>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+            else hipLaunchKernelGGL(k_actor<128>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+        } else {
+            // persistent waves (the 92 weight VGPRs are loaded once per wave): 256 CUs x 8 waves
+            const int grid = n_envs < actor_grid ? n_envs : actor_grid;
+            if (cap == 64) hipLaunchKernelGGL(k_actor_mfma<64>, dim3(grid), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+            else hipLaunchKernelGGL(k_actor_mfma<128>, dim3(grid), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+        }
         return check_launch(err);
     }
     static int launch_probe(const Params &P, int cap, int *sink, void *stream, std::string &err)
