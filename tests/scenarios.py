@@ -190,3 +190,24 @@ def check_fuzz_vs_oracle(backend, n_envs, capacity, ticks, rate, seed, action_sc
         assert close(ovf[:, :5], vf[:, :5], 1e-9), "final state floats, env %d" % e
     assert b.metrics()["overflow"] == 0
     return tot_coll, tot_lock
+
+
+def check_reset_reproducible(backend):
+    """A second reset() replays exactly the same episode (the reference builds a fresh object per episode)."""
+    arr = synthetic_arrivals(3, rate=900.0, horizon_s=60.0, seed=5)
+    b = make_batch(arr, 3, 128, backend, outputs=("obs_post", "reward", "flags", "env_out"))
+    g = torch.Generator().manual_seed(7)
+    acts = (torch.rand(80, 3, 128, generator=g, dtype=torch.float64) * 4 - 2)
+
+    def episode():
+        b.reset()
+        rew = []
+        for t in range(80):
+            out = b.step(acts[t].contiguous().to(b.device))
+            rew.append(_np(out["reward"]).copy())
+        return np.stack(rew), {k: _np(b.state_field(k)).copy() for k in ("p", "v", "id", "meta")}, b.metrics()
+    r1, s1, m1 = episode()
+    r2, s2, m2 = episode()
+    assert np.array_equal(r1, r2) and m1 == m2
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k]), k

@@ -48,3 +48,7 @@ def test_overflow_defers_spawns():
 
 def test_empty_env_and_exhausted_stream():
     scenarios.check_empty_and_exhausted(BACKEND)
+
+
+def test_reset_replays_the_same_episode():
+    scenarios.check_reset_reproducible(BACKEND)
