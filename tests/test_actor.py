@@ -43,3 +43,19 @@ def test_actor_through_c_abi_emulated():
 
 def test_closed_loop_through_c_abi_emulated():
     A.check_closed_loop_on_device("emu", ticks=1000)
+
+
+def test_evaluate_protocol_known_answers(monkeypatch):
+    """pve_mcc_amd.evaluate = main.py:test() on the device; through the emulator it reproduces SURVEY App. D's
+    pretrained-actor row (323 vehicles, 281 passed, 0 collisions, 548 locks, pT-m 12.294 s, 208.799 jerk/veh)."""
+    import os
+    from pve_mcc_amd import evaluate as E
+    from pve_mcc_amd.arrivals import pad_stream
+    from tests.hip_adapter import emulator_lib
+    orig = E.BatchedIntersections
+    monkeypatch.setattr(E, "BatchedIntersections",
+                        lambda *a, **k: orig(*a, **{**k, "device": "cpu", "_lib": emulator_lib()}))
+    res = E.evaluate(pad_stream(A.stream_1000()), load_weights(), ticks=1000, device="cpu")
+    assert (res["vehicles"], res["passed"], res["collisions"], res["lock_num"]) == (323, 281, 0, 548)
+    assert abs(res["pT_m"] - 12.294) < 1e-3 and abs(res["jerk_mean"] - 208.799) < 1e-2
+    assert abs(res["reward_mean"] - 1.30294) < 1e-4
