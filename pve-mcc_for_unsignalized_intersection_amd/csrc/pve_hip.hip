@@ -17,6 +17,7 @@
 
 using namespace pve;
 
+typedef __attribute__((address_space(4))) const char *KernargPtr;
 // diagnostics (pve_debug_phase_cycles): every wave keeps the clock ticks it spent in each phase (incl. the
 // wait at the closing barrier) in registers and adds them to its private row of a [n_waves][16] device
 // buffer at the end of the kernel (no shared atomics, no extra memory traffic inside the phases)
@@ -28,8 +29,11 @@ using namespace pve;
     }
 
 template <int CAP>
-__global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
+__global__ __launch_bounds__(CAP) void k_tick(const Const c_arg, const Params P_arg)
 {
+    KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka0_;
+    const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + ((sizeof(Const) + 7) / 8 * 8));
     __shared__ Shared<CAP> sh;
     const int t = threadIdx.x;
     const int env = blockIdx.x;
@@ -87,8 +91,9 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c, const Params P)
 }
 
 template <int CAP>
-__global__ __launch_bounds__(CAP) void k_compact(const Params P)
+__global__ __launch_bounds__(CAP) void k_compact(const Params P_arg)
 {
+    const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ Shared<CAP> sh;
     const int t = threadIdx.x;
     const int env = blockIdx.x;
@@ -114,8 +119,11 @@ __global__ __launch_bounds__(CAP) void k_probe(const Params P, int *sink)
 }
 
 template <int CAP>
-__global__ __launch_bounds__(64) void k_reset(const Const c, const Params P, int cap_ticks)
+__global__ __launch_bounds__(64) void k_reset(const Const c_arg, const Params P_arg, int cap_ticks)
 {
+    KernargPtr kar_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const PVE_AS4 Const &c = *(const PVE_AS4 Const *)kar_;
+    const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(kar_ + ((sizeof(Const) + 7) / 8 * 8));
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env < P.n_envs) reset_env<CAP>(c, P, env, cap_ticks);
 }

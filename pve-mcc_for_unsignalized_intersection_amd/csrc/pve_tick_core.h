@@ -18,6 +18,11 @@
 #include "pve_types.h"
 #include <math.h>
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PVE_AS4 __attribute__((address_space(4)))
+#else
+#define PVE_AS4
+#endif
 #if defined(__HIPCC__)
 #undef PVE_HD
 #define PVE_HD __device__ __forceinline__
@@ -232,7 +237,7 @@ PVE_HD void sincos_q1(double x, double &sn, double &cs)
     cs = fold ? s1 : c1;
 }
 
-PVE_HD void get_xy(const Const &c, double p, int lane, double &X, double &Y)
+PVE_HD void get_xy(const PVE_AS4 Const &c, double p, int lane, double &X, double &Y)
 {   // straight-line (select-based) so that the two evaluations per vehicle pair overlap in the pipeline
     const double cw = c.cw;
     const int m = lane % 3;
@@ -259,7 +264,7 @@ PVE_HD void get_xy(const Const &c, double p, int lane, double &X, double &Y)
 }
 
 // single-precision position for the collision PRE-FILTER only (never for a decision): |error| < 1e-3 m
-PVE_HD void get_xy_f32(const Const &c, double pd, int lane, float &X, float &Y)
+PVE_HD void get_xy_f32(const PVE_AS4 Const &c, double pd, int lane, float &X, float &Y)
 {
     const float cw = (float)c.cw, p = (float)pd;
     const int m = lane % 3;
@@ -287,7 +292,7 @@ PVE_HD bool key_less(double d1, double v1, int r1, double d2, double v2, int r2)
     return d1 < d2 || (d1 == d2 && (v1 < v2 || (v1 == v2 && r1 < r2)));
 }
 
-PVE_HD int brake_needed(const Const &c, double p, double v, double fp, double fv)
+PVE_HD int brake_needed(const PVE_AS4 Const &c, double p, double v, double fp, double fv)
 {   // ref :1509-1516 (front = vehicle j-1 AFTER its own update)
     // straight-line (no branch) so that the divisions of both outcomes overlap
     const double d_safe = v * 0.4 + (v * v - fv * fv) / c.two_abs_am - (v - fv) * c.vm / c.abs_am;
@@ -307,7 +312,7 @@ template <int CAP> struct Tick {
     static constexpr int NW = CAP / 64;
 
     // ============================================================== L: load
-    static PVE_HD void ph_load(const Const &c, const Params &P, int env, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_load(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
         const EnvHeader &gh = P.headers[env];
         {
@@ -342,7 +347,7 @@ template <int CAP> struct Tick {
     }
 
     // ============================================================== S1: step, both outcomes
-    static PVE_HD void outcome(const Const &c, double p, double v, double a, bool ctl, double &pn, double &vn)
+    static PVE_HD void outcome(const PVE_AS4 Const &c, double p, double v, double a, bool ctl, double &pn, double &vn)
     {   // ref :1528-1535
         pn = p - v * c.deltaT - 0.5 * a * c.dt2;
         double x = v + a * c.deltaT;
@@ -350,12 +355,12 @@ template <int CAP> struct Tick {
         vn = (x < c.vM) ? x : c.vM;
         if (!ctl) vn = c.v0;
     }
-    static PVE_HD double clip_a(const Const &c, double x)
+    static PVE_HD double clip_a(const PVE_AS4 Const &c, double x)
     {   // min(aM, max(am, x)), ref :1502, 1521
         double y = (x > c.am) ? x : c.am;
         return (c.aM < y) ? c.aM : y;
     }
-    static PVE_HD void ph_step1(const Const &c, const Params &P, int env, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_step1(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
         r.ctl = 0; r.lane = 0; r.j = 0; r.a0 = r.a1 = 0;
         if (r.alive) {
@@ -383,7 +388,7 @@ template <int CAP> struct Tick {
     }
 
     // ============================================================== S2: brake decision per front outcome
-    static PVE_HD void ph_step2(const Const &c, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_step2(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         int bb = 0;
         if (r.alive && r.j > 0 && r.ctl && mask_test(sh.m_ctl, t - 1)) {         // ref :1509-1510
@@ -394,7 +399,7 @@ template <int CAP> struct Tick {
     }
 
     // ============================================================== S3: resolve the in-lane chain
-    static PVE_HD void ph_step3(const Const &c, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_step3(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         if (r.alive) {
             int k = t;
@@ -416,7 +421,7 @@ template <int CAP> struct Tick {
 
     // ============================================================== LISTS: offsets (runs beside S2 / S3)
     // thread d < 12: size and segment layout of virtual-lane list d from the controlled-vehicle ballot.
-    static PVE_HD void ph_lists_a(const Const &c, int t, Sh &sh)
+    static PVE_HD void ph_lists_a(const PVE_AS4 Const &c, int t, Sh &sh)
     {
         int cnt = 0;
         if (t < NL * 5) {                                 // lane t: segment k of list d
@@ -442,7 +447,7 @@ template <int CAP> struct Tick {
 
     // ============================================================== BUILD: every controlled vehicle files
     // itself into its own lane's list and into the lists of the lanes it conflicts with (ref :240-270)
-    static PVE_HD void ph_build(const Const &c, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_build(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         if (!(r.alive && r.ctl)) return;
         const int lane = r.lane;
@@ -497,7 +502,7 @@ template <int CAP> struct Tick {
     }
 
     // ============================================================== WALK: predecessor, 6 nearest, reward, hit
-    static PVE_HD void ph_scan(const Const &c, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_scan(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         r.reward = 0; r.hit = 0; r.hdr = -1;
 #pragma unroll
@@ -630,7 +635,7 @@ template <int CAP> struct Tick {
     }
 
     // ============================================================== REWARD: reward terms + XY collision test
-    static PVE_HD void ph_reward(const Const &c, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_reward(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         if (!(r.alive && r.ctl)) return;
         const int lane = r.lane;
@@ -684,7 +689,7 @@ template <int CAP> struct Tick {
     }
 
     // ============================================================== FX: ordered effects
-    static PVE_HD void ph_effects(const Const &c, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_effects(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         r.del = 0; r.fin = 0; r.coll_seen = 0; r.coll_fin = 0;
         if (r.alive) {
@@ -721,7 +726,7 @@ template <int CAP> struct Tick {
     }
 
     // ============================================================== LOCK: dead-lock scan + reductions
-    static PVE_HD void ph_lock(const Const &c, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_lock(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         if (r.alive && r.ctl && sh.rew_ovr[t]) r.reward = -10;                    // ref :346 via reward[-1]
         block_sum(sh.red_reward, t, (r.alive && r.ctl) ? r.reward : 0.0);
@@ -767,7 +772,7 @@ template <int CAP> struct Tick {
     // writes +1 then -1; a vehicle is never its own predecessor, so cycles have length >= 2.
 
     // ============================================================== FIN: re-pack + write-back
-    template <class R> static PVE_HD void store_slot(const Params &P, size_t g, const R &r, int meta, int hdr_word)
+    template <class R> static PVE_HD void store_slot(const PVE_AS4 Params &P, size_t g, const R &r, int meta, int hdr_word)
     {
         P.f64[F_P][g] = r.p; P.f64[F_V][g] = r.v; P.f64[F_A][g] = r.a; P.f64[F_JERK][g] = r.jerk;
         P.f64[F_JERK_SUM][g] = r.jerk_sum; P.f64[F_VIR_DIS][g] = r.vir_dis; P.f64[F_CLOSER_P][g] = r.closer_p;
@@ -782,7 +787,7 @@ template <int CAP> struct Tick {
         return (l << 16) | (slot - sh.hd.lane_start[l]);
     }
 
-    static PVE_HD void ph_final(const Const &c, const Params &P, int env, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_final(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
         EnvHeader &gh = P.headers[env];
         const int N = sh.hd.n_alive;
@@ -943,7 +948,7 @@ template <int CAP> struct Tick {
     // neighbour precedes us in (lane, j) order ("fresh", read back from obs_pre written in FIN), else
     // the row it stored last tick ("stale", obs_prev_post at the same slot); zeros when absent (ref :1335).
     // Runs after a workgroup barrier + fence so that obs_pre rows of the other threads are visible.
-    static PVE_HD void ph_state(const Params &P, int env, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
         if (!P.out.state_pre || !(r.alive && r.ctl)) return;
         const size_t base = (size_t)env * CAP;
@@ -961,7 +966,7 @@ template <int CAP> struct Tick {
     }
 
     // ============================================================== COMPACT (delete_vehicle only)
-    static PVE_HD void ph_c_load(const Params &P, int env, int t, Sh &sh, CRegs &r)
+    static PVE_HD void ph_c_load(const PVE_AS4 Params &P, int env, int t, Sh &sh, CRegs &r)
     {
         const EnvHeader &gh = P.headers[env];
         {
@@ -986,7 +991,7 @@ template <int CAP> struct Tick {
         }
         vote<NW>(sh.m_keep, t, r.alive && !(r.meta & M_DEL));
     }
-    static PVE_HD void ph_c_store(const Params &P, int env, int t, Sh &sh, CRegs &r)
+    static PVE_HD void ph_c_store(const PVE_AS4 Params &P, int env, int t, Sh &sh, CRegs &r)
     {
         EnvHeader &gh = P.headers[env];
         const int n_post = mask_count<NW>(sh.m_keep);
@@ -1009,7 +1014,7 @@ template <int CAP> struct Tick {
 // One thread per environment: advance the clock (repeated += deltaT) and spawn (lane order) until
 // at least one vehicle exists.  cap_ticks bounds the loop for streams that never deliver.
 template <int CAP>
-PVE_HD void reset_env(const Const &c, const Params &P, int env, int cap_ticks)
+PVE_HD void reset_env(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int cap_ticks)
 {
     EnvHeader h;
     {
