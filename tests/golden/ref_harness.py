@@ -65,11 +65,19 @@ class ObjRunner:
         self.guard_hits = 0
         self.tape = []          # actions fed this tick, (lane, j) order, all alive vehicles
         self._nbr_log = []
+        self.nl = int(getattr(env, "lane_num", 12))          # physical lanes
+        self.ndir = int(getattr(env, "direction_num", 12))   # virtual-lane lists (routes)
+        # lane whose scene_update pass rebuilds virtual_lane_4[0] (ref :235-239)
+        self.owner0 = 0
+        if hasattr(env, "direction"):
+            for lane in range(self.nl):
+                if 0 in list(env.direction[lane]):
+                    self.owner0 = lane
 
     def alive_view(self):
         env = self.env
         ids, ctl, obs = [], [], []
-        for lane in range(12):
+        for lane in range(self.nl):
             for veh in env.veh_info[lane]:
                 ids.append(veh["id_info"][0])
                 ctl.append(1 if veh["control"] else 0)
@@ -85,7 +93,7 @@ class ObjRunner:
         actions = np.asarray(actions, np.float64)
         self.tape = actions
         k = 0
-        for lane in range(12):
+        for lane in range(self.nl):
             for ind, veh in enumerate(env.veh_info[lane]):
                 a = float(actions[k]) if veh["control"] else 0
                 env.step(lane, ind, a)
@@ -93,7 +101,7 @@ class ObjRunner:
         self._nbr_log.clear()
         guarded = False
         plain = None
-        if self.guard and len(env.veh_info[0]) == 0 and len(env.virtual_lane_4[0]) > 0:
+        if self.guard and len(env.veh_info[self.owner0]) == 0 and len(env.virtual_lane_4[0]) > 0:
             plain = env.virtual_lane_4[0]
             env.virtual_lane_4[0] = _SilentIter(plain)
             guarded = True
@@ -127,8 +135,8 @@ class ObjRunner:
         rec["lock"] = int(lock)
         rec["jerks"] = np.array([float(x) for x in jerks], np.float64)
         rec["deleted"] = np.array(env.delete_veh, np.int32).reshape(len(env.delete_veh), 2)
-        vi, vf = [], []
-        for lane in range(12):
+        vi, vf, intent = [], [], []
+        for lane in range(self.nl):
             for j, v in enumerate(env.veh_info[lane]):
                 d = dict(lane=lane, j=j, id=v["id_info"][0], seq=v["seq_in_lane"], vnum=v["id_info"][1],
                          control=int(bool(v["control"])), finish=int(bool(v["finish"])),
@@ -137,15 +145,18 @@ class ObjRunner:
                          hdr_lane=int(v["vir_header"][0]), hdr_j=int(v["vir_header"][1]))
                 vi.append([d[c] for c in VEH_I_COLS])
                 vf.append([float(v[c]) for c in VEH_F_COLS])
+                intent.append([int(v.get("intention", lane % 3)), int(v.get("route", lane))])
         rec["veh_i"] = np.array(vi, np.int32).reshape(len(vi), len(VEH_I_COLS))
         rec["veh_f"] = np.array(vf, np.float64).reshape(len(vf), len(VEH_F_COLS))
+        rec["intent"] = np.array(intent, np.int32).reshape(len(intent), 2)
+        rec["intention_re"] = int(getattr(env, "intention_re", 0))
         rec["id_seq"] = int(env.id_seq)
         rec["passed"] = int(env.passed_veh)
         rec["passed_step_total"] = int(env.passed_veh_step_total)
         rec["veh_num"] = np.array(env.veh_num, np.int32)
         rec["veh_rec"] = np.array(env.veh_rec, np.int32)
-        heads = np.zeros((12, 3), np.int32)
-        for d in range(12):
+        heads = np.zeros((self.ndir, 3), np.int32)
+        for d in range(self.ndir):
             vl = env.virtual_lane_4[d]
             if len(vl) > 0:
                 heads[d] = (1, vl[0][1], vl[0][2])
@@ -169,3 +180,56 @@ class RefRunner(ObjRunner):
             orig(i, j, vl4, mode=mode, veh_num=veh_num)
             self._nbr_log.append([list(c) for c in env.closer_cars])
         env.virtual_lane_search_closer = spy
+
+
+class _ChoiceShim:
+    """Stands in for the `random` module inside the reference (ref :381, :390): seed() is a no-op and
+    randint(0, 1) replays `choice[veh_rec[lane]][lane]` for the lane that is spawning."""
+
+    def __init__(self, choice):
+        self.choice = np.asarray(choice, np.int64)
+        self.lane = 0
+        self.rec = 0
+        self.draws = 0
+
+    def seed(self, *a, **k):
+        pass
+
+    def randint(self, a, b):
+        assert (a, b) == (0, 1)
+        self.draws += 1
+        return int(self.choice[self.rec][self.lane])
+
+
+class GeoRefRunner(ObjRunner):
+    """ObjRunner over the unmodified reference class with lane_num 4 or 8 (or 12).  A thin subclass tells the
+    random shim which lane is spawning; everything else is the reference's own code."""
+
+    def __init__(self, arrive_time, lane_num, policy, choice=None, want_state=False, **ctor_kw):
+        tis = import_reference()
+        arrive_time = np.asarray(arrive_time, np.float64)
+        if choice is None:
+            choice = np.zeros(arrive_time.shape, np.int64)
+        shim = _ChoiceShim(choice)
+        self.shim = shim
+
+        class _Spy(tis.TrafficInteraction):
+            def add_new_veh(self_env, i):
+                shim.lane = i
+                shim.rec = self_env.veh_rec[i]
+                return tis.TrafficInteraction.add_new_veh(self_env, i)
+
+        self._tis = tis
+        self._saved_random = tis.random
+        tis.random = shim
+        env = _Spy(arrive_time, 150, default_args(), show_col=False, virtual_l=True, lane_num=lane_num, **ctor_kw)
+        ObjRunner.__init__(self, env, policy, want_state, guard=True)
+        orig = env.virtual_lane_search_closer
+
+        def spy(i, j, vl4, mode="front", veh_num=3):
+            orig(i, j, vl4, mode=mode, veh_num=veh_num)
+            self._nbr_log.append([list(c) for c in env.closer_cars])
+        env.virtual_lane_search_closer = spy
+
+    def close(self):
+        self._tis.random = self._saved_random

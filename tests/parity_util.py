@@ -9,6 +9,8 @@ from oracle.record import (DIGEST_F_COLS, DIGEST_I_COLS, compare_records, digest
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASE_NAMES = ["s1000_zero", "s1000_sin1", "s200_sin1", "s1200_sin1", "s1200_zero", "s400_sin2",
               "s1000_sin3", "s1000_sin1_vm6"]
+# 4- / 8-lane geometries: synthetic streams + intention draws stored in the fixture
+GEO_CASE_NAMES = ["geo_g4_zero", "geo_g4_sin2", "geo_g4_sin3", "geo_g8_zero", "geo_g8_sin2", "geo_g8_sin3"]
 DENSE_FIELDS = ("ids", "nbr", "reward", "obs0", "coll_pv", "deleted", "jerks", "veh_i", "veh_f",
                 "heads", "veh_num", "veh_rec")
 
@@ -26,10 +28,14 @@ class GoldenCase:
         self.policy = get_policy(self.meta["policy"])
         self.dense_ticks = set(int(t) for t in self.z["dense_ticks"])
         self.state_ticks = set(int(t) for t in self.z["state_ticks"])
+        self.lane_num = int(self.meta.get("lane_num", 12))
+        self.choice = np.ascontiguousarray(self.z["choice"], np.int32) if "choice" in self.z.files else None
 
     def dense_record(self, t):
         z = self.z
         rec = {f: z["t%d_%s" % (t, f)] for f in DENSE_FIELDS}
+        if "t%d_intent" % t in z.files:
+            rec["intent"] = z["t%d_intent" % t]
         sc = z["t%d_scalars" % t]
         rec.update(tick=t, time=float(z["t%d_time" % t]), collisions=int(sc[0]), lock=int(sc[1]),
                    id_seq=int(sc[2]), passed=int(sc[3]), passed_step_total=int(sc[4]))
@@ -57,7 +63,10 @@ def check_against_golden(case, t, rec, ftol=1e-9, dtol=1e-9):
         assert abs(df[k] - gf[k]) <= ftol * scale, "%s tick %d: digest float %s: %r vs golden %r" % (
             case.name, t, col, df[k], gf[k])
     if t in case.dense_ticks:
-        compare_records(case.dense_record(t), rec, tol=dtol, label=case.name + "/dense")
+        gold = case.dense_record(t)
+        compare_records(gold, rec, tol=dtol, label=case.name + "/dense")
+        if "intent" in gold and rec.get("intent") is not None:
+            assert np.array_equal(gold["intent"], rec["intent"]), "%s tick %d: intent differs" % (case.name, t)
 
 
 def replay_case(case, env, ticks=None, ftol=1e-9, dtol=1e-9, want_state=True):

@@ -30,3 +30,30 @@ def test_oracle_dense_vs_live_reference(stream, pol, ticks, kw):
         rb = orc.tick(acts, want_state=True)
         compare_records(ra, rb, tol=1e-12, label="%s/%s" % (stream, pol))
     assert orc.ref_would_raise == 0
+
+
+GEO_CASES = [(4, "zero", 2.0, 11, 500), (4, "sin3", 1.2, 12, 500), (8, "sin2", 1.5, 13, 500),
+             (8, "sin3", 1.2, 14, 400), (12, "sin3", 1.5, 15, 300)]
+
+
+@pytest.mark.parametrize("lane_num,pol,mean,seed,ticks", GEO_CASES)
+def test_geo_oracle_dense_vs_live_reference(lane_num, pol, mean, seed, ticks):
+    """oracle/pve_oracle_geo.c vs the live reference with lane_num 4 / 8 / 12 on fresh synthetic streams
+    (other seeds than the committed fixtures), every tick, every field, full 7x28 state."""
+    from oracle.oracle_geo import OracleGeoEnv
+    from tests.golden import ref_harness as rh
+    from tests.golden.gen_golden_geo import make_stream
+    arr, choice = make_stream(lane_num, 400, mean, seed)
+    policy = get_policy(pol)
+    ref = rh.GeoRefRunner(arr, lane_num, policy, choice=choice, want_state=True)
+    try:
+        orc = OracleGeoEnv(arr, lane_num, choice=choice)
+        for t in range(ticks):
+            ra = ref.tick()
+            rb = orc.tick(ref.tape, want_state=True)
+            compare_records(ra, rb, tol=1e-12, label="geo%d/%s" % (lane_num, pol))
+            assert np.array_equal(ra["intent"], rb["intent"])
+            assert ra["intention_re"] == rb["intention_re"]
+        assert orc.ref_would_raise == 0
+    finally:
+        ref.close()
