@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define PVE_ABI_VERSION 1
-#define PVE_LANES 12
+#define PVE_ABI_VERSION 2
+#define PVE_LANES 12          /* physical lanes: lane_num = 4, 8 or 12 (arrays are padded to 12) */
+#define PVE_MAX_DIRS 16       /* virtual-lane lists (routes): 12 for lane_num 4 / 12, 16 for lane_num 8 (ref :86, :132, :167) */
 #define PVE_OBS_WIDTH 28      /* (o_agent_num + 1) * 4, ref :1295 */
 #define PVE_NBR 6             /* ref :1324 hard-codes 6 neighbours */
 #define PVE_STATE_ROWS 7
@@ -43,7 +44,9 @@ enum {
 };
 
 /* Constructor arguments of the reference, ref :21-23 (`TrafficInteraction.__init__`), plus
- * args.collision_thr (ref :32).  lane_num must be 12 (3/4/8-lane branches are out of scope). */
+ * args.collision_thr (ref :32).  lane_num = 12 runs the optimised kernel (BASELINE metric); lane_num = 4 or 8
+ * (ref :66-145) run the general-geometry kernel.  The 3-lane branch is broken upstream. */
+#define PVE_CFG_GENERAL_PATH 0x1   /* flags: use the general-geometry kernel for lane_num = 12 too (cross-checks) */
 typedef struct pve_config {
     double deltaT;          /* 0.1 */
     double vm, vM;          /* 5, 13   (train(): vm = 6, main.py:230) */
@@ -52,8 +55,8 @@ typedef struct pve_config {
     double lane_cw;         /* 2.5 */
     double dis_ctl;         /* 150 */
     double collision_thr;   /* 2 (main.py:104) */
-    int32_t lane_num;       /* 12 */
-    int32_t reserved;
+    int32_t lane_num;       /* 12 (default), 4 or 8 */
+    int32_t flags;          /* PVE_CFG_* */
 } pve_config;
 
 /* Per-tick outputs.  Every pointer may be NULL (that output is skipped).
@@ -82,6 +85,8 @@ typedef struct pve_outputs {
 #define PVE_F_DELETED   0x08  /* in delete_veh (exit or collision, ref :348) */
 #define PVE_F_FINISHED  0x10  /* passed the box this tick: reward 5, jerks entry (ref :350-359) */
 #define PVE_F_LOCK      0x20  /* veh["lock"] set by the dead-lock scan (ref :1482) */
+#define PVE_F_INTENT_SHIFT 6  /* bits 6-7: veh["intention"] (ref :382-394); scene_update emits `ids` in
+                                 (lane, intention, j) order (ref :233-275), which differs from slot order for lane_num 4 / 8 */
 
 #define PVE_ENV_OUT_N 8
 enum { PVE_EO_N_PRE = 0,      /* vehicles alive at tick start */
@@ -111,8 +116,9 @@ typedef struct pve_env_info {
     int32_t lane_count[PVE_LANES];       /* veh_num, ref :206 */
     int32_t veh_rec[PVE_LANES];          /* ref :207 */
     int32_t id_seq, passed_veh, passed_veh_step_total;   /* ref :197-198, 212 */
-    int32_t head_valid[PVE_LANES], head_lane[PVE_LANES], head_j[PVE_LANES];  /* virtual_lane_4[d][0][1:3], ref :1517 */
+    int32_t head_valid[PVE_MAX_DIRS], head_lane[PVE_MAX_DIRS], head_j[PVE_MAX_DIRS];  /* virtual_lane_4[d][0][1:3], ref :1517 */
     int32_t overflow;                    /* spawns deferred because the env was full */
+    int32_t intention_re;                /* ref :42, :387-392 (lane_num 4 / 8) */
 } pve_env_info;
 
 typedef struct pve_handle_s *pve_handle;
@@ -133,9 +139,15 @@ int pve_destroy(pve_handle h);
 int pve_set_stream(pve_handle h, void *stream);
 
 /* Arrival streams `arrive_time` (ref :195, main.py:388-389): DEVICE buffer of float64
- * [n_envs][rows][12] (env_stride_rows = rows) or one shared [rows][12] stream (env_stride_rows = 0).
+ * [n_envs][rows][lane_num] (env_stride_rows = rows) or one shared [rows][lane_num] stream (env_stride_rows = 0).
  * Times beyond the run must be padded with +inf.  The buffer must outlive the handle's use of it. */
 int pve_set_arrivals(pve_handle h, const double *arrivals, int rows, int env_stride_rows);
+
+/* lane_num = 8 only: the reference draws each new vehicle's intention with random.randint(0, 1) after reseeding
+ * `random` from OS entropy (ref :381, :390), i.e. irreproducibly; here the draws are an input stream like the
+ * arrivals: DEVICE int32 [n_envs][rows][8] (or shared, env_stride_rows = 0), entry [veh_rec[lane]][lane] in {0,1}
+ * picks intention[lane][draw] (ref :125-134).  Not set = all zeros.  Must be set before pve_reset. */
+int pve_set_intentions(pve_handle h, const int32_t *choice, int rows, int env_stride_rows);
 
 /* Constructor warm-up (ref :196-220): zero all state, then advance each env's clock tick by tick
  * (spawning, ref :378) until it holds at least one vehicle. */

@@ -11,14 +11,18 @@ LIB_NAME = "libpveenv.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 PVE_LANES = 12
+PVE_MAX_DIRS = 16
+DIR_NUM = {4: 12, 8: 16, 12: 12}     # virtual-lane lists per layout (ref :86, :132, :167)
+CFG_GENERAL_PATH = 0x1
 PVE_OBS_WIDTH = 28
 PVE_NBR = 6
 PVE_N_METRICS = 12
 PVE_ENV_OUT_N = 8
 PVE_ACTOR_N_WEIGHTS = 6393
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F_ALIVE, F_CTL, F_DONE, F_DELETED, F_FINISHED, F_LOCK = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+F_INTENT_SHIFT = 6
 META_CONTROL, META_FINISH, META_DONE, META_LOCK = 0x1, 0x2, 0x4, 0x8
 METRIC_NAMES = ("slot_steps", "alive_steps", "ctl_steps", "spawned", "passed", "collided", "locks",
                 "sum_reward", "sum_jerk", "passed_steps", "overflow", "ticks")
@@ -32,7 +36,7 @@ class PveError(RuntimeError):
 class PveConfig(C.Structure):
     _fields_ = [("deltaT", C.c_double), ("vm", C.c_double), ("vM", C.c_double), ("am", C.c_double),
                 ("aM", C.c_double), ("v0", C.c_double), ("lane_cw", C.c_double), ("dis_ctl", C.c_double),
-                ("collision_thr", C.c_double), ("lane_num", C.c_int32), ("reserved", C.c_int32)]
+                ("collision_thr", C.c_double), ("lane_num", C.c_int32), ("flags", C.c_int32)]
 
 
 class PveOutputs(C.Structure):
@@ -51,15 +55,16 @@ class PveVehicle(C.Structure):
 class PveEnvInfo(C.Structure):
     _fields_ = [("current_time", C.c_double), ("n_alive", C.c_int32), ("lane_count", C.c_int32 * 12),
                 ("veh_rec", C.c_int32 * 12), ("id_seq", C.c_int32), ("passed_veh", C.c_int32),
-                ("passed_veh_step_total", C.c_int32), ("head_valid", C.c_int32 * 12),
-                ("head_lane", C.c_int32 * 12), ("head_j", C.c_int32 * 12), ("overflow", C.c_int32)]
+                ("passed_veh_step_total", C.c_int32), ("head_valid", C.c_int32 * 16),
+                ("head_lane", C.c_int32 * 16), ("head_j", C.c_int32 * 16), ("overflow", C.c_int32),
+                ("intention_re", C.c_int32)]
 
 
 EXPORTS = ("pve_abi_version", "pve_last_error", "pve_default_config", "pve_workspace_bytes", "pve_create",
            "pve_destroy", "pve_set_stream", "pve_set_arrivals", "pve_reset", "pve_step_all",
            "pve_scene_update", "pve_compact", "pve_read_env", "pve_read_vehicles", "pve_get_metrics",
            "pve_state_field", "pve_synchronize", "pve_debug_phase_cycles", "pve_actor_forward",
-           "pve_step_all_actor", "pve_debug_traffic_probe")
+           "pve_step_all_actor", "pve_debug_traffic_probe", "pve_set_intentions")
 
 
 def _declare(L):
@@ -73,6 +78,7 @@ def _declare(L):
     L.pve_destroy.argtypes = [vp]
     L.pve_set_stream.argtypes = [vp, vp]
     L.pve_set_arrivals.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.pve_set_intentions.argtypes = [vp, vp, C.c_int, C.c_int]
     L.pve_reset.argtypes = [vp]
     L.pve_step_all.argtypes = [vp, vp, C.POINTER(PveOutputs)]
     L.pve_scene_update.argtypes = [vp, vp, C.POINTER(PveOutputs)]

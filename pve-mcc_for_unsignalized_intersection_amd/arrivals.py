@@ -3,18 +3,27 @@ MATLAB v5 `arvTimeNewVeh` files (main.py:387-389, data/test/*.mat)."""
 import numpy as np
 
 
-def synthetic_arrivals(n_envs, rate, horizon_s, seed=20250213, rows=None):
-    """float64 [n_envs, rows, 12]: per env e and lane, cumulative sums of inter-arrival times
+def synthetic_arrivals(n_envs, rate, horizon_s, seed=20250213, rows=None, lane_num=12):
+    """float64 [n_envs, rows, lane_num]: per env e and lane, cumulative sums of inter-arrival times
     max(1.0, Exponential(3600/rate)) from numpy.random.default_rng(seed + e), padded with +inf
     (the shipped streams have the same clipped-exponential shape)."""
     mean = 3600.0 / float(rate)
     if rows is None:
         rows = 64 + int(np.ceil(horizon_s / mean)) * 2
-    out = np.full((n_envs, rows, 12), np.inf, dtype=np.float64)
+    out = np.full((n_envs, rows, lane_num), np.inf, dtype=np.float64)
     for e in range(n_envs):
         rng = np.random.default_rng(seed + e)
-        dt = np.maximum(1.0, rng.exponential(mean, size=(rows - 1, 12)))
+        dt = np.maximum(1.0, rng.exponential(mean, size=(rows - 1, lane_num)))
         out[e, :rows - 1, :] = np.cumsum(dt, axis=0)
+    return out
+
+
+def synthetic_intentions(n_envs, rows, seed=20250213, lane_num=8):
+    """int32 [n_envs, rows, lane_num] of 0/1: the intention draws of the 8-lane layout (the reference's
+    random.randint(0, 1) at ref :390, one per arriving vehicle), from numpy.random.default_rng(seed + e)."""
+    out = np.zeros((n_envs, rows, lane_num), dtype=np.int32)
+    for e in range(n_envs):
+        out[e] = np.random.default_rng(seed + 7919 * (e + 1)).integers(0, 2, size=(rows, lane_num))
     return out
 
 

@@ -1,4 +1,5 @@
-"""BatchedIntersections: thousands of independent 12-lane intersections per GPU.
+"""BatchedIntersections: thousands of independent intersections per GPU (12-lane fast path; 4- / 8-lane layouts
+through the general-geometry kernel).
 
 Python host code over the C ABI (include/pve_env.h); torch is used only for device memory and
 the stream.  One fused HIP kernel launch per tick = the reference's
@@ -30,13 +31,17 @@ def make_config(lib, **kw):
 class BatchedIntersections:
     """n_envs environments x `capacity` vehicle slots, state resident in HBM (struct of arrays).
 
-    arrivals: float64 array/tensor [rows, 12] (shared by all envs) or [n_envs, rows, 12]; the
+    arrivals: float64 array/tensor [rows, lane_num] (shared by all envs) or [n_envs, rows, lane_num]; the
               reference's `arrive_time` matrix (main.py:388-389). Pad with +inf.
     outputs:  names of per-tick output buffers to allocate (see include/pve_env.h `pve_outputs`).
+    intentions: lane_num = 8 only -- int array [rows, 8] / [n_envs, rows, 8] of 0/1: the reference's
+              random.randint(0, 1) draws (ref :390) as an input stream (None = zeros).
+    config:   reference constructor arguments (lane_num = 12 | 8 | 4, vm, ...); general_path=True runs the
+              general-geometry kernel for lane_num = 12 too (cross-checks).
     """
 
     def __init__(self, n_envs, capacity, arrivals, device=None, outputs=DEFAULT_OUTPUTS, stream=None,
-                 _lib=None, **config):
+                 intentions=None, _lib=None, **config):
         if device is None:
             device = "cuda"
         self.device = torch.device(device)
@@ -47,7 +52,11 @@ class BatchedIntersections:
             _lib = _capi.load_library()
         self.lib = _lib
         self.n_envs, self.capacity = int(n_envs), int(capacity)
+        if config.pop("general_path", False):
+            config["flags"] = int(config.get("flags", 0)) | _capi.CFG_GENERAL_PATH
         self.cfg = make_config(self.lib, **config)
+        self.lane_num = int(self.cfg.lane_num)
+        self.dir_num = _capi.DIR_NUM.get(self.lane_num, 12)
         nbytes = self.lib.pve_workspace_bytes(self.n_envs, self.capacity)
         if nbytes == 0:
             raise PveError("invalid n_envs/capacity (capacity must be 64 or 128)")
@@ -62,6 +71,9 @@ class BatchedIntersections:
               "pve_create")
         self._h = h
         self.set_arrivals(arrivals)
+        self.intentions = None
+        if intentions is not None:
+            self.set_intentions(intentions)
         E, K = self.n_envs, self.capacity
         dev = self.device
         self.out = {}
@@ -108,18 +120,29 @@ class BatchedIntersections:
     def set_arrivals(self, arrivals):
         a = torch.as_tensor(np.asarray(arrivals) if not torch.is_tensor(arrivals) else arrivals,
                             dtype=torch.float64)
-        if a.dim() == 2:
-            assert a.shape[1] == 12, "arrivals must be [rows, 12]"
-            stride_rows = 0
-            rows = a.shape[0]
-        else:
-            assert a.dim() == 3 and a.shape[0] == self.n_envs and a.shape[2] == 12, \
-                "arrivals must be [rows,12] or [n_envs,rows,12]"
-            rows = a.shape[1]
-            stride_rows = rows
+        rows, stride_rows = self._stream_shape(a, "arrivals")
         self.arrivals = a.contiguous().to(self.device)
         check(self.lib, self.lib.pve_set_arrivals(self._h, C.c_void_p(self.arrivals.data_ptr()), rows, stride_rows),
               "pve_set_arrivals")
+        self._is_reset = False
+
+    def _stream_shape(self, a, what):
+        ln = self.lane_num
+        if a.dim() == 2:
+            assert a.shape[1] == ln, "%s must be [rows, %d]" % (what, ln)
+            return a.shape[0], 0
+        assert a.dim() == 3 and a.shape[0] == self.n_envs and a.shape[2] == ln, \
+            "%s must be [rows,%d] or [n_envs,rows,%d]" % (what, ln, ln)
+        return a.shape[1], a.shape[1]
+
+    def set_intentions(self, choice):
+        """lane_num = 8: the 0/1 intention draws (ref :390), same shape as the arrival stream."""
+        c = torch.as_tensor(np.asarray(choice) if not torch.is_tensor(choice) else choice, dtype=torch.int32)
+        rows, stride_rows = self._stream_shape(c, "intentions")
+        self.intentions = c.contiguous().to(self.device)
+        check(self.lib, self.lib.pve_set_intentions(self._h, C.c_void_p(self.intentions.data_ptr()), rows, stride_rows),
+              "pve_set_intentions")
+        self._is_reset = False
 
     def state_field(self, name):
         """Zero-copy [n_envs, capacity] view of a persistent per-slot field (see pve_state_field)."""

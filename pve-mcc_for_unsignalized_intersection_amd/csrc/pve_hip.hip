@@ -13,6 +13,7 @@
 
 #include "pve_host.h"
 #include "pve_tick_core.h"
+#include "pve_tick_geo.h"
 #include "pve_actor.h"
 
 using namespace pve;
@@ -88,6 +89,58 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c_arg, const Params P_
 #pragma unroll
         for (int k = 0; k < 12; k++) row[k] += pc_[k];
     }
+}
+
+// General-geometry tick (lane_num 4 / 8): same workgroup-per-intersection structure, phases of
+// pve_tick_geo.h.  Correctness-first (per-vehicle scans instead of sorted lists).
+template <int CAP>
+__global__ __launch_bounds__(CAP) void k_tick_geo(const GeoConst g_arg, const Params P_arg)
+{
+    KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const PVE_AS4 GeoConst &g = *(const PVE_AS4 GeoConst *)ka0_;
+    const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + ((sizeof(GeoConst) + 7) / 8 * 8));
+    __shared__ SharedGeo<CAP> sh;
+    const int t = threadIdx.x;
+    const int env = blockIdx.x;
+    Regs r;
+    typedef TickGeo<CAP> T;
+    typedef Tick<CAP, SharedGeo<CAP>> B;
+    T::ph_load(g, P, env, t, sh, r);
+    __syncthreads();
+    T::ph_step1(g, P, env, t, sh, r);
+    __syncthreads();
+    B::ph_step2(g.base, t, sh, r);
+    T::ph_order(t, sh, r);
+    __syncthreads();
+    B::ph_step3(g.base, t, sh, r);
+    B::ph_step3_publish(t, sh, r);
+    T::ph_order2(t, sh);
+    __syncthreads();
+    T::ph_scan(g, t, sh, r);
+    T::ph_reward(g, t, sh, r);
+    __syncthreads();
+    T::ph_effects(g, t, sh, r);
+    __syncthreads();
+    B::ph_lock(g.base, t, sh, r);
+    __syncthreads();
+    B::ph_lock2(t, sh, r);
+    __syncthreads();
+    T::ph_final(g, P, env, t, sh, r);
+    if (P.out.state_pre) {
+        __threadfence_block();
+        __syncthreads();
+        T::ph_state(P, env, t, sh, r);
+    }
+}
+
+template <int CAP>
+__global__ __launch_bounds__(64) void k_reset_geo(const GeoConst g_arg, const Params P_arg, int cap_ticks)
+{
+    KernargPtr kar_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const PVE_AS4 GeoConst &g = *(const PVE_AS4 GeoConst *)kar_;
+    const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(kar_ + ((sizeof(GeoConst) + 7) / 8 * 8));
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env < P.n_envs) reset_env_geo<CAP>(g, P, env, cap_ticks);
 }
 
 template <int CAP>
@@ -178,6 +231,21 @@ struct Backend {
         hipStream_t s = (hipStream_t)stream;
         if (cap == 64) hipLaunchKernelGGL(k_tick<64>, dim3(P.n_envs), dim3(64), 0, s, c, P);
         else hipLaunchKernelGGL(k_tick<128>, dim3(P.n_envs), dim3(128), 0, s, c, P);
+        return check_launch(err);
+    }
+    static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        if (cap == 64) hipLaunchKernelGGL(k_tick_geo<64>, dim3(P.n_envs), dim3(64), 0, s, g, P);
+        else hipLaunchKernelGGL(k_tick_geo<128>, dim3(P.n_envs), dim3(128), 0, s, g, P);
+        return check_launch(err);
+    }
+    static int launch_reset_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        const int blocks = (P.n_envs + 63) / 64;
+        if (cap == 64) hipLaunchKernelGGL(k_reset_geo<64>, dim3(blocks), dim3(64), 0, s, g, P, 200000);
+        else hipLaunchKernelGGL(k_reset_geo<128>, dim3(blocks), dim3(64), 0, s, g, P, 200000);
         return check_launch(err);
     }
     static int launch_compact(const Params &P, int cap, void *stream, std::string &err)

@@ -67,6 +67,105 @@ inline Const make_const(const pve_config &cfg)
     return c;
 }
 
+// General geometry: constructor tables of the 4- / 8-lane branches (ref :66-145), get_virtual_distance as a table
+// (ref :453-660), get_p as canonical path + quarter turns (ref :896-1249).  lane_num = 12 re-expresses make_const's
+// tables in the same form (used to cross-check the general kernel against the fast path).
+inline GeoConst make_geo_const(const pve_config &cfg)
+{
+    GeoConst g;
+    memset(&g, 0, sizeof(g));
+    g.base = make_const(cfg);
+    Const &c = g.base;
+    const int LN = cfg.lane_num;
+    const double cw = cfg.lane_cw, dc = cfg.dis_ctl;
+    g.lane_num = LN;
+    memset(g.l2l, -1, sizeof(g.l2l));
+    memset(g.direction, -1, sizeof(g.direction));
+    memset(g.dir_lane, 0, sizeof(g.dir_lane));
+    auto set = [&](int ty, int k, double A, double B, double C, double C2) {
+        g.vd[ty][k][0] = A; g.vd[ty][k][1] = B; g.vd[ty][k][2] = C; g.vd[ty][k][3] = C2;
+    };
+    if (LN == 4) {
+        g.dir_num = 12; g.tmod = 3; g.RL = 3; g.H = 2 * cw;
+        const double approach = dc - 2 * cw;                                     // ref :69-71
+        c.inbox[0] = 3.1415 / 2 * 3 * cw; c.inbox[1] = 4 * cw; c.inbox[2] = 3.1415 / 2 * cw;
+        for (int m = 0; m < 3; m++) c.spawn_p[m] = 0 + approach + c.inbox[m];
+        static const int8_t l2l[12][7] = {                                       // ref :74-87
+            {10, 6, 9, 3, 7, 4, 8}, {10, 6, 3, 4, 9, 5, -1}, {6, 10, -1, -1, -1, -1, -1},
+            {1, 9, 0, 6, 10, 7, 11}, {1, 9, 6, 7, 0, 8, -1}, {9, 1, -1, -1, -1, -1, -1},
+            {4, 0, 3, 9, 1, 10, 2},  {4, 0, 9, 10, 3, 11, -1}, {0, 4, -1, -1, -1, -1, -1},
+            {7, 3, 6, 0, 4, 1, 5},   {7, 3, 0, 1, 6, 2, -1},  {3, 7, -1, -1, -1, -1, -1}};
+        for (int d = 0; d < 12; d++) for (int k = 0; k < 7; k++) g.l2l[d][k] = l2l[d][k];
+        static const int8_t dir[4][3] = {{6, 7, 8}, {0, 1, 2}, {9, 10, 11}, {3, 4, 5}};   // ref :88-93
+        for (int i = 0; i < 4; i++) for (int k = 0; k < 3; k++) g.direction[i][k] = dir[i][k];
+        static const int8_t turn[4] = {0, 2, 1, 3};                              // ref :897, :939, :981, :1022
+        for (int i = 0; i < 4; i++) g.turn[i] = turn[i];
+        const double alpha = atan((4 - sqrt(2.0)) / (4 + sqrt(2.0)));            // ref :94-98
+        const double _alpha = atan((4 + sqrt(2.0)) / (4 - sqrt(2.0)));
+        const double beta = atan(2 / sqrt(5.0)), _beta = atan(sqrt(5.0) / 2);
+        const double gama = atan(1.0 / 2 * sqrt(2.0));
+        const double half = 0.5 * 3.1415, q = 1.5 * 3.1415 * cw, cg = cos(gama);
+        auto F = [&](double x) { return (q * x) / half; };                       // 1.5*3.1415*cw*x/(0.5*3.1415)
+        auto G = [&](double x) { return q * (x / half); };                       // (1.5*3.1415)*cw*(x/(0.5*3.1415))
+        set(0, 0, 4 * cw - 3 * cw * cg, 0, 3 * cw * (0.5 * 3.1415 - gama), 0);   // ref :455-459
+        set(0, 1, G(_alpha), 0, G(alpha), 0);                                    // ref :476-480
+        set(0, 2, F(beta), 0, F(_beta), 0);                                      // ref :466-470
+        set(0, 3, F(_beta), 0, F(beta), 0);                                      // ref :471-475
+        set(0, 4, 3 * cw * cg, 0, G(gama), 0);                                   // ref :481-485
+        set(1, 0, cw, 0, 3 * cw, 0);                                             // ref :497-516
+        set(1, 1, F(gama), 0, 3 * cw * cg, 0);
+        set(1, 2, F(0.5 * 3.1415 - gama), 0, 4 * cw - 3 * cw * cg, 0);
+        set(1, 3, 3 * cw, 0, cw, 0);
+        g.fix_d = (_alpha - alpha) * 3 * cw;                                     // ref :1304
+        g.fix_hi = _alpha * 3 * cw; g.fix_lo = alpha * 3 * cw;                   // ref :1309, :1316
+    } else if (LN == 8) {
+        g.dir_num = 16; g.tmod = 4; g.RL = 5; g.H = 4 * cw;
+        const double approach = dc - 4 * cw;                                     // ref :103-105
+        c.inbox[0] = 3.1415 / 2 * 5 * cw; c.inbox[1] = 8 * cw; c.inbox[2] = 3.1415 / 2 * cw;
+        for (int m = 0; m < 3; m++) c.spawn_p[m] = 0 + approach + c.inbox[m];
+        static const int8_t l2l[16][7] = {                                       // ref :107-124
+            {14, 4, 13, 12, 9, 10, 5}, {14, 13, 8, 4, 5, 6, 12}, {14, 13, 8, 4, 5, 6, 7}, {14, -1, -1, -1, -1, -1, -1},
+            {2, 8, 1, 0, 13, 14, 9},   {2, 1, 12, 8, 9, 10, 0},  {2, 1, 12, 8, 9, 10, 11}, {2, -1, -1, -1, -1, -1, -1},
+            {6, 12, 5, 4, 1, 2, 13},   {6, 5, 0, 12, 13, 14, 4}, {6, 5, 0, 12, 13, 14, 15}, {6, -1, -1, -1, -1, -1, -1},
+            {10, 0, 9, 8, 5, 6, 1},    {10, 9, 4, 0, 1, 2, 8},   {10, 9, 4, 0, 1, 2, 3},   {10, -1, -1, -1, -1, -1, -1}};
+        for (int d = 0; d < 16; d++) for (int k = 0; k < 7; k++) g.l2l[d][k] = l2l[d][k];
+        static const int8_t dir[8][3] = {{0, 1, -1}, {-1, 2, 3}, {4, 5, -1}, {-1, 6, 7},
+                                         {8, 9, -1}, {-1, 10, 11}, {12, 13, -1}, {-1, 14, 15}};   // ref :135-144
+        for (int i = 0; i < 8; i++) for (int k = 0; k < 3; k++) g.direction[i][k] = dir[i][k];
+        static const int8_t turn[4] = {2, 3, 0, 1};                              // lane pairs, ref :1062-1249
+        for (int i = 0; i < 8; i++) g.turn[i] = turn[i / 2];
+        const double s24 = sqrt(24.0);
+        set(0, 0, 8 * cw - s24 * cw, 0, atan(s24) * 5 * cw, 0);                  // ref :540-575
+        set(0, 1, atan(3.0 / 4) * 5 * cw, 0, atan(4.0 / 3) * 5 * cw, 0);
+        set(0, 2, 4 * cw, 0, atan(4.0 / 3) * 5 * cw, 0);
+        set(0, 3, atan(4.0 / 3) * 5 * cw, 0, atan(3.0 / 4) * 5 * cw, 0);
+        set(0, 4, 4 * cw, 0, atan(3.0 / 4) * 5 * cw, 0);
+        set(0, 5, s24 * cw, 0, atan(1 / s24) * 5 * cw, 0);
+        set(1, 0, 3 * cw, 0, 7 * cw, 0);                                         // ref :578-613
+        set(1, 1, 3 * cw, 0, 5 * cw, 0);
+        set(1, 2, atan(3.0 / 4) * 5 * cw, 0, 4 * cw, 0);
+        set(1, 3, atan(4.0 / 3) * 5 * cw, 0, 4 * cw, 0);
+        set(1, 4, 5 * cw, 0, 3 * cw, 0);
+        set(1, 5, 5 * cw, 0, cw, 0);
+        set(2, 0, cw, 0, 7 * cw, 0);                                             // ref :615-652
+        set(2, 1, cw, 0, 5 * cw, 0);
+        set(2, 2, atan(1 / s24) * 5 * cw, 0, s24 * cw, 0);
+        set(2, 3, atan(s24) * 5 * cw, 0, 8 * cw, s24 * cw);                      // abs(d) + 8cw - sqrt(24)cw, ref :634
+        set(2, 4, 7 * cw, 0, 3 * cw, 0);
+        set(2, 5, 7 * cw, 0, cw, 0);
+    } else {
+        g.dir_num = 12; g.tmod = 3; g.RL = 7; g.H = 6 * cw;
+        for (int d = 0; d < 12; d++) for (int k = 0; k < 4; k++) g.l2l[d][k] = c.l2l[d][k];
+        for (int i = 0; i < 12; i++) g.direction[i][i % 3] = (int8_t)i;          // ref :168-181
+        for (int m = 0; m < 2; m++) for (int k = 0; k < 4; k++) set(m, k, c.vdA[m][k], c.vdB[m][k], c.vdC[m][k], 0);
+    }
+    c.exit_p = -dc + (double)((LN + 1) / 2) * cw;                                // ref :341-342
+    for (int i = 0; i < LN; i++)
+        for (int m = 0; m < 3; m++)
+            if (g.direction[i][m] >= 0) { g.dir_lane[g.direction[i][m]] = (int8_t)i; g.dir_index[g.direction[i][m]] = (int8_t)m; }
+    return g;
+}
+
 inline std::string &last_error_ref()
 {
     static thread_local std::string e;
@@ -82,6 +181,12 @@ inline int fail(int code, const std::string &msg)
 
 struct pve_handle_s {
     pve::Const c;
+    pve::GeoConst g;                  // general-geometry path (lane_num 4 / 8, or 12 with PVE_CFG_GENERAL_PATH)
+    bool geo;
+    int lane_num;
+    const int32_t *choice;
+    long long choice_stride;
+    int choice_rows;
     pve_config cfg;
     int n_envs, cap, device;
     pve::Layout L;

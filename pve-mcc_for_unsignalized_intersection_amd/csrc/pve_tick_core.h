@@ -200,6 +200,7 @@ struct Regs {
     int hit, coll_seen, coll_fin;
     int alive, ctl, del, fin;
     int cyc;                         // dead-lock cycle membership: bit0 | len << 1 | rank << 5 | leader slot << 9
+    int intent, route, ord;          // general-geometry path only (intention, direction[lane][intention], processing order)
 };
 struct CRegs {                       // MODE_COMPACT moves every persistent field verbatim
     double p, v, a, jerk, jerk_sum, vir_dis, closer_p;
@@ -307,8 +308,10 @@ PVE_HD int slot_lane(const EnvHeader &hd, int t)
     return lane;
 }
 
-template <int CAP> struct Tick {
-    typedef Shared<CAP> Sh;
+// ShT: the LDS block the phases work on (Shared<CAP> for the 12-lane fast path; the general-geometry path of
+// pve_tick_geo.h re-uses the step / dead-lock / compaction phases on its own block with the same member names)
+template <int CAP, class ShT = Shared<CAP>> struct Tick {
+    typedef ShT Sh;
     static constexpr int NW = CAP / 64;
 
     // ============================================================== L: load
@@ -1021,7 +1024,7 @@ PVE_HD void reset_env(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, 
         int *z = (int *)&h;
         for (int w = 0; w < (int)(sizeof(EnvHeader) / 4); w++) z[w] = 0;
     }
-    for (int l = 0; l < NL; l++) { h.head_lane[l] = -1; h.head_j[l] = -1; }
+    for (int l = 0; l < ND; l++) { h.head_lane[l] = -1; h.head_j[l] = -1; }
     const double *arr = P.arrivals + (size_t)env * P.arr_env_stride;
     int n = 0;
     int lane_of[NL];

@@ -1,0 +1,568 @@
+// pve_tick_geo.h -- the environment tick for the 4- and 8-lane layouts (lane_num = 12 is
+// accepted too and must reproduce the fast path of pve_tick_core.h bit for bit -- the tests use that).
+//
+// What is different from the 12-lane layout (ref = traffic_interaction_scene.py):
+//   - a physical lane carries several movements: a vehicle has an `intention` (ref :382-394) and a route
+//     `direction[lane][intention]` (ref :88-93, :135-144); the virtual-lane lists are per ROUTE (12 or 16 of them),
+//     built from the vehicles of the same route, the vehicles of the same lane with another intention that have
+//     not reached the box yet (ref :250-257) and the routes of lane2lane[route] (<= 7, ref :74-87, :107-124);
+//   - scene_update walks lane -> intention -> j (ref :233-275): the processing order that decides collision
+//     visibility (ref :333-340), the reward[-1] overrides (ref :346, :357) and fresh/stale neighbour rows (ref :1332)
+//     is (lane, intention, j), not the slot order (lane, j);
+//   - 4-lane only: while the left-turn vehicles of one route are processed, the list entries of the opposing
+//     left-turn route are re-written by every one of them in turn (ref :1301-1319, stored back at ref :286-287);
+//   - step() tests the head of virtual_lane_4[LANE index] (ref :1517) and forces aM on lanes 2, 5, 8, 11 (ref :1519)
+//     whatever the layout: both quirks are part of the behaviour and are kept.
+//
+// Slots stay sorted by (lane, j); one workgroup = one intersection, thread t = slot t.  The step chain, the
+// dead-lock scan and the compaction are the phases of pve_tick_core.h (Tick<CAP, SharedGeo<CAP>>); the
+// neighbour search is a per-vehicle scan over the controlled vehicles (no sorted lists: this path is the
+// correctness-first one, the 12-lane fast path is where the optimisation work went).
+#pragma once
+#include "pve_tick_core.h"
+
+namespace pve {
+
+template <int CAP> struct SharedGeo {
+    static constexpr int NW = CAP / 64;
+    EnvHeader hd;
+    double p[CAP], v[CAP], a[CAP];
+    double p1[CAP], v1[CAP];
+    double virdis[CAP];
+    double red_reward[NW], red_jerk[NW];
+    double u_vd[CAP];                // dead-lock scratch: records by rank (ph_lock2)
+    double vdt[4][MAXK][4];          // get_virtual_distance table (GeoConst::vd)
+    double inbox[4];
+    int cnt[CAP];
+    int acc_passed_steps, acc_collisions, lead_n, emu_scan;
+    int16_t hdr[CAP], cyc_off[CAP], ord[CAP], slot_at[CAP];
+    uint8_t bb[CAP], rew_ovr[CAP], lane_of[CAP], route_of[CAP], intent_of[CAP], s_slot[CAP];
+    u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW], m_spawn[NW];
+    u64 m_int[3][NW];                // alive slots by intention
+    u64 m_ctl_ord[NW];               // "controlled" flags in processing order
+    int8_t pos[ND][ND];              // pos[d][route] = index of route in lane2lane[d], or -1
+    int8_t opp[ND];                  // lane2lane[d][1] (4-lane fix-up, ref :1303)
+};
+
+// XY position (ref :896-1249): every (lane, intention) branch of the reference is one of three canonical paths
+// (approach along +x below the axis) turned by a quarter-turn count; sign changes are exact.
+PVE_HD void geo_xy(const PVE_AS4 GeoConst &g, double p, int lane, int m, double &X, double &Y)
+{
+    if (g.lane_num == 12) { get_xy(g.base, p, lane, X, Y); return; }
+    const double cw = g.base.cw, H = g.H;
+    const double yo = (g.lane_num == 8 && (lane & 1)) ? 3 * cw : cw;
+    const double Lb = (m == 2) ? g.base.inbox[2] : g.base.inbox[0];
+    const double rl = (double)g.RL;
+    const bool before = p > Lb, inside = !before && p > 0;
+    double sn, cs;
+    sincos_q1((inside && m != 1) ? ((m == 0) ? p / (rl * cw) : p / cw) : 0.0, sn, cs);
+    double x, y;
+    if (m == 1) { x = -1 * p + H; y = -yo; }
+    else if (m == 0) {
+        const double dy = sn * rl * cw, dx = cs * rl * cw;
+        x = before ? -(p - Lb + H) : (inside ? (dx - H) : cw);
+        y = before ? -cw : (inside ? (H - dy) : (-1 * p + H));
+    } else {
+        const double dy = sn * cw, dx = cs * cw;
+        x = before ? -(p - Lb + H) : (inside ? -(H - dx) : -yo);
+        y = before ? -yo : (inside ? -(H - dy) : -(-1 * p + H));
+    }
+    const int q = g.turn[lane];
+    X = (q == 0) ? x : (q == 1) ? -y : (q == 2) ? -x : y;
+    Y = (q == 0) ? y : (q == 1) ? x : (q == 2) ? -y : -x;
+}
+
+template <int CAP> struct TickGeo {
+    typedef SharedGeo<CAP> Sh;
+    typedef Tick<CAP, Sh> Base;
+    static constexpr int NW = CAP / 64;
+
+    // ============================================================== L: load
+    static PVE_HD void ph_load(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        const EnvHeader &gh = P.headers[env];
+        {
+            const int *src = (const int *)&gh;
+            int *dst = (int *)&sh.hd;
+            for (int w = t + 2; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];
+        }
+        if (t == 0) sh.hd.current_time = gh.current_time + g.base.deltaT;       // ref :223
+        const int N = gh.n_alive;
+        const size_t gi = (size_t)env * CAP + t;
+        r.alive = t < N;
+        r.jerk = 0;
+        r.p = P.f64[F_P][gi]; r.v = P.f64[F_V][gi]; r.a = P.f64[F_A][gi];
+        r.jerk_sum = P.f64[F_JERK_SUM][gi]; r.vir_dis = P.f64[F_VIR_DIS][gi]; r.closer_p = P.f64[F_CLOSER_P][gi];
+        r.id = P.i32[I_ID][gi]; r.seq = P.i32[I_SEQ][gi]; r.vnum = P.i32[I_VNUM][gi];
+        r.step = P.i32[I_STEP][gi]; r.count = P.i32[I_COUNT][gi]; r.meta = P.i32[I_META][gi];
+        sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
+        if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
+        for (int w = t; w < 4 * MAXK * 4; w += CAP) (&sh.vdt[0][0][0])[w] = (&g.vd[0][0][0])[w];
+        if (t < 3) sh.inbox[t] = g.base.inbox[t];
+        for (int w = t; w < ND * ND; w += CAP) {
+            const int d = w / ND, rt = w - d * ND;
+            int k = -1;
+            for (int q = 0; q < MAXK; q++) if (g.l2l[d][q] == rt) k = q;
+            sh.pos[d][rt] = (int8_t)k;
+        }
+        if (t < ND) sh.opp[t] = g.l2l[t][1];
+    }
+
+    // ============================================================== S1..S3: step() -- the 12-lane phases; the head
+    // test indexes the lists by LANE number and lanes 2, 5, 8, 11 always get aM (ref :1517-1520), as there.
+    static PVE_HD void ph_step1(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        Base::ph_step1(g.base, P, env, t, sh, r);
+        r.intent = 0; r.route = 0;
+        if (r.alive) {
+            r.intent = (g.lane_num == 12) ? (r.lane % 3) : ((r.meta >> M_INT_SHIFT) & M_INT_MASK);
+            r.route = g.direction[r.lane][r.intent];
+            sh.route_of[t] = (uint8_t)r.route;
+            sh.intent_of[t] = (uint8_t)r.intent;
+        }
+        vote<NW>(sh.m_int[0], t, r.alive && r.intent == 0);
+        vote<NW>(sh.m_int[1], t, r.alive && r.intent == 1);
+        vote<NW>(sh.m_int[2], t, r.alive && r.intent == 2);
+    }
+    // processing order of scene_update: lane, then intention, then j (ref :233-275)
+    static PVE_HD void ph_order(int t, Sh &sh, Regs &r)
+    {
+        r.ord = t;
+        if (r.alive) {
+            const int ls = sh.hd.lane_start[r.lane], le = sh.hd.lane_start[r.lane + 1];
+            int o = ls;
+            for (int k = 0; k < 3; k++) {
+                if (k < r.intent) o += mask_below<NW>(sh.m_int[k], le) - mask_below<NW>(sh.m_int[k], ls);
+                else if (k == r.intent) o += mask_below<NW>(sh.m_int[k], t) - mask_below<NW>(sh.m_int[k], ls);
+            }
+            r.ord = o;
+            sh.ord[t] = (int16_t)o;
+            sh.slot_at[o] = (int16_t)t;
+        }
+    }
+    static PVE_HD void ph_order2(int t, Sh &sh)
+    {
+        const int N = sh.hd.n_alive;
+        vote<NW>(sh.m_ctl_ord, t, t < N && mask_test(sh.m_ctl, sh.slot_at[t < N ? t : 0]));
+    }
+
+    // ============================================================== membership of vehicle x in the list of route d
+    // (physical lane li, intention index m), ref :240-270.  vo = the entry's virtual distance at list build.
+    static PVE_HD bool member(const PVE_AS4 GeoConst &g, const Sh &sh, int d, int li, int m, int x, double &vo)
+    {
+        const int lx = sh.lane_of[x], rx = sh.route_of[x];
+        const double px = sh.p[x];
+        if (lx == li) {
+            if (rx == d) { vo = px; return true; }                                     // ref :246-249
+            const double q = px - sh.inbox[sh.intent_of[x]];                           // ref :251-252
+            if (q > 0) { vo = q + sh.inbox[m]; return true; }                          // ref :253-257
+            return false;
+        }
+        const int k = sh.pos[d][rx];                                                   // ref :258
+        if (k < 0) return false;
+        const double *e = sh.vdt[d % g.tmod][k];
+        const double delta = (px - e[0]) + e[1];                                       // ref :453-660 / :733-803
+        if (!(delta > 0)) return false;
+        vo = (delta + e[2]) - e[3];
+        return true;
+    }
+
+    // ============================================================== SCAN: list heads, predecessor, 6 nearest
+    static PVE_HD void ph_scan(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
+    {
+        r.reward = 0; r.hit = 0; r.hdr = -1;
+#pragma unroll
+        for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
+        // (a) thread d < dir_num: head of list d, persisted for next tick's step (ref :1517); lists are rebuilt only
+        //     when their physical lane holds a vehicle (ref :234), otherwise the old head stays (stale by design)
+        if (t < g.dir_num) {
+            const int d = t, li = g.dir_lane[d], m = g.dir_index[d];
+            if (sh.hd.lane_start[li + 1] > sh.hd.lane_start[li]) {
+                double best = INFINITY; int bs = -1;
+                for (int w = 0; w < NW; w++)
+                    for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
+                        const int x = w * 64 + __builtin_ctzll(bits);
+                        double vo;
+                        if (member(g, sh, d, li, m, x, vo) && vo < best) { best = vo; bs = x; }   // ties: lower slot stays
+                    }
+                if (bs >= 0) {
+                    lds_or(&sh.hd.head_valid, 1 << d);
+                    const int hl = sh.lane_of[bs];
+                    sh.hd.head_lane[d] = hl;
+                    sh.hd.head_j[d] = bs - sh.hd.lane_start[hl];
+                } else {
+                    lds_and(&sh.hd.head_valid, ~(1 << d));
+                }
+            }
+        }
+        if (!(r.alive && r.ctl)) return;
+        // (b) every controlled vehicle scans the members of its route's list
+        const int d = r.route, li = r.lane, m = r.intent;
+        const double me = r.p;                                   // own entry: vd = p, never adjusted
+        const bool fix = (g.lane_num == 4) && (d % 3 == 0);      // ref :1301
+        const int opp = sh.opp[d];
+        const int ls = sh.hd.lane_start[li], le = sh.hd.lane_start[li + 1];
+        double bvo = -INFINITY, bvc = 0; int bslot = -1;
+        double kd[NNB], ko[NNB], kc[NNB]; int ks[NNB];
+#pragma unroll
+        for (int k = 0; k < NNB; k++) { kd[k] = INFINITY; ko[k] = INFINITY; kc[k] = 0; ks[k] = -1; }
+        for (int w = 0; w < NW; w++)
+            for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
+                const int x = w * 64 + __builtin_ctzll(bits);
+                double vo;
+                if (x == t || !member(g, sh, d, li, m, x, vo)) continue;
+                double vc = vo;
+                if (fix && sh.route_of[x] == opp) {
+                    // 4-lane: the controlled vehicles of this route up to and including us have, one after the
+                    // other, re-written this entry (ref :1301-1319; the copy is stored back at ref :286-287)
+                    for (int w2 = 0; w2 < NW; w2++) {
+                        u64 eb = sh.m_ctl[w2] & sh.m_int[m][w2];
+                        for (; eb; eb &= eb - 1) {
+                            const int e = w2 * 64 + __builtin_ctzll(eb);
+                            if (e < ls || e >= le || e > t) continue;
+                            const double pe = sh.p[e];
+                            const double ori = vc + g.fix_d;                           // ref :1304
+                            if (pe < ori) {                                            // ref :1305-1312
+                                const double r2 = ori - g.fix_hi + g.fix_lo;
+                                vc = (r2 < pe) ? pe + 1 : r2;
+                            } else {                                                   // ref :1313-1319
+                                const double r2 = ori + g.fix_hi - g.fix_lo;
+                                vc = (r2 > pe) ? pe - 1 : r2;
+                            }
+                        }
+                    }
+                }
+                // predecessor in list order = stable sort by the build-time distance (ref :271, :1353)
+                const bool before = vo < me || (vo == me && x < t);
+                if (before && (vo > bvo || (vo == bvo && x > bslot))) { bvo = vo; bslot = x; bvc = vc; }
+                // 6 nearest: stable sort of the list by |vd - vd_self| on the current values (ref :1383-1397)
+                double cd = fabs(vc - me), co = vo, cc = vc; int cs = x;
+#pragma unroll
+                for (int k = 0; k < NNB; k++) {
+                    const bool sw = key_less(cd, co, cs, kd[k], ko[k], ks[k] < 0 ? 0x7fffffff : ks[k]);
+                    const double td = sw ? kd[k] : cd, to = sw ? ko[k] : co, tc = sw ? kc[k] : cc;
+                    const int ts = sw ? ks[k] : cs;
+                    kd[k] = sw ? cd : kd[k]; ko[k] = sw ? co : ko[k]; kc[k] = sw ? cc : kc[k]; ks[k] = sw ? cs : ks[k];
+                    cd = td; co = to; cc = tc; cs = ts;
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < NNB; k++) { r.kr[k] = ks[k]; r.kv[k] = (ks[k] >= 0) ? kc[k] : 0.0; }
+        r.hdr = bslot;                                                                  // ref :1348-1354
+        r.vir_dis = (bslot >= 0) ? (me - bvc) : 100.0;
+        sh.hdr[t] = (int16_t)bslot;
+        sh.virdis[t] = r.vir_dis;
+        r.count += 1;                                                                   // ref :292
+    }
+
+    // ============================================================== REWARD + XY collision test (ref :280-334)
+    static PVE_HD void ph_reward(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
+    {
+        if (!(r.alive && r.ctl)) return;
+        const PVE_AS4 Const &c = g.base;
+        const double ps = r.p;
+        double t_distance = 2, d_distance = 10;
+        const int n0 = r.kr[0];
+        if (n0 >= 0) {
+            const double vdn = r.kv[0];
+            d_distance = fabs(ps - vdn);
+            r.closer_p = vdn;
+            if (d_distance != 0) t_distance = (ps - vdn) / (r.v - sh.v[n0] + 0.0001);
+        } else {
+            r.closer_p = 150;
+        }
+        double r_ = 0;
+        if (0 < t_distance && t_distance < 4) r_ += 1 / tanh(-t_distance / 4.0);
+        {
+            double jd = r.jerk / c.deltaT;
+            r_ -= jd * jd / 3600.0 * 3.0;
+        }
+        if (d_distance < 10) {
+            double q1 = d_distance / 10, q2 = q1 * q1;
+            r_ += log(q2 * q2 * q1 + 0.00001);
+        }
+        r_ += (r.v - c.vm) / c.aM_minus_am * 2.0;
+        r_ = (r_ > -20) ? r_ : -20;
+        r.reward = (r_ < 20) ? r_ : 20;
+        r.jerk_sum += fabs(r.jerk / c.deltaT);
+        if (n0 >= 0) {
+            double ax, ay, bx, by;
+            geo_xy(g, ps, r.lane, r.intent, ax, ay);
+            geo_xy(g, sh.p[n0], sh.lane_of[n0], sh.intent_of[n0], bx, by);
+            const double dx = bx - ax, dy = by - ay;
+            const double dxy = sqrt(dx * dx + dy * dy);
+            if (fabs(dxy) < c.collision_thr) {
+                r.hit = 1;
+                lds_add(&sh.cnt[n0], (r.ord < sh.ord[n0]) ? 1 : (1 << 16));   // seen by n0 this tick iff we precede it
+            }
+        }
+    }
+
+    // ============================================================== FX: ordered effects (ref :333-359)
+    static PVE_HD void ph_effects(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
+    {
+        const PVE_AS4 Const &c = g.base;
+        r.del = 0; r.fin = 0; r.coll_seen = 0; r.coll_fin = 0;
+        if (r.alive) {
+            const int cc = sh.cnt[t];
+            const int prev = (r.meta >> M_COLL_SHIFT) & M_COLL_MASK;
+            r.coll_seen = prev + r.hit + (cc & 0xffff);
+            r.coll_fin = r.coll_seen + (cc >> 16);
+            if (r.ctl && r.coll_seen > 0) lds_add(&sh.acc_collisions, r.coll_seen);
+            if (r.p < c.exit_p || r.coll_seen > 0) {
+                r.del = 1;
+                if (r.coll_seen > 0) {
+                    if (r.ctl) r.reward = -10;
+                    else {                                     // reward[-1]: the controlled vehicle processed last before us
+                        const int po = mask_prev<NW>(sh.m_ctl_ord, r.ord);
+                        if (po >= 0) sh.rew_ovr[sh.slot_at[po]] = 1;
+                    }
+                }
+                r.meta |= M_DONE;
+                r.hdr = -1; sh.hdr[t] = -1;
+            } else if (r.p < 0 && (r.meta & M_CONTROL)) {
+                r.fin = 1;
+                r.meta |= M_DONE | M_FINISH;
+                r.meta &= ~(M_CONTROL | M_LOCK);
+                r.hdr = -1; sh.hdr[t] = -1;
+                r.reward = 5;
+                lds_add(&sh.acc_passed_steps, r.step);
+            }
+        }
+        vote<NW>(sh.m_del, t, r.del);
+        vote<NW>(sh.m_fin, t, r.fin);
+        vote<NW>(sh.m_ctlnow, t, r.alive && !r.del && (r.meta & M_CONTROL));
+        vote<NW>(sh.m_coll, t, r.alive && r.ctl && r.coll_seen > 0);
+        vote<NW>(sh.m_spawn, t, t < g.lane_num && sh.hd.current_time >= sh.hd.next_arr[t < NL ? t : 0]);   // ref :379
+    }
+
+    // ============================================================== FIN: re-pack + spawn + write-back
+    static PVE_HD int pack_lanej(const Sh &sh, int slot) { return Base::pack_lanej(sh, slot); }
+
+    static PVE_HD void ph_final(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        const PVE_AS4 Const &c = g.base;
+        EnvHeader &gh = P.headers[env];
+        const int N = sh.hd.n_alive;
+        const int LN = g.lane_num;
+        const size_t gpre = (size_t)env * CAP + t;
+        const bool fused = (P.mode == MODE_FUSED);
+        const unsigned want = (unsigned)(sh.m_spawn[0] & 0xFFFull);
+        unsigned sp = 0; int room = CAP - N;
+#pragma unroll
+        for (int l = 0; l < NL; l++) if ((want >> l) & 1) { if (room > 0) { sp |= 1u << l; room--; } }
+        const int n_over = __builtin_popcount(want) - __builtin_popcount(sp);
+        u64 keep[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) keep[k] = fused ? (sh.m_alive[k] & ~sh.m_del[k]) : sh.m_alive[k];
+        int meta = 0, hdr_word = -1, new_slot = -1, lockf = 0;
+        if (r.alive) {
+            int coll = r.coll_fin > M_COLL_MASK ? M_COLL_MASK : r.coll_fin;
+            meta = (r.meta & (M_CONTROL | M_FINISH | M_DONE | (M_INT_MASK << M_INT_SHIFT))) | M_ALIVE | (coll << M_COLL_SHIFT);
+            if (r.cyc & 1) {                                                           // ref :1493-1497
+                const int len = (r.cyc >> 1) & 15, off = sh.cyc_off[r.cyc >> 9];
+                double sum = 0;
+#pragma unroll
+                for (int q = 0; q < 10; q++) if (q < len) sum = sum + sh.u_vd[off + q];
+                const int best_o = sh.s_slot[off];
+                meta |= M_LOCK;
+                lockf = 1;
+                if (sh.u_vd[off] < c.collision_thr || sum / (double)len < c.lock_mean_thr) {
+                    if (best_o == t) meta |= M_LOCKA_POS;
+                    else if (sh.hdr[best_o] == t) meta |= M_LOCKA_NEG;
+                }
+            }
+            if (r.del) meta |= M_DEL;
+            hdr_word = pack_lanej(sh, r.hdr);
+            if (mask_test(keep, t)) {
+                new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
+                Base::store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word);
+            }
+        }
+        const int n_post = mask_below<NW>(keep, sh.hd.lane_start[NL]) + __builtin_popcount(sp);
+        if (t <= NL) gh.lane_start[t] = mask_below<NW>(keep, sh.hd.lane_start[t]) + __builtin_popcount(sp & ((1u << t) - 1u));
+        // ---- spawned vehicles (one per lane at most), ref :378-433
+        if (t < LN && ((sp >> t) & 1)) {
+            const int nth = __builtin_popcount(sp & ((1u << t) - 1u));               // spawns of lower lanes come first
+            const int slot = mask_below<NW>(keep, sh.hd.lane_start[t + 1]) + nth;
+            int intention;
+            if (LN == 4) intention = (sh.hd.intention_re + nth) % 3;                   // ref :385-388
+            else if (LN == 8) {                                                        // ref :389-392, draws as input
+                const int ch = P.choice ? P.choice[(size_t)env * P.choice_env_stride + (size_t)sh.hd.veh_rec[t] * LN + t] : 0;
+                intention = (t & 1) ? (ch ? 2 : 1) : (ch ? 1 : 0);                     // ref :125-134
+            } else intention = t % 3;                                                  // ref :393-394
+            Regs nv;
+            nv.p = c.spawn_p[intention]; nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
+            nv.vir_dis = 100; nv.closer_p = 150;
+            nv.id = sh.hd.id_seq + nth;
+            nv.seq = sh.hd.veh_rec[t];
+            nv.vnum = sh.hd.lane_start[t + 1] - sh.hd.lane_start[t];
+            nv.step = 0; nv.count = 0;
+            Base::store_slot(P, (size_t)env * CAP + slot, nv,
+                             M_CONTROL | M_ALIVE | (LN == 12 ? 0 : (intention << M_INT_SHIFT)), -1);   // 12-lane: lane % 3, not stored
+            if (P.out.obs_post) {
+                double *o = P.out.obs_post + ((size_t)env * CAP + slot) * OBSW;
+                for (int k = 0; k < OBSW; k++) o[k] = 0.0;                             // ref :380, :420
+            }
+            const int rec1 = sh.hd.veh_rec[t] + 1;
+            gh.veh_rec[t] = rec1;
+            gh.next_arr[t] = (rec1 < P.rows) ? P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec1 * LN + t] : INFINITY;
+        }
+        if (t >= n_post) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
+        if (t < ND) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
+        const int n_ctl = mask_count<NW>(sh.m_ctl);
+        const int n_lock = mask_count<NW>(sh.m_lead);
+        const int n_fin = mask_count<NW>(sh.m_fin);
+        const int n_del = mask_count<NW>(sh.m_del);
+        if (t == 0) {
+            double sr = 0, sj = 0;
+#if PVE_DEVICE_CODE
+            for (int k = 0; k < NW; k++) { sr += sh.red_reward[k]; sj += sh.red_jerk[k]; }
+#else
+            sr = sh.red_reward[0]; sj = sh.red_jerk[0];
+#endif
+            gh.current_time = sh.hd.current_time;
+            gh.n_alive = n_post;
+            gh.id_seq = sh.hd.id_seq + __builtin_popcount(sp);
+            if (LN != 12) gh.intention_re = sh.hd.intention_re + __builtin_popcount(sp);   // ref :388, :392
+            gh.passed = sh.hd.passed + n_fin;
+            gh.passed_step_total = sh.hd.passed_step_total + sh.acc_passed_steps;
+            gh.head_valid = sh.hd.head_valid;
+            gh.sum_reward = sh.hd.sum_reward + sr;
+            gh.sum_jerk = sh.hd.sum_jerk + sj;
+            gh.alive_steps = sh.hd.alive_steps + N;
+            gh.ctl_steps = sh.hd.ctl_steps + n_ctl;
+            gh.ticks = sh.hd.ticks + 1;
+            gh.collided = sh.hd.collided + mask_count<NW>(sh.m_coll);
+            gh.locks = sh.hd.locks + n_lock;
+            gh.overflow = sh.hd.overflow + n_over;
+            if (P.out.env_out) {
+                int *eo = P.out.env_out + (size_t)env * 8;
+                eo[0] = N; eo[1] = n_ctl; eo[2] = sh.acc_collisions;
+                eo[3] = n_lock; eo[4] = n_del; eo[5] = n_fin; eo[6] = __builtin_popcount(sp); eo[7] = n_post;
+            }
+        }
+        if (P.out.flags) {
+            int f = 0;
+            if (r.alive) {
+                f = 0x01 | (r.ctl ? 0x02 : 0) | ((r.meta & M_DONE) ? 0x04 : 0) | (r.del ? 0x08 : 0) |
+                    (r.fin ? 0x10 : 0) | (lockf ? 0x20 : 0) | (r.intent << 6) | (r.ctl ? (r.coll_seen << 8) : 0);
+            }
+            P.out.flags[gpre] = f;
+        }
+        if (P.out.reward) P.out.reward[gpre] = (r.alive && r.ctl) ? r.reward : 0.0;
+        if (P.out.lanej) P.out.lanej[gpre] = r.alive ? ((r.lane << 16) | r.j) : -1;
+        if (P.out.new_slot) P.out.new_slot[gpre] = new_slot;
+        if (P.out.nbr) {
+            int *nb = P.out.nbr + gpre * NNB;
+#pragma unroll
+            for (int k = 0; k < NNB; k++) nb[k] = (r.alive && r.ctl) ? pack_lanej(sh, r.kr[k]) : -1;
+        }
+        if (r.alive && r.ctl && (P.out.obs_pre || (P.out.obs_post && new_slot >= 0))) {
+            double row[OBSW];                                                          // ref :1325-1337
+            row[0] = r.p; row[1] = r.v; row[2] = r.a; row[3] = (double)r.route;
+#pragma unroll
+            for (int k = 0; k < NNB; k++) {
+                const int x = r.kr[k];
+                if (x >= 0) {
+                    row[4 + 4 * k] = r.kv[k]; row[5 + 4 * k] = sh.v[x]; row[6 + 4 * k] = sh.a[x];
+                    row[7 + 4 * k] = (double)sh.route_of[x];
+                } else {
+                    row[4 + 4 * k] = 0; row[5 + 4 * k] = 0; row[6 + 4 * k] = 0; row[7 + 4 * k] = 0;
+                }
+            }
+            if (P.out.obs_pre) {
+                double *o = P.out.obs_pre + gpre * OBSW;
+#pragma unroll
+                for (int k = 0; k < OBSW; k++) o[k] = row[k];
+            }
+            if (P.out.obs_post && new_slot >= 0) {
+                double *o = P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+#pragma unroll
+                for (int k = 0; k < OBSW; k++) o[k] = row[k];
+            }
+        }
+    }
+
+    // ============================================================== STATE: 7x28; a neighbour's row is this tick's
+    // if it was processed before us (order, not slot), else the row it stored last tick (ref :1332)
+    static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        if (!P.out.state_pre || !(r.alive && r.ctl)) return;
+        const size_t base = (size_t)env * CAP;
+        double *dst = P.out.state_pre + (base + t) * (size_t)((NNB + 1) * OBSW);
+        const double *own = P.out.obs_pre + (base + t) * OBSW;
+        for (int k = 0; k < OBSW; k++) dst[k] = own[k];
+        for (int q = 0; q < NNB; q++) {
+            const int x = r.kr[q];
+            double *row = dst + (q + 1) * OBSW;
+            if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = 0.0; continue; }
+            const double *src = (sh.ord[x] < r.ord) ? (P.out.obs_pre + (base + x) * OBSW)
+                                                    : (P.out.obs_prev_post + (base + x) * OBSW);
+            for (int k = 0; k < OBSW; k++) row[k] = src[k];
+        }
+    }
+};
+
+// ================================================================== reset / warm-up, ref :196-220
+template <int CAP>
+PVE_HD void reset_env_geo(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int cap_ticks)
+{
+    const PVE_AS4 Const &c = g.base;
+    const int LN = g.lane_num;
+    EnvHeader h;
+    {
+        int *z = (int *)&h;
+        for (int w = 0; w < (int)(sizeof(EnvHeader) / 4); w++) z[w] = 0;
+    }
+    for (int l = 0; l < ND; l++) { h.head_lane[l] = -1; h.head_j[l] = -1; }
+    const double *arr = P.arrivals + (size_t)env * P.arr_env_stride;
+    int n = 0;
+    int lane_of[NL], int_of[NL];
+    for (int it = 0; it < cap_ticks && n == 0; it++) {
+        h.current_time += c.deltaT;
+        for (int l = 0; l < LN; l++) {
+            if (h.veh_rec[l] < P.rows && h.current_time >= arr[(size_t)h.veh_rec[l] * LN + l] && n < CAP) {
+                int intention;
+                if (LN == 4) { intention = h.intention_re % 3; h.intention_re += 1; }
+                else if (LN == 8) {
+                    const int ch = P.choice ? P.choice[(size_t)env * P.choice_env_stride + (size_t)h.veh_rec[l] * LN + l] : 0;
+                    intention = (l & 1) ? (ch ? 2 : 1) : (ch ? 1 : 0);
+                    h.intention_re += 1;
+                } else intention = l % 3;
+                lane_of[n] = l; int_of[n] = intention;
+                n++;
+                h.veh_rec[l] += 1;
+            }
+        }
+    }
+    for (int s = 0; s < CAP; s++) {
+        size_t gi = (size_t)env * CAP + s;
+        if (s < n) {
+            P.f64[F_P][gi] = c.spawn_p[int_of[s]]; P.f64[F_V][gi] = c.v0; P.f64[F_A][gi] = 0; P.f64[F_JERK][gi] = 0;
+            P.f64[F_JERK_SUM][gi] = 0; P.f64[F_VIR_DIS][gi] = 100; P.f64[F_CLOSER_P][gi] = 150;
+            P.i32[I_ID][gi] = s; P.i32[I_SEQ][gi] = 0; P.i32[I_VNUM][gi] = 0; P.i32[I_STEP][gi] = 0;
+            P.i32[I_COUNT][gi] = 0; P.i32[I_HDR][gi] = -1;
+            P.i32[I_META][gi] = M_CONTROL | M_ALIVE | (LN == 12 ? 0 : (int_of[s] << M_INT_SHIFT));
+        } else {
+            P.f64[F_P][gi] = 0; P.f64[F_V][gi] = 0; P.f64[F_A][gi] = 0; P.f64[F_JERK][gi] = 0;
+            P.f64[F_JERK_SUM][gi] = 0; P.f64[F_VIR_DIS][gi] = 0; P.f64[F_CLOSER_P][gi] = 0;
+            P.i32[I_ID][gi] = -1; P.i32[I_SEQ][gi] = 0; P.i32[I_VNUM][gi] = 0; P.i32[I_STEP][gi] = 0;
+            P.i32[I_COUNT][gi] = 0; P.i32[I_META][gi] = 0; P.i32[I_HDR][gi] = -1;
+        }
+    }
+    {
+        int s = 0;
+        for (int l = 0; l <= NL; l++) {
+            h.lane_start[l] = s;
+            while (s < n && l < NL && lane_of[s] == l) s++;
+        }
+    }
+    for (int l = 0; l < NL; l++)
+        h.next_arr[l] = (l < LN && h.veh_rec[l] < P.rows) ? arr[(size_t)h.veh_rec[l] * LN + l] : INFINITY;
+    h.n_alive = n;
+    h.id_seq = n;
+    P.headers[env] = h;
+}
+
+}  // namespace pve

@@ -13,7 +13,9 @@
 
 namespace pve {
 
-constexpr int NL = 12;        // lanes (12-lane geometry only, ref :146-186)
+constexpr int NL = 12;        // physical lanes: 12 (fast path), or 4 / 8 padded to 12 (general-geometry path)
+constexpr int ND = 16;        // virtual-lane lists = routes: 12 (4- and 12-lane), 16 (8-lane) (ref :86, :132, :167)
+constexpr int MAXK = 8;       // longest lane2lane row is 7 (ref :74-87, :107-124), padded
 constexpr int OBSW = 28;      // observation row width, ref :1295
 constexpr int NNB = 6;        // neighbours, ref :1324
 
@@ -23,6 +25,7 @@ constexpr int M_LOCKA_POS = 0x10, M_LOCKA_NEG = 0x20;   // lock_a = +1 / -1 (ref
 constexpr int M_DEL = 0x40;                             // in delete_veh, awaiting delete_vehicle() (ref :348)
 constexpr int M_ALIVE = 0x80;
 constexpr int M_COLL_SHIFT = 8, M_COLL_MASK = 0xFFFF;   // veh["collision"] (ref :333-334)
+constexpr int M_INT_SHIFT = 24, M_INT_MASK = 0x3;       // veh["intention"] (ref :382-394); 12-lane: lane % 3, not stored
 
 // launch modes
 constexpr int MODE_FUSED = 0;     // step* + scene_update + delete_vehicle
@@ -62,14 +65,29 @@ struct EnvHeader {
     int32_t veh_rec[NL];           // arrival cursors (ref :207)
     int32_t id_seq, passed, passed_step_total;   // ref :212, 197, 198
     int32_t head_valid;            // bit d: len(virtual_lane_4[d]) > 0 at its last rebuild (ref :1517)
-    int32_t head_lane[NL], head_j[NL];           // virtual_lane_4[d][0][1:3] (stale by design); dwords -> scalar loads
+    int32_t head_lane[ND], head_j[ND];           // virtual_lane_4[d][0][1:3] (stale by design); dwords -> scalar loads
     int32_t collided, locks, overflow;
-    int32_t pad_;
+    int32_t intention_re;          // 4-/8-lane spawn counter (ref :387-388, :392)
 };
 
 // Persistent per-slot SoA field indices
 enum { F_P = 0, F_V, F_A, F_JERK, F_JERK_SUM, F_VIR_DIS, F_CLOSER_P, NF64 };
 enum { I_ID = 0, I_SEQ, I_VNUM, I_STEP, I_COUNT, I_META, I_HDR, NI32 };
+
+// General geometry (lane_num 4 / 8, and 12 for cross-checks): everything the 4-/8-lane branches of the reference
+// derive in the constructor (ref :66-145), get_virtual_distance (ref :453-660) and get_p (ref :896-1249).
+struct GeoConst {
+    Const base;                    // scalars; inbox / spawn_p / exit_p are those of this lane_num
+    int32_t lane_num, dir_num, tmod, RL;   // tmod: routes of the same type are d % tmod apart; RL: left radius / cw
+    double H;                      // half box width: 2cw (4-lane), 4cw (8-lane)
+    double fix_d, fix_hi, fix_lo;  // 4-lane far-conflict fix-up (ref :1304-1318): (_alpha-alpha)*3*cw, _alpha*3*cw, alpha*3*cw
+    double vd[4][MAXK][4];         // [route type][k] = A, B, C, C2:  delta = (p1 - A) + B ; vd = (delta + C) - C2
+    int8_t l2l[ND][MAXK];          // lane2lane rows, -1 padded
+    int8_t direction[NL][4];       // direction[lane][intention], -1 = none (ref :88-93, :135-144, :168-181)
+    int8_t dir_lane[ND], dir_index[ND];    // inverse of direction
+    int8_t turn[NL];               // get_p: quarter turns of the canonical path (ref :896-1249)
+    int8_t pad_[4];
+};
 
 struct Outputs {        // mirrors pve_outputs (include/pve_env.h)
     double *obs_post, *obs_pre, *state_pre;
@@ -89,6 +107,8 @@ struct Params {
     int32_t n_envs;
     int32_t mode;
     int32_t mask_uncontrolled;   // 1: actions of uncontrolled slots are forced to 0 (main.py:401)
+    const int32_t *choice;       // 8-lane: the randint(0,1) draws of ref :390, [rows][lane_num] per env, or null (all 0)
+    long long choice_env_stride; // int32 elements between envs (0 = shared)
     unsigned long long *phase_cycles;   // diagnostics: 16 counters of wave-cycles per phase, or null
     Outputs out;
 };

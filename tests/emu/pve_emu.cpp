@@ -12,6 +12,7 @@
 
 #include "../../pve-mcc_for_unsignalized_intersection_amd/csrc/pve_host.h"
 #include "../../pve-mcc_for_unsignalized_intersection_amd/csrc/pve_tick_core.h"
+#include "../../pve-mcc_for_unsignalized_intersection_amd/csrc/pve_tick_geo.h"
 #include "../../pve-mcc_for_unsignalized_intersection_amd/csrc/pve_actor.h"
 
 using namespace pve;
@@ -45,6 +46,34 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
     delete shp;
 }
 
+template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
+{
+    typedef TickGeo<CAP> T;
+    typedef Tick<CAP, SharedGeo<CAP>> B;
+    std::vector<Regs> regs(CAP);
+    SharedGeo<CAP> *shp = new SharedGeo<CAP>();
+    for (int env = 0; env < P.n_envs; env++) {
+        SharedGeo<CAP> &sh = *shp;
+        memset(&sh, 0, sizeof(sh));
+        for (int t = 0; t < CAP; t++) T::ph_load(g, P, env, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_step1(g, P, env, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) B::ph_step2(g.base, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_order(t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) B::ph_step3(g.base, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) B::ph_step3_publish(t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_order2(t, sh);
+        for (int t = 0; t < CAP; t++) T::ph_scan(g, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_reward(g, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_effects(g, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) B::ph_lock(g.base, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) B::ph_lock2(t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_final(g, P, env, t, sh, regs[t]);
+        if (P.out.state_pre)
+            for (int t = 0; t < CAP; t++) T::ph_state(P, env, t, sh, regs[t]);
+    }
+    delete shp;
+}
+
 template <int CAP> static void emu_compact(const Params &P)
 {
     std::vector<CRegs> regs(CAP);
@@ -72,6 +101,18 @@ struct Backend {
     static int launch_compact(const Params &P, int cap, void *, std::string &)
     {
         if (cap == 64) emu_compact<64>(P); else emu_compact<128>(P);
+        return 0;
+    }
+    static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *, std::string &)
+    {
+        if (cap == 64) emu_tick_geo<64>(g, P); else emu_tick_geo<128>(g, P);
+        return 0;
+    }
+    static int launch_reset_geo(const GeoConst &g, const Params &P, int cap, void *, std::string &)
+    {
+        for (int env = 0; env < P.n_envs; env++) {
+            if (cap == 64) reset_env_geo<64>(g, P, env, 200000); else reset_env_geo<128>(g, P, env, 200000);
+        }
         return 0;
     }
     // plain float32 loop with the same layer order / epsilon as csrc/pve_actor.h (host-logic tests only)

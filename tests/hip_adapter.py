@@ -25,11 +25,12 @@ def emulator_lib():
     return _emu
 
 
-def make_batch(arrivals, n_envs=1, capacity=128, backend="emu", outputs=ALL_OUTPUTS, **cfg):
+def make_batch(arrivals, n_envs=1, capacity=128, backend="emu", outputs=ALL_OUTPUTS, intentions=None, **cfg):
     if backend == "emu":
         return BatchedIntersections(n_envs, capacity, arrivals, device="cpu", outputs=outputs,
-                                    _lib=emulator_lib(), **cfg)
-    return BatchedIntersections(n_envs, capacity, arrivals, device="cuda", outputs=outputs, **cfg)
+                                    intentions=intentions, _lib=emulator_lib(), **cfg)
+    return BatchedIntersections(n_envs, capacity, arrivals, device="cuda", outputs=outputs,
+                                intentions=intentions, **cfg)
 
 
 def _np(t):
@@ -48,6 +49,7 @@ def state_snapshot(b, env):
     n = info.n_alive
     counts = list(info.lane_count)
     lane = np.repeat(np.arange(12), counts).astype(np.int32)
+    b._last_lane = lane
     j = np.concatenate([np.arange(c) for c in counts]).astype(np.int32) if n else np.zeros(0, np.int32)
     f = {k: _np(b.state_field(k)[env, :n]) for k in ("p", "v", "a", "jerk", "jerk_sum", "vir_dis", "closer_p")}
     i = {k: _np(b.state_field(k)[env, :n]) for k in ("id", "seq", "vnum", "step", "count", "meta", "hdr")}
@@ -101,8 +103,11 @@ class SplitEnv:
         eo = _np(out["env_out"][e])
         n_pre = int(eo[0])
         flags = _np(out["flags"][e, :n_pre]).astype(np.int64)
-        ctl = (flags & _capi.F_CTL) != 0
         lanej = decode_lanej(_np(out["lanej"][e, :n_pre]))
+        # `ids` order of scene_update = (lane, intention, j) (ref :233-275); == slot order for lane_num 12
+        intent_pre = (flags >> _capi.F_INTENT_SHIFT) & 3
+        order = np.lexsort((lanej[:, 1], intent_pre, lanej[:, 0])) if n_pre else np.zeros(0, np.int64)
+        ctl = order[((flags & _capi.F_CTL) != 0)[order]]            # controlled slots in processing order
         rec = dict(tick=self.tick_no)
         rec["ids"] = lanej[ctl]
         rec["nbr"] = decode_lanej(_np(out["nbr"][e, :n_pre]))[ctl].reshape(-1, 6, 2)
@@ -118,16 +123,20 @@ class SplitEnv:
         rec["coll_pv"] = (flags[ctl] >> 8).astype(np.int32)
         rec["collisions"] = int(eo[2])
         rec["lock"] = int(eo[3])
-        rec["deleted"] = lanej[(flags & _capi.F_DELETED) != 0]
+        rec["deleted"] = lanej[order[((flags & _capi.F_DELETED) != 0)[order]]]
         info, veh_i, veh_f = state_snapshot(b, e)
         new_slot = _np(out["new_slot"][e, :n_pre])
-        fin = (flags & _capi.F_FINISHED) != 0
-        rec["jerks"] = veh_f[new_slot[fin], 4].astype(np.float64) if fin.any() else np.zeros(0)
+        fin = order[((flags & _capi.F_FINISHED) != 0)[order]]
+        rec["jerks"] = veh_f[new_slot[fin], 4].astype(np.float64) if len(fin) else np.zeros(0)
         rec["veh_i"], rec["veh_f"] = veh_i, veh_f
         rec["time"] = float(info.current_time)
         rec["id_seq"], rec["passed"], rec["passed_step_total"] = info.id_seq, info.passed_veh, info.passed_veh_step_total
-        rec["veh_num"] = np.array(list(info.lane_count), np.int32)
-        rec["veh_rec"] = np.array(list(info.veh_rec), np.int32)
+        nl, nd = b.lane_num, b.dir_num
+        rec["veh_num"] = np.array(list(info.lane_count), np.int32)[:nl]
+        rec["veh_rec"] = np.array(list(info.veh_rec), np.int32)[:nl]
         rec["heads"] = np.stack([np.array(list(info.head_valid)), np.array(list(info.head_lane)),
-                                 np.array(list(info.head_j))], axis=1).astype(np.int32)
+                                 np.array(list(info.head_j))], axis=1).astype(np.int32)[:nd]
+        vs = b.read_vehicles(e)
+        rec["intent"] = np.array([[v.intention, v.route] for v in vs], np.int32).reshape(len(vs), 2)
+        rec["intention_re"] = int(info.intention_re)
         return rec

@@ -43,10 +43,11 @@ def batches_equal(b1, b2, what):
         assert np.array_equal(_np(b1.obs[e, :n])[ctl], _np(b2.obs[e, :n])[ctl]), "%s: env %d obs differs" % (what, e)
 
 
-def check_fused_equals_split(case, backend, ticks, capacity=128):
+def check_fused_equals_split(case, backend, ticks, capacity=128, mk=None):
     """pve_step_all == pve_scene_update + pve_compact, bit for bit (same kernels, one launch)."""
-    bs = make_batch(case.arrive, 1, capacity, backend, **case.ctor)
-    bf = make_batch(case.arrive, 1, capacity, backend, **case.ctor)
+    if mk is None:
+        mk = lambda: make_batch(case.arrive, 1, capacity, backend, **case.ctor)   # noqa: E731
+    bs, bf = mk(), mk()
     bs.reset(); bf.reset()
     batches_equal(bs, bf, "after reset")
     for t in range(min(ticks, case.ticks)):
@@ -211,3 +212,121 @@ def check_reset_reproducible(backend):
     assert np.array_equal(r1, r2) and m1 == m2
     for k in s1:
         assert np.array_equal(s1[k], s2[k]), k
+
+
+# ---------------------------------------------------------------- general geometry
+def make_geo_batch(case, backend, capacity=128, n_envs=1, **kw):
+    cfg = dict(case.ctor)
+    cfg.update(kw)
+    return make_batch(case.arrive, n_envs, capacity, backend, lane_num=case.lane_num,
+                      intentions=case.choice if case.lane_num == 8 else None, **cfg)
+
+
+def check_geo_golden(case, backend, ticks=None, capacity=128, want_state=True, **kw):
+    """Split protocol on the general-geometry kernel vs the golden vectors of the live reference (digest every
+    tick, every field on the dense ticks, the 7x28 state on the state ticks)."""
+    from tests.parity_util import replay_case
+    b = make_geo_batch(case, backend, capacity, **kw)
+    env = SplitEnv(b)
+    n = replay_case(case, env, ticks=ticks, ftol=1e-9, dtol=1e-9, want_state=want_state)
+    assert b.metrics()["overflow"] == 0
+    return n
+
+
+def check_geo_vs_oracle(case, backend, ticks, capacity=128, tol=1e-9):
+    """Every tick, every field (incl. the full state) against the sequential general-geometry oracle."""
+    from oracle.oracle_geo import OracleGeoEnv
+    orc = OracleGeoEnv(case.arrive, case.lane_num, choice=case.choice, **case.ctor)
+    b = make_geo_batch(case, backend, capacity)
+    env = SplitEnv(b)
+    for t in range(min(ticks, case.ticks)):
+        va, ca, oa = orc.alive_view()
+        vb, cb, ob = env.alive_view()
+        assert np.array_equal(va, vb) and np.array_equal(ca, cb), "alive set differs at tick %d" % t
+        assert close(np.where(ca[:, None] != 0, oa, 0), ob, tol), "stored observation differs at tick %d" % t
+        acts = case.policy(t, va, ca, oa)
+        ra, rb = orc.tick(acts, want_state=True), env.tick(acts, want_state=True)
+        compare_records(ra, rb, tol=tol, label=case.name)
+        assert np.array_equal(ra["intent"], rb["intent"]), "intent differs at tick %d" % t
+        assert ra["intention_re"] == rb["intention_re"]
+    assert b.metrics()["overflow"] == 0
+
+
+def check_geo_fused_equals_split(case, backend, ticks, capacity=128):
+    check_fused_equals_split(case, backend, ticks, capacity, mk=lambda: make_geo_batch(case, backend, capacity))
+
+
+def check_general_path_equals_fast_path(backend, n_envs=6, capacity=128, ticks=300, rate=1100.0, seed=21):
+    """lane_num = 12 through the general-geometry kernel == the optimised 12-lane kernel, bit for bit, on random
+    action tapes (state, headers, observations and every per-tick output)."""
+    rng = np.random.default_rng(seed)
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed)
+    outs = ("obs_post", "obs_pre", "reward", "flags", "nbr", "env_out", "new_slot", "lanej")
+    bf = make_batch(arr, n_envs, capacity, backend, outputs=outs)
+    bg = make_batch(arr, n_envs, capacity, backend, outputs=outs, general_path=True)
+    bf.reset(); bg.reset()
+    batches_equal(bf, bg, "after reset")
+    for t in range(ticks):
+        acts = rng.uniform(-3, 3, size=(n_envs, capacity)).astype(np.float32).astype(np.float64)
+        a = torch.as_tensor(acts).to(bf.device)
+        o1, o2 = bf.step(a), bg.step(a)
+        for k in ("reward", "flags", "lanej", "nbr", "env_out", "new_slot"):
+            x, y = _np(o1[k]), _np(o2[k])
+            if k == "flags":
+                y = y & ~(3 << 6)             # the general path also reports the intention (lane % 3)
+            assert np.array_equal(x, y), "tick %d: output %s differs between the fast and the general path" % (t, k)
+        c = (_np(o1["flags"]) & 2) != 0
+        assert np.array_equal(_np(o1["obs_pre"])[c], _np(o2["obs_pre"])[c]), "tick %d: obs_pre differs" % t
+        if t % 25 == 0 or t == ticks - 1:
+            batches_equal(bf, bg, "tick %d" % t)
+
+
+def check_geo_fuzz_vs_oracle(backend, lane_num, n_envs, capacity, ticks, rate, seed, action_scale=3.0, quantize=None):
+    """Random action tapes on a batch of 4- or 8-lane envs (own arrival + intention streams), fused ticks, every env
+    against its own sequential oracle every tick: processing order, controlled set, neighbours, rewards,
+    observations, collision counters, lock counts; full persistent state at the end."""
+    from oracle.oracle_geo import OracleGeoEnv
+    from pve_mcc_amd.arrivals import synthetic_intentions
+    rng = np.random.default_rng(seed)
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed, lane_num=lane_num)
+    ch = synthetic_intentions(n_envs, arr.shape[1], seed=seed, lane_num=lane_num) if lane_num == 8 else None
+    b = make_batch(arr, n_envs, capacity, backend, lane_num=lane_num, intentions=ch,
+                   outputs=("obs_post", "obs_pre", "reward", "flags", "nbr", "env_out", "new_slot", "lanej"))
+    b.reset()
+    oracles = [OracleGeoEnv(arr[e], lane_num, choice=None if ch is None else ch[e]) for e in range(n_envs)]
+    tot_coll = tot_lock = 0
+    for t in range(ticks):
+        acts = rng.uniform(-action_scale, action_scale, size=(n_envs, capacity)).astype(np.float32).astype(np.float64)
+        if quantize:
+            acts = np.round(acts / quantize) * quantize
+        out = b.step(torch.as_tensor(acts).to(b.device))
+        rew, flags, eo = _np(out["reward"]), _np(out["flags"]).astype(np.int64), _np(out["env_out"])
+        nbr, obs, lanej = _np(out["nbr"]), _np(out["obs_pre"]), _np(out["lanej"]).astype(np.int64)
+        for e, o in enumerate(oracles):
+            n = o.n_alive
+            _vid, ctlm, _ = o.alive_view()
+            rec = o.tick(np.where(ctlm != 0, acts[e, :n], 0.0))
+            f = flags[e, :n]
+            order = np.lexsort((lanej[e, :n] & 0xFFFF, (f >> 6) & 3, lanej[e, :n] >> 16))
+            ctl = order[((f & 2) != 0)[order]]
+            assert int(eo[e, 0]) == n and len(ctl) == len(rec["ids"]), "controlled set: tick %d env %d" % (t, e)
+            ids = np.stack([lanej[e, ctl] >> 16, lanej[e, ctl] & 0xFFFF], -1)
+            assert np.array_equal(ids, rec["ids"]), "ids order: tick %d env %d" % (t, e)
+            assert int(eo[e, 2]) == rec["collisions"] and int(eo[e, 3]) == rec["lock"], "counters: tick %d env %d" % (t, e)
+            assert np.array_equal(f[ctl] >> 8, rec["coll_pv"]), "coll_pv: tick %d env %d" % (t, e)
+            nb = nbr[e, ctl].astype(np.int64)
+            nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)
+            assert np.array_equal(nb, rec["nbr"]), "neighbours: tick %d env %d" % (t, e)
+            assert close(rec["reward"], rew[e, ctl], 1e-9), "reward: tick %d env %d" % (t, e)
+            assert close(rec["obs0"], obs[e, ctl], 1e-9), "obs: tick %d env %d" % (t, e)
+            tot_coll += rec["collisions"]
+            tot_lock += rec["lock"]
+    for e, o in enumerate(oracles):
+        info, vi, vf = state_snapshot(b, e)
+        ovi, ovf, _, ointent = o.vehicles()
+        assert np.array_equal(vi[:, :13], ovi[:, :13]), "final state ints, env %d" % e
+        assert close(ovf[:, :5], vf[:, :5], 1e-9), "final state floats, env %d" % e
+        got = np.array([[v.intention, v.route] for v in b.read_vehicles(e)], np.int32).reshape(-1, 2)
+        assert np.array_equal(got, ointent), "intentions / routes, env %d" % e
+    assert b.metrics()["overflow"] == 0
+    return tot_coll, tot_lock

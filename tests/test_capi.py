@@ -41,7 +41,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_capi.PveConfig) == 9 * 8 + 8
     assert C.sizeof(_capi.PveOutputs) == 10 * 8
     assert C.sizeof(_capi.PveVehicle) == 7 * 8 + 17 * 4 + 4   # padded to 8
-    assert C.sizeof(_capi.PveEnvInfo) == 8 + 4 * (1 + 12 + 12 + 3 + 36 + 1) + 4
+    assert C.sizeof(_capi.PveEnvInfo) == 8 + 4 * (1 + 12 + 12 + 3 + 3 * 16 + 1 + 1)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
@@ -68,9 +68,13 @@ def test_argument_validation_and_call_order():
     assert b"capacity" in lib.pve_last_error()
     assert lib.pve_create(C.byref(cfg), 0, 64, 0, None, None, C.byref(h)) == -1
     bad = _capi.PveConfig.from_buffer_copy(cfg)
-    bad.lane_num = 4
+    bad.lane_num = 3                                       # the 3-lane branch is broken upstream
     assert lib.pve_create(C.byref(bad), 4, 64, 0, None, None, C.byref(h)) == -1
-    assert b"12-lane" in lib.pve_last_error()
+    assert b"lane_num" in lib.pve_last_error()
+    assert lib.pve_create(C.byref(cfg), 2, 64, 0, None, None, C.byref(h)) == 0
+    ch = np.zeros((4, 12), np.int32)
+    assert lib.pve_set_intentions(h, ch.ctypes.data_as(C.c_void_p), 4, 0) == -1      # 8-lane only (ref :389-390)
+    assert lib.pve_destroy(h) == 0
     assert lib.pve_create(C.byref(cfg), 2, 64, 0, None, None, C.byref(h)) == 0
     assert lib.pve_reset(h) == -3 and b"pve_set_arrivals" in lib.pve_last_error()
     assert lib.pve_step_all(h, None, None) == -3

@@ -1,0 +1,46 @@
+"""SURVEY.md §8 f4 on CPU: the general-geometry kernel phases (csrc/pve_tick_geo.h, lane_num 4 / 8 / 12) executed by
+the test emulator and compared with the golden vectors of the live reference and with the sequential oracle.
+The `-m gpu` twin (test_gpu_parity.py) runs the real kernel."""
+import pytest
+
+from tests.parity_util import GEO_CASE_NAMES, GoldenCase, replay_case
+from tests.hip_adapter import SplitEnv, make_batch
+from tests import scenarios
+
+BACKEND = "emu"
+
+
+@pytest.mark.parametrize("name", GEO_CASE_NAMES)
+def test_geo_split_protocol_matches_golden(name):
+    case = GoldenCase(name)
+    assert scenarios.check_geo_golden(case, BACKEND) == case.ticks
+
+
+@pytest.mark.parametrize("name", ["geo_g4_sin3", "geo_g8_sin3"])
+def test_geo_matches_oracle_every_field(name):
+    scenarios.check_geo_vs_oracle(GoldenCase(name), BACKEND, ticks=400)
+
+
+@pytest.mark.parametrize("name", ["s1000_sin1", "s400_sin2", "s1000_sin3"])
+def test_general_path_with_12_lanes_reproduces_the_12_lane_vectors(name):
+    """lane_num = 12 through the general-geometry kernel == the golden tapes that pin the fast path."""
+    case = GoldenCase(name)
+    b = make_batch(case.arrive, 1, 128, BACKEND, general_path=True, **case.ctor)
+    replay_case(case, SplitEnv(b), ftol=1e-9, dtol=1e-9, want_state=True)
+
+
+def test_geo_fused_equals_split():
+    scenarios.check_geo_fused_equals_split(GoldenCase("geo_g4_sin3"), BACKEND, ticks=250)
+    scenarios.check_geo_fused_equals_split(GoldenCase("geo_g8_sin3"), BACKEND, ticks=250)
+
+
+def test_general_path_equals_fast_path_bit_for_bit():
+    scenarios.check_general_path_equals_fast_path(BACKEND, n_envs=3, ticks=200)
+
+
+@pytest.mark.parametrize("lane_num,rate,cap,quant,seed", [(4, 1800.0, 64, None, 31), (8, 1500.0, 128, 1.0, 32),
+                                                          (4, 2400.0, 128, 3.0, 33)])
+def test_geo_fuzz_random_tapes(lane_num, rate, cap, quant, seed):
+    coll, lock = scenarios.check_geo_fuzz_vs_oracle(BACKEND, lane_num, n_envs=4, capacity=cap, ticks=300, rate=rate,
+                                                    seed=seed, quantize=quant)
+    assert coll > 0 and lock > 0

@@ -169,3 +169,40 @@ def test_gpu_side_stream_and_two_handles():
     for k in ("p", "v", "a", "id", "meta", "step"):
         assert torch.equal(b0.state_field(k), b1.state_field(k)) and torch.equal(b0.state_field(k), b2.state_field(k)), k
     assert b0.metrics() == b1.metrics() == b2.metrics()
+
+
+# ---------------------------------------------------------------- 4- / 8-lane layouts (k_tick_geo)
+@pytest.mark.parametrize("name", ["geo_g4_zero", "geo_g4_sin2", "geo_g4_sin3", "geo_g8_zero", "geo_g8_sin2", "geo_g8_sin3"])
+def test_gpu_geo_split_protocol_matches_golden(name):
+    case = GoldenCase(name)
+    assert scenarios.check_geo_golden(case, BACKEND) == case.ticks
+
+
+@pytest.mark.parametrize("name", ["geo_g4_sin3", "geo_g8_sin3"])
+def test_gpu_geo_matches_oracle_every_field(name):
+    scenarios.check_geo_vs_oracle(GoldenCase(name), BACKEND, ticks=400, tol=TOL)
+
+
+def test_gpu_geo_fused_equals_split():
+    scenarios.check_geo_fused_equals_split(GoldenCase("geo_g4_sin3"), BACKEND, ticks=250)
+    scenarios.check_geo_fused_equals_split(GoldenCase("geo_g8_sin3"), BACKEND, ticks=250)
+
+
+def test_gpu_general_path_equals_fast_path_bit_for_bit():
+    """lane_num = 12 through k_tick_geo == k_tick on 16 envs x 400 random-action ticks."""
+    scenarios.check_general_path_equals_fast_path(BACKEND, n_envs=16, ticks=400)
+
+
+@pytest.mark.parametrize("name", ["s1000_sin1", "s1000_sin3"])
+def test_gpu_general_path_reproduces_12_lane_golden(name):
+    case = GoldenCase(name)
+    b = make_batch(case.arrive, 1, 128, BACKEND, general_path=True, **case.ctor)
+    replay_case(case, SplitEnv(b), ftol=TOL, dtol=TOL, want_state=True)
+
+
+@pytest.mark.parametrize("lane_num,rate,cap,quant,seed", [(4, 1800.0, 64, None, 31), (8, 1500.0, 128, 1.0, 32),
+                                                          (4, 2400.0, 128, 3.0, 33), (8, 1800.0, 128, None, 34)])
+def test_gpu_geo_fuzz_random_tapes(lane_num, rate, cap, quant, seed):
+    coll, lock = scenarios.check_geo_fuzz_vs_oracle(BACKEND, lane_num, n_envs=16, capacity=cap, ticks=400, rate=rate,
+                                                    seed=seed, quantize=quant)
+    assert coll > 0 and lock > 0
