@@ -8,8 +8,13 @@ but every tick runs in the hand-written HIP kernels of libpveenv.so through the 
 library or without an AMD GPU construction raises PveError.
 
 What is NOT provided (out of scope): the matplotlib renderer `Visible`, the
-plotting recorders (`virtual_data`, `choose_veh_info`, `veh_info_record` stay empty), the 3/4/8-lane
-geometries (lane_num must be 12), and the reference's crash at :371-375.
+plotting recorders (`virtual_data`, `choose_veh_info`, `veh_info_record` stay empty), the 3-lane layout (broken
+upstream) and the reference's crash at :371-375.
+
+lane_num = 12 runs the optimised kernel; lane_num = 4 / 8 (ref :66-145) run the general-geometry kernel.  For
+lane_num = 8 the reference draws every new vehicle's intention with an entropy-seeded random.randint(0, 1)
+(ref :381, :390); here the draws come from `intentions` ([rows, 8] of 0/1) or, when that is None, from
+numpy.random.default_rng(intention_seed) -- random like the reference, but reproducible.
 """
 import numpy as np
 import torch
@@ -23,9 +28,9 @@ _OUTPUTS = ("obs_post", "obs_pre", "state_pre", "reward", "flags", "lanej", "nbr
 class TrafficInteraction:
     def __init__(self, arrive_time, dis_ctl, args, deltaT=0.1, vm=5, vM=13, am=-3, aM=3, v0=10, diff_max=220,
                  lane_cw=2.5, loc_con=True, show_col=False, virtual_l=True, lane_num=12,
-                 capacity=128, device=None, _lib=None):
-        if lane_num != 12:
-            raise _capi.PveError("only the 12-lane intersection is implemented (lane_num=12)")
+                 capacity=128, device=None, intentions=None, intention_seed=None, _lib=None):
+        if lane_num not in (12, 8, 4):
+            raise _capi.PveError("lane_num must be 12, 8 or 4 (the 3-lane branch is broken upstream)")
         if not loc_con:
             raise _capi.PveError("loc_con=False is not supported")
         # attributes main.py / the renderer read (ref :28-45, :148-152, :195-213)
@@ -41,10 +46,20 @@ class TrafficInteraction:
         self.c_mode = getattr(args, "c_mode", "closer")
         if self.closer_veh_num != 6:
             raise _capi.PveError("o_agent_num must be 6 (the reference hard-codes 6 neighbours, ref :1324)")
+        half, rl = {12: (6, 7), 8: (4, 5), 4: (2, 3)}[lane_num]           # ref :69-71, :103-105, :149-151
         self.lane_info = [
-            [dis_ctl - 6 * lane_cw, 3.1415 / 2 * 7 * lane_cw, -(dis_ctl - 6 * lane_cw)],
-            [dis_ctl - 6 * lane_cw, 12 * lane_cw, -(dis_ctl - 6 * lane_cw)],
-            [dis_ctl - 6 * lane_cw, 3.1415 / 2 * lane_cw, -(dis_ctl - 6 * lane_cw)]]
+            [dis_ctl - half * lane_cw, 3.1415 / 2 * rl * lane_cw, -(dis_ctl - half * lane_cw)],
+            [dis_ctl - half * lane_cw, 2 * half * lane_cw, -(dis_ctl - half * lane_cw)],
+            [dis_ctl - half * lane_cw, 3.1415 / 2 * lane_cw, -(dis_ctl - half * lane_cw)]]
+        if lane_num == 4:                                                 # ref :88-93
+            self.direction = [[6, 7, 8], [0, 1, 2], [9, 10, 11], [3, 4, 5]]
+        elif lane_num == 8:                                               # ref :135-144
+            self.direction = [[0, 1, -1], [-1, 2, 3], [4, 5, -1], [-1, 6, 7],
+                              [8, 9, -1], [-1, 10, 11], [12, 13, -1], [-1, 14, 15]]
+        else:                                                             # ref :168-181
+            self.direction = [[i if m == i % 3 else -1 for m in range(3)] for i in range(12)]
+        self.direction_num = _capi.DIR_NUM[lane_num]
+        self.intention_re = 0
         self.deltaT = deltaT
         self.dis_control = dis_ctl
         self.diff_max = diff_max
@@ -52,9 +67,12 @@ class TrafficInteraction:
         self.choose_veh_info = [[] for _ in range(lane_num)]
         self.veh_info_record = [[] for _ in range(lane_num)]
         self.delete_veh = []
-        self.virtual_lane_4 = [[] for _ in range(lane_num)]   # only the head entry [vd?, lane, j] is mirrored
+        self.virtual_lane_4 = [[] for _ in range(self.direction_num)]   # only the head entry [vd?, lane, j] is mirrored
         arr = np.ascontiguousarray(np.asarray(arrive_time, dtype=np.float64))
+        if lane_num == 8 and intentions is None:
+            intentions = np.random.default_rng(intention_seed).integers(0, 2, size=arr.shape).astype(np.int32)
         self._b = BatchedIntersections(1, capacity, arr, device=device, outputs=_OUTPUTS, _lib=_lib,
+                                       intentions=intentions if lane_num == 8 else None, lane_num=lane_num,
                                        deltaT=deltaT, vm=vm, vM=vM, am=am, aM=aM, v0=v0, lane_cw=lane_cw,
                                        dis_ctl=dis_ctl, collision_thr=args.collision_thr)
         self._cap = capacity
@@ -71,14 +89,16 @@ class TrafficInteraction:
         info = b.read_env(0)
         vehs = b.read_vehicles(0)
         self.current_time = info.current_time
-        self.veh_num = list(info.lane_count)
-        self.veh_rec = list(info.veh_rec)
+        nl = self.lane_num
+        self.veh_num = list(info.lane_count)[:nl]
+        self.veh_rec = list(info.veh_rec)[:nl]
+        self.intention_re = info.intention_re
         self.id_seq = info.id_seq
         self.passed_veh = info.passed_veh
         self.passed_veh_step_total = info.passed_veh_step_total
-        for d in range(12):
+        for d in range(self.direction_num):
             self.virtual_lane_4[d] = [[None, info.head_lane[d], info.head_j[d]]] if info.head_valid[d] else []
-        lanes = [[] for _ in range(12)]
+        lanes = [[] for _ in range(nl)]
         seen = set()
         for slot, v in enumerate(vehs):
             vid = v.id
@@ -129,8 +149,11 @@ class TrafficInteraction:
         eo = out["env_out"][0].cpu().numpy()
         n_pre = int(eo[0])
         flags = out["flags"][0, :n_pre].cpu().numpy().astype(np.int64)
-        ctl = (flags & _capi.F_CTL) != 0
-        lanej = out["lanej"][0, :n_pre].cpu().numpy()
+        lanej = out["lanej"][0, :n_pre].cpu().numpy().astype(np.int64)
+        # scene_update reports in processing order: lane, intention, j (ref :233-275); == slot order for 12 lanes
+        order = np.lexsort((lanej & 0xFFFF, (flags >> _capi.F_INTENT_SHIFT) & 3, lanej >> 16)) if n_pre else \
+            np.zeros(0, np.int64)
+        ctl = order[((flags & _capi.F_CTL) != 0)[order]]
         state = out["state_pre"][0, :n_pre].cpu().numpy()
         reward = out["reward"][0, :n_pre].cpu().numpy()
         new_slot = out["new_slot"][0, :n_pre].cpu().numpy()
@@ -141,12 +164,13 @@ class TrafficInteraction:
         cpv = [[int(c), 0] for c in (flags[ctl] >> 8)]
         nbr = out["nbr"][0, :n_pre].cpu().numpy()[ctl]
         self.last_nbr = [[[int(x) >> 16, int(x) & 0xFFFF] if x >= 0 else [-1, -1] for x in row] for row in nbr]
-        self.delete_veh = [[int(x) >> 16, int(x) & 0xFFFF] for x in lanej[(flags & _capi.F_DELETED) != 0]]
+        self.delete_veh = [[int(x) >> 16, int(x) & 0xFFFF]
+                           for x in lanej[order[((flags & _capi.F_DELETED) != 0)[order]]]]
         # veh["state"] = deep copy of the new state for the controlled vehicles (ref :288)
         ids_dev = b.state_field("id")[0].cpu().numpy()
-        states = {int(ids_dev[new_slot[k]]): np.array(state[k]) for k in np.flatnonzero(ctl)}
+        states = {int(ids_dev[new_slot[k]]): np.array(state[k]) for k in ctl}
         self._refresh(states)
-        fin = np.flatnonzero((flags & _capi.F_FINISHED) != 0)
+        fin = order[((flags & _capi.F_FINISHED) != 0)[order]]
         jerks = [float(self._veh[int(ids_dev[new_slot[k]])]["jerk_sum"]) for k in fin]
         return ids, re_state, rew, actions, int(eo[2]), 0, cpv, jerks, int(eo[3])
 

@@ -18,7 +18,9 @@ def make_env(case, backend):
     kw = dict(case.ctor)
     if backend == "emu":
         kw.update(device="cpu", _lib=emulator_lib())
-    return TrafficInteraction(case.arrive, 150, args, show_col=False, virtual_l=True, lane_num=12, **kw)
+    if case.lane_num == 8:
+        kw["intentions"] = case.choice
+    return TrafficInteraction(case.arrive, 150, args, show_col=False, virtual_l=True, lane_num=case.lane_num, **kw)
 
 
 def run_compat(name, ticks, backend):
@@ -38,6 +40,16 @@ def run_compat(name, ticks, backend):
 def test_compat_class_reproduces_golden(name, ticks):
     env = run_compat(name, ticks, "emu")
     assert env.id_seq > 0 and env.deltaT == 0.1 and env.lane_num == 12
+
+
+@pytest.mark.parametrize("name,ticks,lanes", [("geo_g4_sin2", 500, 4), ("geo_g8_sin3", 500, 8)])
+def test_compat_class_4_and_8_lanes_reproduce_golden(name, ticks, lanes):
+    """SURVEY §8 f4 through the drop-in class: `ids` / rewards / states come out in (lane, intention, j) order."""
+    env = run_compat(name, ticks, "emu")
+    assert env.lane_num == lanes and len(env.veh_info) == lanes and env.id_seq > 0
+    assert env.direction_num == (12 if lanes == 4 else 16)
+    routes = {v["route"] for lane in env.veh_info for v in lane}
+    assert routes and all(0 <= r < env.direction_num for r in routes)
 
 
 def test_compat_constructor_pins_and_caller_mutation():
