@@ -206,3 +206,10 @@ def test_gpu_geo_fuzz_random_tapes(lane_num, rate, cap, quant, seed):
     coll, lock = scenarios.check_geo_fuzz_vs_oracle(BACKEND, lane_num, n_envs=16, capacity=cap, ticks=400, rate=rate,
                                                     seed=seed, quantize=quant)
     assert coll > 0 and lock > 0
+
+
+@pytest.mark.parametrize("name,ticks", [("geo_g4_sin2", 400), ("geo_g8_sin3", 400)])
+def test_gpu_compat_class_4_and_8_lanes(name, ticks):
+    from tests.test_compat_class import run_compat
+    env = run_compat(name, ticks, "hip")
+    assert env.lane_num in (4, 8) and env.id_seq > 0
