@@ -39,14 +39,18 @@ def action_pool(n_envs, cap, seed):
     return a.astype(np.float32).astype(np.float64)
 
 
-def cpu_baseline(arr, pool, cap, warm, ticks):
+def cpu_baseline(arr, pool, cap, warm, ticks, lane_num=12, choice=None):
     """The CPU oracle (oracle/pve_oracle.c, a plain-C port of the reference algorithm) timed on this
     host's cores on a bounded sample of the same workload: the first `n` envs of the same arrival
     tensor with the same action pool, one env per thread-task, all cores busy."""
     from oracle.oracle import OracleEnv
     cores = os.cpu_count() or 1
     n = min(arr.shape[0], max(cores * 8, 16))
-    envs = [OracleEnv(arr[e]) for e in range(n)]
+    if lane_num == 12:
+        envs = [OracleEnv(arr[e]) for e in range(n)]
+    else:
+        from oracle.oracle_geo import OracleGeoEnv
+        envs = [OracleGeoEnv(arr[e], lane_num, choice=None if choice is None else choice[e]) for e in range(n)]
     res = [None] * n
     nxt = [0]
     lock = threading.Lock()
@@ -104,6 +108,8 @@ def main(argv=None, env_factory=None):
     ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default 1100 at cap 128, 500 at cap 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
+    ap.add_argument("--lane-num", type=int, default=12, choices=(12, 8, 4),
+                    help="intersection layout; 12 = BASELINE metric (k_tick), 4 / 8 = SURVEY 8 f4 (k_tick_geo)")
     ap.add_argument("--actor", action="store_true",
                     help="BASELINE config 5: close the loop on the device (k_actor -> k_tick per step) instead of the action pool")
     args = ap.parse_args(argv)
@@ -133,21 +139,23 @@ def main(argv=None, env_factory=None):
             torch.cuda.synchronize(dev)
 
     import pve_mcc_amd
-    from pve_mcc_amd.arrivals import synthetic_arrivals
+    from pve_mcc_amd.arrivals import synthetic_arrivals, synthetic_intentions
     from pve_mcc_amd.distributed import gather_metrics
 
-    cap, n_envs = args.capacity, args.envs
-    rate = args.rate or (1100.0 if cap == 128 else 500.0)
+    cap, n_envs, lane_num = args.capacity, args.envs, args.lane_num
+    rate = args.rate or {12: (1100.0 if cap == 128 else 500.0), 8: 1500.0, 4: 1800.0}[lane_num]
     K, W = args.steps, args.warmup
     horizon = (K + W) * 0.1 + 20.0
     # weak scaling: every rank owns its own n_envs environments (global env index = rank*n_envs + e)
-    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=horizon, seed=20250213 + rank * n_envs)
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=horizon, seed=20250213 + rank * n_envs, lane_num=lane_num)
+    choice = synthetic_intentions(n_envs, arr.shape[1], seed=20250213 + rank * n_envs) if lane_num == 8 else None
     pool_np = action_pool(n_envs, cap, seed=99 + rank)
     outputs = tuple(x for x in args.outputs.split(",") if x)
     if emu:
         env = env_factory(n_envs, cap, arr, outputs)
     else:
-        env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs)
+        env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs, lane_num=lane_num,
+                                               intentions=choice)
     pool = torch.as_tensor(pool_np, device=dev)
     env.reset()
     if args.actor:
@@ -196,15 +204,15 @@ def main(argv=None, env_factory=None):
         value = slot_steps / wall
         kern_s = gpu_ms * 1e-3 / K
         achieved = B_ALG_FP64 * cap * n_envs / kern_s / 1e9
-        traffic, traffic_src = pmc_traffic(n_envs, cap, outputs, args.actor)
+        traffic, traffic_src = pmc_traffic(n_envs, cap, outputs, args.actor or lane_num != 12)
         line = {
             "metric": "env-steps/sec (vehicles x envs x steps/s) at 128 veh x 4096 envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "synthetic (injected test environment: timings meaningless)",
-            "config": {"workload": "%d parallel 12-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
+            "config": {"workload": "%d parallel %d-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
-                                   % (n_envs, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
+                                   % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
                                       if args.actor else "sin action pool"),
                        "envs_per_gpu": n_envs, "capacity": cap, "parallelism": "env-parallel x%d" % world,
                        "outputs": list(outputs)},
@@ -215,13 +223,13 @@ def main(argv=None, env_factory=None):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
-                         "kernel": "k_tick<%d>" % cap, "kernel_ms": kern_s * 1e3,
+                         "kernel": ("k_tick<%d>" if lane_num == 12 else "k_tick_geo<%d>") % cap, "kernel_ms": kern_s * 1e3,
                          "alg_bytes_per_slot_step": B_ALG_FP64},
         }
         if args.actor:
             line["roofline"]["note"] = "kernel_ms = k_actor + k_tick per step; achieved uses the tick's algorithmic bytes only"
         if not args.no_cpu_baseline and not args.actor:
-            line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, min(W, 300), min(K, 200))
+            line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, min(W, 300), min(K, 200), lane_num, choice)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()                # every rank leaves together (rank 0 may still be timing the CPU baseline)

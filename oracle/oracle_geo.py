@@ -60,6 +60,8 @@ def lib():
     L.pvg_get_p.argtypes = [vp, C.c_double, C.c_int, C.c_int, dp]
     L.pvg_get_virtual_distance.restype = C.c_int
     L.pvg_get_virtual_distance.argtypes = [vp, C.c_int, C.c_int, C.c_double, dp]
+    L.pvg_run_pool.restype = C.c_long
+    L.pvg_run_pool.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
     _lib = L
     return L
 
@@ -189,3 +191,13 @@ class OracleGeoEnv:
         rec["veh_rec"] = ev[4 + nl:4 + 2 * nl].copy()
         rec["heads"] = ev[4 + 2 * nl:].reshape(nd_, 3).copy()
         return rec
+
+    def run_pool(self, ticks, pool, tick0=0):
+        """Timing loop entirely in C with a per-slot action pool [n_pool, cap] (bench.py cpu_baseline).
+        -> (alive_steps, ctl_steps)"""
+        pool = np.ascontiguousarray(pool, dtype=np.float64)
+        ctl = C.c_long(0)
+        alive = self._L.pvg_run_pool(self._h, int(ticks), pool.ctypes.data_as(C.POINTER(C.c_double)),
+                                     pool.shape[0], pool.shape[1], int(tick0), C.byref(ctl))
+        self.tick_no += ticks
+        return int(alive), int(ctl.value)

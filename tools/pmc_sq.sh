@@ -1,0 +1,36 @@
+#!/usr/bin/env bash
+# SQ-level counters of k_tick (instruction mix, LDS conflicts, wait cycles): separate --pmc passes, kernel-trace only.
+# Usage on the GPU box:  bash tools/pmc_sq.sh <tag>     -> gpurun_out/pmc_sq_<tag>.txt
+set -u
+TAG=${1:-r1}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/pmc_sq_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" \
+           "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_INT32" \
+           "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS_ATOMIC"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-trace -d "$OUT/p$i" -o p$i --output-format csv -- python3 "$REPO/bench.py" --steps 20 --warmup 300 --no-cpu-baseline ${PMC_BENCH_ARGS:-} > "$OUT/p$i.log" 2>&1
+done
+python3 - "$OUT" <<'PY' > "$REPO/gpurun_out/pmc_sq_$TAG.txt"
+import sys, glob, csv, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row.get("Kernel_Name", "")
+        if "k_tick" not in k and "k_actor" not in k:
+            continue
+        acc[k.split("(")[0][:40]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, d in acc.items():
+    print(k)
+    for c in sorted(d):
+        v = d[c]
+        print("   %-28s mean/launch %.4g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+PY
+cat "$REPO/gpurun_out/pmc_sq_$TAG.txt"
