@@ -288,6 +288,42 @@ PVE_HD void get_xy_f32(const PVE_AS4 Const &c, double pd, int lane, float &X, fl
     Y = y * rc + x * rs;
 }
 
+// ------------------------------------------------------------------ reward terms: ref :311-320
+// The reward is a float output (tolerance 1e-5, asserted at 1e-9), never an input of a discrete decision, so its two
+// transcendental terms use short forms instead of the general-purpose library routines (tanh: 165 VALU instructions,
+// log: 98): both are accurate to ~1e-15 on the ranges the reward can produce before it is clamped to [-20, 20].
+// 1 / tanh(-t/4) for 0 < t < 4 (ref :314-315): coth(x) = (e^2x + 1) / (e^2x - 1), x = -t/4 in (-1, 0).  The
+// cancellation in e^2x - 1 only bites for t < 1e-3, where the term is < -4000 and the clamp takes over.
+PVE_HD double reward_coth_term(double t_distance)
+{
+    const double u = exp(-0.5 * t_distance);            // e^(2x); -t/4 * 2 is exact
+    return (u + 1.0) / (u - 1.0);
+}
+// log(z) for z in [1e-5, 1.00001] (ref :317-318: z = (d/10)^5 + 1e-5, d < 10): z = 2^e * m, m in [sqrt(1/2), sqrt(2)),
+// log(m) = 2s(1 + s^2/3 + s^4/5 + ...), s = (m - 1)/(m + 1), |s| <= 0.172: 10 terms give 1e-16.
+PVE_HD double reward_log_term(double z)
+{
+    int e;
+    double m = frexp(z, &e);                            // m in [0.5, 1)
+    const bool lo = m < 0.70710678118654752;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double w = s * s;
+    double q = 1.0 / 19.0;
+    q = __builtin_fma(q, w, 1.0 / 17.0);
+    q = __builtin_fma(q, w, 1.0 / 15.0);
+    q = __builtin_fma(q, w, 1.0 / 13.0);
+    q = __builtin_fma(q, w, 1.0 / 11.0);
+    q = __builtin_fma(q, w, 1.0 / 9.0);
+    q = __builtin_fma(q, w, 1.0 / 7.0);
+    q = __builtin_fma(q, w, 1.0 / 5.0);
+    q = __builtin_fma(q, w, 1.0 / 3.0);
+    q = __builtin_fma(q, w, 1.0);
+    return __builtin_fma((double)e, 0.69314718055994530942, (s + s) * q);
+}
+
 PVE_HD bool key_less(double d1, double v1, int r1, double d2, double v2, int r2)
 {   // total order of the reference's stable sort on |vd - vd_self| over a vd-sorted list (ref :271, :1389)
     return d1 < d2 || (d1 == d2 && (v1 < v2 || (v1 == v2 && r1 < r2)));
@@ -656,19 +692,18 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
         // ref :311-320
         double r_ = 0;
-        if (0 < t_distance && t_distance < 4) r_ += 1 / tanh(-t_distance / 4.0);
-        {
-            double jd = r.jerk / c.deltaT;
-            r_ -= jd * jd / 3600.0 * 3.0;
-        }
+        if (0 < t_distance && t_distance < 4) r_ += reward_coth_term(t_distance);
+        // divisions by constants become multiplications in these reward-only terms (no decision reads them)
+        const double jd = r.jerk * c.inv_dt;
+        r_ -= jd * jd * (3.0 / 3600.0);
         if (d_distance < 10) {
-            double q1 = d_distance / 10, q2 = q1 * q1;
-            r_ += log(q2 * q2 * q1 + 0.00001);
+            double q1 = d_distance * 0.1, q2 = q1 * q1;
+            r_ += reward_log_term(q2 * q2 * q1 + 0.00001);
         }
-        r_ += (r.v - c.vm) / c.aM_minus_am * 2.0;
+        r_ += (r.v - c.vm) * c.inv_span * 2.0;
         r_ = (r_ > -20) ? r_ : -20;
         r.reward = (r_ < 20) ? r_ : 20;
-        r.jerk_sum += fabs(r.jerk / c.deltaT);                                    // ref :321
+        r.jerk_sum += fabs(jd);                                                   // ref :321
         // ref :322-334
         // pre-filter in single precision: the exact FP64 positions (two divisions + polynomials each) are only
         // evaluated when the pair is within 5 cm of the threshold band -- the decision itself is always FP64

@@ -272,19 +272,18 @@ template <int CAP> struct TickGeo {
             r.closer_p = 150;
         }
         double r_ = 0;
-        if (0 < t_distance && t_distance < 4) r_ += 1 / tanh(-t_distance / 4.0);
-        {
-            double jd = r.jerk / c.deltaT;
-            r_ -= jd * jd / 3600.0 * 3.0;
-        }
+        if (0 < t_distance && t_distance < 4) r_ += reward_coth_term(t_distance);
+        // divisions by constants become multiplications in these reward-only terms (no decision reads them)
+        const double jd = r.jerk * c.inv_dt;
+        r_ -= jd * jd * (3.0 / 3600.0);
         if (d_distance < 10) {
-            double q1 = d_distance / 10, q2 = q1 * q1;
-            r_ += log(q2 * q2 * q1 + 0.00001);
+            double q1 = d_distance * 0.1, q2 = q1 * q1;
+            r_ += reward_log_term(q2 * q2 * q1 + 0.00001);
         }
-        r_ += (r.v - c.vm) / c.aM_minus_am * 2.0;
+        r_ += (r.v - c.vm) * c.inv_span * 2.0;
         r_ = (r_ > -20) ? r_ : -20;
         r.reward = (r_ < 20) ? r_ : 20;
-        r.jerk_sum += fabs(r.jerk / c.deltaT);
+        r.jerk_sum += fabs(jd);
         if (n0 >= 0) {
             double ax, ay, bx, by;
             geo_xy(g, ps, r.lane, r.intent, ax, ay);

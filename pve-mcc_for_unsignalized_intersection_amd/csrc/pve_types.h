@@ -39,6 +39,7 @@ struct Const {
     double vm, vM, am, aM, v0;
     double abs_am, two_abs_am;     // |am|, 2*|am| (ref :1513-1514)
     double aM_minus_am;            // float(aM - am) (ref :319)
+    double inv_dt, inv_span;       // 1/deltaT, 1/(aM - am): reward-only terms use a multiplication (float output, ~1 ulp)
     double collision_thr, lock_mean_thr;   // thr, thr + 3 (ref :1471, 1495)
     double exit_p;                 // -dis_ctl + int((12+1)/2)*cw (ref :341-342)
     double cw;
