@@ -16,4 +16,8 @@ timeout 300 python bench.py --capacity 64 --no-cpu-baseline 2>&1 | tail -1 > $O/
 timeout 300 python bench.py --actor --no-cpu-baseline 2>&1 | tail -1 > $O/bench_actor.json
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_actor -o r -- python bench.py --actor --no-cpu-baseline --steps 300 > /dev/null 2>&1
 python tools/phase_profile.py --ticks 50 > $O/phase_profile.txt 2>&1
+# general-geometry kernel (4 / 8 lanes)
+timeout 300 python bench.py --lane-num 8 --steps 300 2>&1 | tail -1 > $O/bench_lanes8.json
+timeout 300 python bench.py --lane-num 4 --capacity 64 --steps 300 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_lanes4.json
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_lanes8 -o r -- python bench.py --lane-num 8 --steps 300 --no-cpu-baseline > /dev/null 2>&1
 ls $O
