@@ -177,7 +177,8 @@ int pve_compact(pve_handle h, double *obs_post /* optional: rows are moved with 
 int pve_actor_forward(pve_handle h, const float *weights, const double *obs, double *actions);
 
 /* Closed loop on the device, no host round trip: pve_actor_forward(obs_in -> actions) followed by
- * pve_step_all(actions, out) on the same stream (BASELINE config 5). out->obs_post must not alias obs_in. */
+ * pve_step_all(actions, out) on the same stream (BASELINE config 5).  out->obs_post may be obs_in itself (the tick
+ * never reads observations) unless out->state_pre is requested, which needs the previous rows (obs_prev_post). */
 int pve_step_all_actor(pve_handle h, const float *weights, const double *obs_in, double *actions,
                        const pve_outputs *out);
 

@@ -82,7 +82,11 @@ class BatchedIntersections:
             names.update(("obs_pre", "obs_post"))
         self._obs = None
         if "obs_post" in names:
-            self._obs = [torch.zeros(E, K, 28, dtype=torch.float64, device=dev) for _ in range(2)]
+            # state_pre reads the rows the previous tick stored (stale neighbour rows, ref :1332): ping-pong pair.
+            # Otherwise ONE buffer: the tick never reads observations, and 117 MB less working set per 4096 envs
+            # keeps more of the tick's traffic in the 256 MB Infinity Cache (57.2 vs 59.1 us per tick).
+            self._obs = [torch.zeros(E, K, 28, dtype=torch.float64, device=dev)
+                         for _ in range(2 if "state_pre" in names else 1)]
             self._obs_cur = 0
         shapes = dict(obs_pre=((E, K, 28), torch.float64), state_pre=((E, K, 7, 28), torch.float64),
                       reward=((E, K), torch.float64), flags=((E, K), torch.int32), lanej=((E, K), torch.int32),
@@ -177,10 +181,11 @@ class BatchedIntersections:
     def _outputs_struct(self, flip_obs):
         o = PveOutputs()
         if self._obs is not None:
-            if flip_obs:
-                self._obs_cur ^= 1
+            if len(self._obs) == 2:
+                if flip_obs:
+                    self._obs_cur ^= 1
+                o.obs_prev_post = self._obs[self._obs_cur ^ 1].data_ptr()
             o.obs_post = self._obs[self._obs_cur].data_ptr()
-            o.obs_prev_post = self._obs[self._obs_cur ^ 1].data_ptr()
         for n, tns in self.out.items():
             setattr(o, n, tns.data_ptr())
         return o
