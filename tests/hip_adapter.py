@@ -49,7 +49,6 @@ def state_snapshot(b, env):
     n = info.n_alive
     counts = list(info.lane_count)
     lane = np.repeat(np.arange(12), counts).astype(np.int32)
-    b._last_lane = lane
     j = np.concatenate([np.arange(c) for c in counts]).astype(np.int32) if n else np.zeros(0, np.int32)
     f = {k: _np(b.state_field(k)[env, :n]) for k in ("p", "v", "a", "jerk", "jerk_sum", "vir_dis", "closer_p")}
     i = {k: _np(b.state_field(k)[env, :n]) for k in ("id", "seq", "vnum", "step", "count", "meta", "hdr")}
