@@ -167,6 +167,30 @@ template <int CAP> struct TickGeo {
         return true;
     }
 
+    // 4-lane far-conflict fix-up (ref :1301-1319): current value of an entry of the opposing left-turn route as seen
+    // by ego t: the controlled vehicles of the ego's route up to and including the ego have, one after the other,
+    // re-written it (the adjusted copy is stored back at ref :286-287, so the adjustments compound)
+    static PVE_HD double adjusted(const PVE_AS4 GeoConst &g, const Sh &sh, int m, int ls, int le, int t, double vc)
+    {
+        for (int w2 = 0; w2 < NW; w2++) {
+            u64 eb = sh.m_ctl[w2] & sh.m_int[m][w2];
+            for (; eb; eb &= eb - 1) {
+                const int e = w2 * 64 + __builtin_ctzll(eb);
+                if (e < ls || e >= le || e > t) continue;
+                const double pe = sh.p[e];
+                const double ori = vc + g.fix_d;                                       // ref :1304
+                if (pe < ori) {                                                        // ref :1305-1312
+                    const double r2 = ori - g.fix_hi + g.fix_lo;
+                    vc = (r2 < pe) ? pe + 1 : r2;
+                } else {                                                               // ref :1313-1319
+                    const double r2 = ori + g.fix_hi - g.fix_lo;
+                    vc = (r2 > pe) ? pe - 1 : r2;
+                }
+            }
+        }
+        return vc;
+    }
+
     // ============================================================== SCAN: list heads, predecessor, 6 nearest
     static PVE_HD void ph_scan(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
     {
@@ -203,51 +227,59 @@ template <int CAP> struct TickGeo {
         const int opp = sh.opp[d];
         const int ls = sh.hd.lane_start[li], le = sh.hd.lane_start[li + 1];
         double bvo = -INFINITY, bvc = 0; int bslot = -1;
-        double kd[NNB], ko[NNB], kc[NNB]; int ks[NNB];
+        // the 6 nearest so far, sorted by |vd - vd_self|: only (distance, slot) travel through the insertion chain;
+        // the build-time / current distances of the 6 winners are re-derived at the end, and the rare exact
+        // distance ties (which the reference's stable sort breaks by list position) take the full-key path
+        double kd[NNB]; int ks[NNB];
 #pragma unroll
-        for (int k = 0; k < NNB; k++) { kd[k] = INFINITY; ko[k] = INFINITY; kc[k] = 0; ks[k] = -1; }
+        for (int k = 0; k < NNB; k++) { kd[k] = INFINITY; ks[k] = -1; }
         for (int w = 0; w < NW; w++)
             for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
                 const int x = w * 64 + __builtin_ctzll(bits);
                 double vo;
                 if (x == t || !member(g, sh, d, li, m, x, vo)) continue;
-                double vc = vo;
-                if (fix && sh.route_of[x] == opp) {
-                    // 4-lane: the controlled vehicles of this route up to and including us have, one after the
-                    // other, re-written this entry (ref :1301-1319; the copy is stored back at ref :286-287)
-                    for (int w2 = 0; w2 < NW; w2++) {
-                        u64 eb = sh.m_ctl[w2] & sh.m_int[m][w2];
-                        for (; eb; eb &= eb - 1) {
-                            const int e = w2 * 64 + __builtin_ctzll(eb);
-                            if (e < ls || e >= le || e > t) continue;
-                            const double pe = sh.p[e];
-                            const double ori = vc + g.fix_d;                           // ref :1304
-                            if (pe < ori) {                                            // ref :1305-1312
-                                const double r2 = ori - g.fix_hi + g.fix_lo;
-                                vc = (r2 < pe) ? pe + 1 : r2;
-                            } else {                                                   // ref :1313-1319
-                                const double r2 = ori + g.fix_hi - g.fix_lo;
-                                vc = (r2 > pe) ? pe - 1 : r2;
-                            }
-                        }
-                    }
-                }
+                const double vc = (fix && sh.route_of[x] == opp) ? adjusted(g, sh, m, ls, le, t, vo) : vo;
                 // predecessor in list order = stable sort by the build-time distance (ref :271, :1353)
                 const bool before = vo < me || (vo == me && x < t);
                 if (before && (vo > bvo || (vo == bvo && x > bslot))) { bvo = vo; bslot = x; bvc = vc; }
                 // 6 nearest: stable sort of the list by |vd - vd_self| on the current values (ref :1383-1397)
-                double cd = fabs(vc - me), co = vo, cc = vc; int cs = x;
+                double cd = fabs(vc - me); int cs = x;
+                bool tie = false;
 #pragma unroll
-                for (int k = 0; k < NNB; k++) {
-                    const bool sw = key_less(cd, co, cs, kd[k], ko[k], ks[k] < 0 ? 0x7fffffff : ks[k]);
-                    const double td = sw ? kd[k] : cd, to = sw ? ko[k] : co, tc = sw ? kc[k] : cc;
-                    const int ts = sw ? ks[k] : cs;
-                    kd[k] = sw ? cd : kd[k]; ko[k] = sw ? co : ko[k]; kc[k] = sw ? cc : kc[k]; ks[k] = sw ? cs : ks[k];
-                    cd = td; co = to; cc = tc; cs = ts;
+                for (int k = 0; k < NNB; k++) tie = tie || (cd == kd[k]);
+                if (!tie) {
+                    bool ins = false;                             // once placed, the tail shifts down by one
+#pragma unroll
+                    for (int k = 0; k < NNB; k++) {
+                        const bool sw = ins || cd < kd[k];
+                        ins = sw;
+                        const double td = sw ? kd[k] : cd; const int ts = sw ? ks[k] : cs;
+                        kd[k] = sw ? cd : kd[k]; ks[k] = sw ? cs : ks[k];
+                        cd = td; cs = ts;
+                    }
+                } else {
+                    double co = vo;
+#pragma unroll
+                    for (int k = 0; k < NNB; k++) {
+                        double eo = INFINITY;                     // build-time distance of the entry (list position)
+                        if (ks[k] >= 0) member(g, sh, d, li, m, ks[k], eo);
+                        const bool sw = key_less(cd, co, cs, kd[k], eo, ks[k] < 0 ? 0x7fffffff : ks[k]);
+                        const double td = sw ? kd[k] : cd, to = sw ? eo : co; const int ts = sw ? ks[k] : cs;
+                        kd[k] = sw ? cd : kd[k]; ks[k] = sw ? cs : ks[k];
+                        cd = td; co = to; cs = ts;
+                    }
                 }
             }
 #pragma unroll
-        for (int k = 0; k < NNB; k++) { r.kr[k] = ks[k]; r.kv[k] = (ks[k] >= 0) ? kc[k] : 0.0; }
+        for (int k = 0; k < NNB; k++) {
+            double vo = 0;
+            const int x = ks[k];
+            if (x >= 0) {
+                member(g, sh, d, li, m, x, vo);
+                if (fix && sh.route_of[x] == opp) vo = adjusted(g, sh, m, ls, le, t, vo);
+            }
+            r.kr[k] = x; r.kv[k] = vo;
+        }
         r.hdr = bslot;                                                                  // ref :1348-1354
         r.vir_dis = (bslot >= 0) ? (me - bvc) : 100.0;
         sh.hdr[t] = (int16_t)bslot;
