@@ -14,13 +14,14 @@ import json
 import numpy as np
 import torch
 
-from .arrivals import load_arrival_mat, pad_stream, synthetic_arrivals
+from .arrivals import load_arrival_mat, pad_stream, synthetic_arrivals, synthetic_intentions
 from .batched import BatchedIntersections
 
 
-def evaluate(arrivals, weights, ticks=1000, n_envs=1, capacity=128, device="cuda", **config):
-    """-> dict with the quantities main.py prints at the end of test() (main.py:523-526)."""
-    env = BatchedIntersections(n_envs, capacity, arrivals, device=device,
+def evaluate(arrivals, weights, ticks=1000, n_envs=1, capacity=128, device="cuda", intentions=None, **config):
+    """-> dict with the quantities main.py prints at the end of test() (main.py:523-526).
+    config: reference constructor arguments (vm, lane_num = 12 | 8 | 4, ...; main.py --lane_num, :101)."""
+    env = BatchedIntersections(n_envs, capacity, arrivals, device=device, intentions=intentions,
                                outputs=("obs_post", "reward", "flags", "env_out"), **config)
     env.set_actor(weights)
     env.reset()
@@ -47,14 +48,24 @@ def main():
     ap.add_argument("--envs", type=int, default=1)
     ap.add_argument("--capacity", type=int, default=128)
     ap.add_argument("--vm", type=float, default=5.0)
+    ap.add_argument("--lane-num", type=int, default=12, choices=(12, 8, 4), help="main.py --lane_num (:101)")
+    ap.add_argument("--seed", type=int, default=20250213, help="synthetic streams / 8-lane intention draws")
     a = ap.parse_args()
     z = np.load(a.weights)
     weights = {k: z[k] for k in z.files}
     if a.mat:
         arr = pad_stream(load_arrival_mat(a.mat))
     else:
-        arr = synthetic_arrivals(a.envs, rate=a.synthetic or 1000.0, horizon_s=a.ticks * 0.1 + 30)
-    res = evaluate(arr, weights, ticks=a.ticks, n_envs=a.envs, capacity=a.capacity, vm=a.vm)
+        arr = synthetic_arrivals(a.envs, rate=a.synthetic or 1000.0, horizon_s=a.ticks * 0.1 + 30, seed=a.seed,
+                                 lane_num=a.lane_num)
+    if arr.shape[-1] != a.lane_num:
+        ap.error("the arrival stream has %d columns, --lane-num is %d" % (arr.shape[-1], a.lane_num))
+    draws = None
+    if a.lane_num == 8:                        # the reference draws them with random.randint (ref :390)
+        draws = synthetic_intentions(a.envs, arr.shape[-2], seed=a.seed)
+        draws = draws if arr.ndim == 3 else draws[0]
+    res = evaluate(arr, weights, ticks=a.ticks, n_envs=a.envs, capacity=a.capacity, vm=a.vm, lane_num=a.lane_num,
+                   intentions=draws)
     print("vehicle number: %d; collisions occurred number: %d; collisions rate: %s" % (
         res["vehicles"], res["collisions"], res["collisions_rate"]))
     print("pT-m: %.3f s; mean jerk: %.3f; lock_num: %d; mean reward: %.4f" % (
