@@ -228,7 +228,7 @@ def main(argv=None, env_factory=None):
         }
         if args.actor:
             line["roofline"]["note"] = "kernel_ms = k_actor + k_tick per step; achieved uses the tick's algorithmic bytes only"
-        if not args.no_cpu_baseline and not args.actor:
+        if not args.no_cpu_baseline and not args.actor and world == 1:      # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, min(W, 300), min(K, 200), lane_num, choice)
         print(json.dumps(line), flush=True)
     if world > 1:
