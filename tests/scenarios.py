@@ -330,3 +330,47 @@ def check_geo_fuzz_vs_oracle(backend, lane_num, n_envs, capacity, ticks, rate, s
         assert np.array_equal(got, ointent), "intentions / routes, env %d" % e
     assert b.metrics()["overflow"] == 0
     return tot_coll, tot_lock
+
+
+def check_geo_overflow_and_empty(backend, lane_num):
+    """4- / 8-lane edge cases: a full env defers spawns (cursor, intention counter and ids stay consistent); an
+    empty stream only advances the clock; an exhausted stream stops spawning."""
+    from oracle.oracle_geo import OracleGeoEnv
+    rows = 300
+    arr = np.full((rows, lane_num), np.inf)
+    arr[:rows - 1, :] = (np.arange(rows - 1)[:, None] * 0.6 + 1.0)       # one vehicle per lane every 0.6 s
+    ch = (np.arange(rows * lane_num).reshape(rows, lane_num) % 2).astype(np.int32) if lane_num == 8 else None
+    b = make_batch(arr, 1, 64, backend, lane_num=lane_num, intentions=ch, outputs=("obs_post", "env_out", "flags"))
+    b.reset()
+    seen_over = False
+    for t in range(260):
+        b.step(None)
+        info = b.read_env(0)
+        assert 0 <= info.n_alive <= 64 and sum(info.lane_count) == info.n_alive
+        assert all(c == 0 for c in list(info.lane_count)[lane_num:])
+        seen_over = seen_over or info.overflow > 0
+    assert seen_over, "the scenario was meant to overflow a 64-slot env"
+    vs = b.read_vehicles(0)
+    assert len({v.id for v in vs}) == len(vs)
+    assert all(0 <= v.route < b.dir_num and 0 <= v.intention <= 2 for v in vs)
+    # empty stream
+    e = make_batch(np.full((4, lane_num), np.inf), 2, 64, backend, lane_num=lane_num, outputs=("obs_post", "env_out"))
+    e.reset()
+    t0 = e.read_env(0).current_time
+    for _ in range(5):
+        e.step(None)
+    assert e.read_env(1).n_alive == 0 and abs(e.read_env(1).current_time - (t0 + 0.5)) < 1e-9
+    # exhausted stream: two vehicles on lane 1, then nothing; same life cycle as the oracle
+    arr2 = np.full((3, lane_num), np.inf)
+    arr2[0, 1], arr2[1, 1] = 0.35, 0.95
+    ch2 = np.ones((3, lane_num), np.int32) if lane_num == 8 else None
+    x = make_batch(arr2, 1, 64, backend, lane_num=lane_num, intentions=ch2, outputs=("obs_post", "env_out"))
+    x.reset()
+    orc = OracleGeoEnv(arr2, lane_num, choice=ch2)
+    for t in range(450):
+        x.step(None)
+        orc.tick(np.zeros(orc.n_alive))
+    info = x.read_env(0)
+    assert list(info.veh_rec)[1] == 2 and info.id_seq == 2 and info.n_alive == orc.n_alive
+    assert info.passed_veh == 2 or lane_num == 8      # 8-lane lane 1 = straight / right: both pass as well
+    assert info.passed_veh == 2

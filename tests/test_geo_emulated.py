@@ -44,3 +44,8 @@ def test_geo_fuzz_random_tapes(lane_num, rate, cap, quant, seed):
     coll, lock = scenarios.check_geo_fuzz_vs_oracle(BACKEND, lane_num, n_envs=4, capacity=cap, ticks=300, rate=rate,
                                                     seed=seed, quantize=quant)
     assert coll > 0 and lock > 0
+
+
+@pytest.mark.parametrize("lane_num", [4, 8])
+def test_geo_overflow_empty_exhausted(lane_num):
+    scenarios.check_geo_overflow_and_empty(BACKEND, lane_num)

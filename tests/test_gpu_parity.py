@@ -213,3 +213,42 @@ def test_gpu_compat_class_4_and_8_lanes(name, ticks):
     from tests.test_compat_class import run_compat
     env = run_compat(name, ticks, "hip")
     assert env.lane_num in (4, 8) and env.id_seq > 0
+
+
+@pytest.mark.parametrize("lane_num", [4, 8])
+def test_gpu_geo_overflow_empty_exhausted(lane_num):
+    scenarios.check_geo_overflow_and_empty(BACKEND, lane_num)
+
+
+def test_gpu_geo_full_size_invariants():
+    """4096 8-lane envs x 128 slots: the result does not depend on the workgroup index (env e == env e + 2048 on
+    equal streams and draws), ids are unique, lane counts add up, spawned = alive + deleted."""
+    from pve_mcc_amd.arrivals import synthetic_arrivals, synthetic_intentions
+    half = 2048
+    arr = synthetic_arrivals(half, rate=1500.0, horizon_s=40.0, seed=77, lane_num=8)
+    ch = synthetic_intentions(half, arr.shape[1], seed=77)
+    arr, ch = np.concatenate([arr, arr], 0), np.concatenate([ch, ch], 0)
+    b = make_batch(arr, 2 * half, 128, BACKEND, lane_num=8, intentions=ch,
+                   outputs=("obs_post", "reward", "flags", "env_out", "new_slot"))
+    b.reset()
+    g = torch.Generator().manual_seed(6)
+    deleted = torch.zeros(2 * half, dtype=torch.int64, device="cuda")
+    for t in range(200):
+        a = (torch.rand(half, 128, generator=g, dtype=torch.float64) * 4 - 2)
+        out = b.step(torch.cat([a, a], 0).cuda())
+        deleted += out["env_out"][:, 4].long()
+    for k in ("p", "v", "a", "jerk_sum", "id", "meta", "step"):
+        x = b.state_field(k)
+        assert torch.equal(x[:half], x[half:]), "state %s depends on the workgroup index" % k
+    ids = b.state_field("id").cpu().numpy()
+    meta = b.state_field("meta").cpu().numpy()
+    for e in list(range(0, half, 131)) + [half - 1]:
+        info = b.read_env(e)
+        n = info.n_alive
+        assert sum(info.lane_count) == n and all(c == 0 for c in list(info.lane_count)[8:])
+        assert np.all((meta[e, :n] & 0x80) != 0) and np.all(meta[e, n:] == 0)
+        assert len(set(ids[e, :n].tolist())) == n
+        assert info.id_seq == n + int(deleted[e].item()), "conservation violated in env %d" % e
+        assert info.intention_re == info.id_seq                       # one draw per spawn (ref :392)
+    m = b.metrics()
+    assert m["ticks"] == 200 * 2 * half and m["overflow"] == 0
