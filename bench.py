@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_ALG_FP64 = 380.0      # algorithmic bytes per vehicle-slot-step, FP64 layout
+B_ALG_OBS_F32 = 268.0   # the same with float32 observation rows (--obs-f32): 380 - 28 x 4 (SURVEY.md §8d, FP32 output)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
 N_POOL = 16
 
@@ -110,6 +111,9 @@ def main(argv=None, env_factory=None):
     ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
     ap.add_argument("--lane-num", type=int, default=12, choices=(12, 8, 4),
                     help="intersection layout; 12 = BASELINE metric (k_tick), 4 / 8 = SURVEY 8 f4 (k_tick_geo)")
+    ap.add_argument("--obs-f32", action="store_true",
+                    help="float32 observation rows (PVE_CFG_OBS_F32; SURVEY 8d's FP32-output variant, 268 B algorithmic); "
+                         "the headline / BASELINE metric is the float64 parity layout (380 B)")
     ap.add_argument("--actor", action="store_true",
                     help="BASELINE config 5: close the loop on the device (k_actor -> k_tick per step) instead of the action pool")
     args = ap.parse_args(argv)
@@ -155,7 +159,8 @@ def main(argv=None, env_factory=None):
         env = env_factory(n_envs, cap, arr, outputs)
     else:
         env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs, lane_num=lane_num,
-                                               intentions=choice)
+                                               intentions=choice,
+                                               obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
     pool = torch.as_tensor(pool_np, device=dev)
     env.reset()
     if args.actor:
@@ -203,8 +208,9 @@ def main(argv=None, env_factory=None):
         slot_steps = float(cap) * n_envs * K * world
         value = slot_steps / wall
         kern_s = gpu_ms * 1e-3 / K
-        achieved = B_ALG_FP64 * cap * n_envs / kern_s / 1e9
-        traffic, traffic_src = pmc_traffic(n_envs, cap, outputs, args.actor or lane_num != 12)
+        b_alg = B_ALG_OBS_F32 if args.obs_f32 else B_ALG_FP64
+        achieved = b_alg * cap * n_envs / kern_s / 1e9
+        traffic, traffic_src = pmc_traffic(n_envs, cap, outputs, args.actor or lane_num != 12 or args.obs_f32)
         line = {
             "metric": "env-steps/sec (vehicles x envs x steps/s) at 128 veh x 4096 envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -215,7 +221,7 @@ def main(argv=None, env_factory=None):
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
                                       if args.actor else "sin action pool"),
                        "envs_per_gpu": n_envs, "capacity": cap, "parallelism": "env-parallel x%d" % world,
-                       "outputs": list(outputs)},
+                       "outputs": list(outputs), "obs_dtype": "f32" if args.obs_f32 else "f64"},
             "alive_steps_per_s": tot["alive_steps"] / wall,
             "ctl_steps_per_s": tot["ctl_steps"] / wall,
             "mean_alive_per_env": tot["alive_steps"] / (K * n_envs * world),
@@ -224,7 +230,7 @@ def main(argv=None, env_factory=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "kernel": ("k_tick<%d>" if lane_num == 12 else "k_tick_geo<%d>") % cap, "kernel_ms": kern_s * 1e3,
-                         "alg_bytes_per_slot_step": B_ALG_FP64},
+                         "alg_bytes_per_slot_step": b_alg},
         }
         if args.actor:
             line["roofline"]["note"] = "kernel_ms = k_actor + k_tick per step; achieved uses the tick's algorithmic bytes only"

@@ -47,6 +47,10 @@ enum {
  * args.collision_thr (ref :32).  lane_num = 12 runs the optimised kernel (BASELINE metric); lane_num = 4 or 8
  * (ref :66-145) run the general-geometry kernel.  The 3-lane branch is broken upstream. */
 #define PVE_CFG_GENERAL_PATH 0x1   /* flags: use the general-geometry kernel for lane_num = 12 too (cross-checks) */
+#define PVE_CFG_OBS_F32      0x2   /* flags: pve_outputs.obs_post and the actor's obs input hold float32 [n_envs][cap][28]
+                                      (the type the actor consumes, model_agent_maddpg.py:15; SURVEY.md 8d "FP32 observation
+                                      output": 268 instead of 380 algorithmic bytes per slot-step).  Fused ticks only:
+                                      obs_pre / state_pre / pve_compact(obs) stay float64 and are refused with this flag. */
 typedef struct pve_config {
     double deltaT;          /* 0.1 */
     double vm, vM;          /* 5, 13   (train(): vm = 6, main.py:230) */
@@ -64,7 +68,7 @@ typedef struct pve_config {
  * the reference reports in `ids`, ref :291); "post" arrays by the slot it has after compaction
  * and spawning (= where the next tick's action for it must be written). */
 typedef struct pve_outputs {
-    double  *obs_post;      /* [n_envs][cap][28]  row 0 of the state (ref :1336) of the vehicle now in
+    double  *obs_post;      /* [n_envs][cap][28]  (float32 rows with PVE_CFG_OBS_F32) row 0 of the state (ref :1336) of the vehicle now in
                                each slot; zeros for vehicles spawned this tick (ref :380,420) */
     double  *obs_pre;       /* [n_envs][cap][28]  same rows, pre-compaction indexing (`re_state[k][0]`) */
     double  *state_pre;     /* [n_envs][cap][7][28] full state incl. neighbour rows (ref :1325-1337);
@@ -174,12 +178,13 @@ int pve_compact(pve_handle h, double *obs_post /* optional: rows are moved with 
  * layouts, checkpoint names `agent1actor/...`).  obs: [n_envs][cap][28] float64 (= obs_post of the previous
  * tick, zeros after reset); actions: [n_envs][cap] float64 out. */
 #define PVE_ACTOR_N_WEIGHTS 6393
-int pve_actor_forward(pve_handle h, const float *weights, const double *obs, double *actions);
+int pve_actor_forward(pve_handle h, const float *weights, const void *obs /* float64, or float32 with PVE_CFG_OBS_F32 */,
+                      double *actions);
 
 /* Closed loop on the device, no host round trip: pve_actor_forward(obs_in -> actions) followed by
  * pve_step_all(actions, out) on the same stream (BASELINE config 5).  out->obs_post may be obs_in itself (the tick
  * never reads observations) unless out->state_pre is requested, which needs the previous rows (obs_prev_post). */
-int pve_step_all_actor(pve_handle h, const float *weights, const double *obs_in, double *actions,
+int pve_step_all_actor(pve_handle h, const float *weights, const void *obs_in, double *actions,
                        const pve_outputs *out);
 
 /* Host read-back (synchronises the stream). */

@@ -38,10 +38,12 @@ class BatchedIntersections:
               random.randint(0, 1) draws (ref :390) as an input stream (None = zeros).
     config:   reference constructor arguments (lane_num = 12 | 8 | 4, vm, ...); general_path=True runs the
               general-geometry kernel for lane_num = 12 too (cross-checks).
+    obs_dtype: torch.float64 (reference parity layout) or torch.float32 (the actor's input type: the largest output
+              shrinks by half; fused ticks only, no obs_pre / state_pre).
     """
 
     def __init__(self, n_envs, capacity, arrivals, device=None, outputs=DEFAULT_OUTPUTS, stream=None,
-                 intentions=None, _lib=None, **config):
+                 intentions=None, obs_dtype=torch.float64, _lib=None, **config):
         if device is None:
             device = "cuda"
         self.device = torch.device(device)
@@ -54,6 +56,11 @@ class BatchedIntersections:
         self.n_envs, self.capacity = int(n_envs), int(capacity)
         if config.pop("general_path", False):
             config["flags"] = int(config.get("flags", 0)) | _capi.CFG_GENERAL_PATH
+        if obs_dtype not in (torch.float64, torch.float32):
+            raise TypeError("obs_dtype must be torch.float64 or torch.float32")
+        self.obs_dtype = obs_dtype
+        if obs_dtype == torch.float32:
+            config["flags"] = int(config.get("flags", 0)) | _capi.CFG_OBS_F32
         self.cfg = make_config(self.lib, **config)
         self.lane_num = int(self.cfg.lane_num)
         self.dir_num = _capi.DIR_NUM.get(self.lane_num, 12)
@@ -85,7 +92,7 @@ class BatchedIntersections:
             # state_pre reads the rows the previous tick stored (stale neighbour rows, ref :1332): ping-pong pair.
             # Otherwise ONE buffer: the tick never reads observations, and 117 MB less working set per 4096 envs
             # keeps more of the tick's traffic in the 256 MB Infinity Cache (57.2 vs 59.1 us per tick).
-            self._obs = [torch.zeros(E, K, 28, dtype=torch.float64, device=dev)
+            self._obs = [torch.zeros(E, K, 28, dtype=obs_dtype, device=dev)
                          for _ in range(2 if "state_pre" in names else 1)]
             self._obs_cur = 0
         shapes = dict(obs_pre=((E, K, 28), torch.float64), state_pre=((E, K, 7, 28), torch.float64),

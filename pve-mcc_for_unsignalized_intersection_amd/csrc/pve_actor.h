@@ -51,8 +51,8 @@ __device__ __forceinline__ void layer_norm_relu(float (&h)[N], const float *gamm
         _Pragma("unroll") for (int j = 0; j < ACT_H; j++) ACC[j] = fmaf(xi, wr[j], ACC[j]);   \
     }
 
-template <int CAP>
-__global__ __launch_bounds__(64) void k_actor(const float *__restrict__ W, const double *__restrict__ obs,
+template <int CAP, typename OBS_T>
+__global__ __launch_bounds__(64) void k_actor(const float *__restrict__ W, const OBS_T *__restrict__ obs,
                                               const int32_t *__restrict__ meta, double *__restrict__ actions,
                                               int n_envs)
 {
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void k_actor(const float *__restrict__ W, const
         // ---- input row (veh["state"][0], float64 in HBM -> float32 like the TF placeholder)
         float x[ACT_IN];
         {
-            const double *row = obs + (base + slot) * OBSW;
+            const OBS_T *row = obs + (base + slot) * OBSW;
 #pragma unroll
             for (int k = 0; k < ACT_IN; k++) x[k] = (float)row[k];
         }
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(64) void k_actor(const float *__restrict__ W, const
 // One wave64 per intersection; 64 controlled vehicles (2 row tiles of 32) per pass; 184 MFMAs per pass.
 typedef float pve_v16f __attribute__((ext_vector_type(16)));
 
-template <int CAP>
-__global__ __launch_bounds__(64) void k_actor_mfma(const float *__restrict__ W, const double *__restrict__ obs,
+template <int CAP, typename OBS_T>
+__global__ __launch_bounds__(64) void k_actor_mfma(const float *__restrict__ W, const OBS_T *__restrict__ obs,
                                                    const int32_t *__restrict__ meta, double *__restrict__ actions,
                                                    int n_envs)
 {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void k_actor_mfma(const float *__restrict__ W, 
             pve_v16f acc[2];
             // ---- layer 1: LayerNorm(28) -> dense 28x64.  Lane holds features k = 2s + hi of vehicle v0 + lo.
             {
-                const double *row = obs + (base + slot) * OBSW;
+                const OBS_T *row = obs + (base + slot) * OBSW;
                 float x[ACT_IN / 2], sum = 0.f;
 #pragma unroll
                 for (int s = 0; s < ACT_IN / 2; s++) { x[s] = (float)row[2 * s + hi]; sum += x[s]; }

@@ -255,20 +255,27 @@ struct Backend {
         else hipLaunchKernelGGL(k_compact<128>, dim3(P.n_envs), dim3(128), 0, s, P);
         return check_launch(err);
     }
-    static int launch_actor(const float *W, const double *obs, const int32_t *meta, double *actions, int n_envs,
-                            int cap, void *stream, std::string &err)
+    template <typename OBS_T>
+    static void launch_actor_t(const float *W, const OBS_T *obs, const int32_t *meta, double *actions, int n_envs, int cap,
+                               hipStream_t s)
     {
-        hipStream_t s = (hipStream_t)stream;
         static const bool valu = getenv("PVE_ACTOR_VALU") != nullptr;    // A/B knob: the scalar-broadcast VALU kernel
         if (valu) {
-            if (cap == 64) hipLaunchKernelGGL(k_actor<64>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
-            else hipLaunchKernelGGL(k_actor<128>, dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+            if (cap == 64) hipLaunchKernelGGL((k_actor<64, OBS_T>), dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+            else hipLaunchKernelGGL((k_actor<128, OBS_T>), dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
         } else {
             // persistent waves (the 92 weight VGPRs are loaded once per wave): 256 CUs x 8 waves
             const int grid = n_envs < actor_grid ? n_envs : actor_grid;
-            if (cap == 64) hipLaunchKernelGGL(k_actor_mfma<64>, dim3(grid), dim3(64), 0, s, W, obs, meta, actions, n_envs);
-            else hipLaunchKernelGGL(k_actor_mfma<128>, dim3(grid), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+            if (cap == 64) hipLaunchKernelGGL((k_actor_mfma<64, OBS_T>), dim3(grid), dim3(64), 0, s, W, obs, meta, actions, n_envs);
+            else hipLaunchKernelGGL((k_actor_mfma<128, OBS_T>), dim3(grid), dim3(64), 0, s, W, obs, meta, actions, n_envs);
         }
+    }
+    static int launch_actor(const float *W, const void *obs, int obs_f32, const int32_t *meta, double *actions, int n_envs,
+                            int cap, void *stream, std::string &err)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        if (obs_f32) launch_actor_t<float>(W, (const float *)obs, meta, actions, n_envs, cap, s);
+        else launch_actor_t<double>(W, (const double *)obs, meta, actions, n_envs, cap, s);
         return check_launch(err);
     }
     static int launch_probe(const Params &P, int cap, int *sink, void *stream, std::string &err)

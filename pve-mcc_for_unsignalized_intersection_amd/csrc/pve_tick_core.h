@@ -900,7 +900,10 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             for (unsigned rem = sp; rem; rem &= rem - 1) {
                 const int l = __builtin_ctz(rem);
                 const int slot = mask_below<NW>(keep, sh.hd.lane_start[l + 1]) + __builtin_popcount(sp & ((1u << l) - 1u));
-                if (t < OBSW) P.out.obs_post[((size_t)env * CAP + slot) * OBSW + t] = 0.0;
+                if (t < OBSW) {
+                    if (P.obs_f32) ((float *)P.out.obs_post)[((size_t)env * CAP + slot) * OBSW + t] = 0.0f;
+                    else P.out.obs_post[((size_t)env * CAP + slot) * OBSW + t] = 0.0;
+                }
             }
         }
         // ---- clear the tail so stale slots never look alive
@@ -975,9 +978,15 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 for (int k = 0; k < OBSW; k++) o[k] = row[k];
             }
             if (P.out.obs_post && new_slot >= 0) {
-                double *o = P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+                if (P.obs_f32) {                    // uniform: float32 rows (half the bytes of the largest output)
+                    float *o = (float *)P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
 #pragma unroll
-                for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                    for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
+                } else {
+                    double *o = P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+#pragma unroll
+                    for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                }
             }
         }
     }

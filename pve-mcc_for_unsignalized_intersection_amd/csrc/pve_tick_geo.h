@@ -431,9 +431,9 @@ template <int CAP> struct TickGeo {
             nv.step = 0; nv.count = 0;
             Base::store_slot(P, (size_t)env * CAP + slot, nv,
                              M_CONTROL | M_ALIVE | (LN == 12 ? 0 : (intention << M_INT_SHIFT)), -1);   // 12-lane: lane % 3, not stored
-            if (P.out.obs_post) {
-                double *o = P.out.obs_post + ((size_t)env * CAP + slot) * OBSW;
-                for (int k = 0; k < OBSW; k++) o[k] = 0.0;                             // ref :380, :420
+            if (P.out.obs_post) {                                                      // ref :380, :420
+                if (P.obs_f32) { float *o = (float *)P.out.obs_post + ((size_t)env * CAP + slot) * OBSW; for (int k = 0; k < OBSW; k++) o[k] = 0.0f; }
+                else { double *o = P.out.obs_post + ((size_t)env * CAP + slot) * OBSW; for (int k = 0; k < OBSW; k++) o[k] = 0.0; }
             }
             const int rec1 = sh.hd.veh_rec[t] + 1;
             gh.veh_rec[t] = rec1;
@@ -508,9 +508,15 @@ template <int CAP> struct TickGeo {
                 for (int k = 0; k < OBSW; k++) o[k] = row[k];
             }
             if (P.out.obs_post && new_slot >= 0) {
-                double *o = P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+                if (P.obs_f32) {
+                    float *o = (float *)P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
 #pragma unroll
-                for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                    for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
+                } else {
+                    double *o = P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+#pragma unroll
+                    for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                }
             }
         }
     }

@@ -68,3 +68,23 @@ def check_closed_loop_on_device(backend, ticks=1000):
     pt_m = m["passed_steps"] / (m["passed"] + 1e-4) * 0.1
     assert abs(pt_m - 12.294) < 0.15, pt_m
     return m
+
+
+def check_closed_loop_f32_obs_equals_f64(backend, ticks=300, n_envs=4):
+    """PVE_CFG_OBS_F32: the actor casts its input to float32 anyway (model_agent_maddpg.py:15), so the closed loop on
+    float32 observation rows is bit-identical to the closed loop on float64 rows."""
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    w = flat_weights(load_weights())
+    arr = synthetic_arrivals(n_envs, rate=1000.0, horizon_s=ticks * 0.1 + 30, seed=3)
+    outs = ("obs_post", "reward", "flags", "env_out")
+    b64 = make_batch(arr, n_envs, 128, backend, outputs=outs)
+    b32 = make_batch(arr, n_envs, 128, backend, outputs=outs, obs_dtype=torch.float32)
+    for b in (b64, b32):
+        b.reset()
+        b.set_actor(w)
+    for t in range(ticks):
+        o64, o32 = b64.step_with_actor(), b32.step_with_actor()
+        assert np.array_equal(_np(o64["reward"]), _np(o32["reward"])), "tick %d" % t
+    for k in ("p", "v", "a", "id", "meta", "step"):
+        assert np.array_equal(_np(b64.state_field(k)), _np(b32.state_field(k))), k
+    assert b64.metrics() == b32.metrics()

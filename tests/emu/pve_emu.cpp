@@ -130,13 +130,15 @@ struct Backend {
             h[k] = relu ? fmaxf(y, 0.f) : y;
         }
     }
-    static int launch_actor(const float *W, const double *obs, const int32_t *meta, double *actions, int n_envs,
+    static int launch_actor(const float *W, const void *obs_v, int obs_f32, const int32_t *meta, double *actions, int n_envs,
                             int cap, void *, std::string &)
     {
+        const double *obs = (const double *)obs_v;
+        const float *obsf = (const float *)obs_v;
         for (size_t s = 0; s < (size_t)n_envs * cap; s++) {
             if ((meta[s] & (M_ALIVE | M_CONTROL)) != (M_ALIVE | M_CONTROL)) { actions[s] = 0.0; continue; }
             float x[ACT_IN], h[ACT_H], g[ACT_H];
-            for (int k = 0; k < ACT_IN; k++) x[k] = (float)obs[s * OBSW + k];
+            for (int k = 0; k < ACT_IN; k++) x[k] = obs_f32 ? obsf[s * OBSW + k] : (float)obs[s * OBSW + k];
             ln(x, ACT_IN, W + AW_LN0_G, W + AW_LN0_B, false);
             for (int j = 0; j < ACT_H; j++) h[j] = W[AW_B1 + j];
             for (int i = 0; i < ACT_IN; i++) for (int j = 0; j < ACT_H; j++) h[j] = fmaf(x[i], W[AW_W1 + i * ACT_H + j], h[j]);

@@ -374,3 +374,37 @@ def check_geo_overflow_and_empty(backend, lane_num):
     assert list(info.veh_rec)[1] == 2 and info.id_seq == 2 and info.n_alive == orc.n_alive
     assert info.passed_veh == 2 or lane_num == 8      # 8-lane lane 1 = straight / right: both pass as well
     assert info.passed_veh == 2
+
+
+def check_obs_f32(backend, lane_num=12, n_envs=3, capacity=128, ticks=120, seed=41):
+    """PVE_CFG_OBS_F32: the float32 observation rows are exactly float32(float64 rows), the dynamics do not change,
+    the float64-only outputs are refused."""
+    from pve_mcc_amd.arrivals import synthetic_intentions
+    from pve_mcc_amd._capi import PveError
+    rng = np.random.default_rng(seed)
+    rate = {12: 1100.0, 8: 1500.0, 4: 1800.0}[lane_num]
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed, lane_num=lane_num)
+    ch = synthetic_intentions(n_envs, arr.shape[1], seed=seed) if lane_num == 8 else None
+    outs = ("obs_post", "reward", "flags", "env_out", "new_slot")
+    b64 = make_batch(arr, n_envs, capacity, backend, outputs=outs, lane_num=lane_num, intentions=ch)
+    b32 = make_batch(arr, n_envs, capacity, backend, outputs=outs, lane_num=lane_num, intentions=ch,
+                     obs_dtype=torch.float32)
+    assert b32.obs.dtype == torch.float32 and b32.obs.shape == (n_envs, capacity, 28)
+    b64.reset(); b32.reset()
+    for t in range(ticks):
+        a = torch.as_tensor(rng.uniform(-2, 2, size=(n_envs, capacity))).to(b64.device)
+        o64, o32 = b64.step(a), b32.step(a)
+        assert np.array_equal(_np(o64["reward"]), _np(o32["reward"])) and np.array_equal(_np(o64["flags"]), _np(o32["flags"]))
+        ctl = (_np(b64.state_field("meta")) & 1) != 0
+        x64, x32 = _np(b64.obs)[ctl], _np(b32.obs)[ctl]
+        assert np.array_equal(x64.astype(np.float32), x32), "tick %d: float32 rows are not float32(float64 rows)" % t
+    for k in STATE_F + STATE_I:
+        assert np.array_equal(_np(b64.state_field(k)), _np(b32.state_field(k))), k
+    try:
+        bad = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre"), lane_num=lane_num,
+                         intentions=ch, obs_dtype=torch.float32)
+        bad.reset()
+        bad.step(None)
+        raise AssertionError("obs_pre must be refused with float32 observations")
+    except PveError:
+        pass

@@ -59,3 +59,7 @@ def test_evaluate_protocol_known_answers(monkeypatch):
     assert (res["vehicles"], res["passed"], res["collisions"], res["lock_num"]) == (323, 281, 0, 548)
     assert abs(res["pT_m"] - 12.294) < 1e-3 and abs(res["jerk_mean"] - 208.799) < 1e-2
     assert abs(res["reward_mean"] - 1.30294) < 1e-4
+
+
+def test_closed_loop_on_float32_observations_is_bit_identical():
+    A.check_closed_loop_f32_obs_equals_f64("emu", ticks=150, n_envs=2)

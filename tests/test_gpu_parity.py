@@ -252,3 +252,13 @@ def test_gpu_geo_full_size_invariants():
         assert info.intention_re == info.id_seq                       # one draw per spawn (ref :392)
     m = b.metrics()
     assert m["ticks"] == 200 * 2 * half and m["overflow"] == 0
+
+
+def test_gpu_float32_observation_rows():
+    scenarios.check_obs_f32(BACKEND, lane_num=12, n_envs=8, ticks=200)
+    scenarios.check_obs_f32(BACKEND, lane_num=4, n_envs=8, capacity=64, ticks=200)
+
+
+def test_gpu_closed_loop_on_float32_observations_is_bit_identical():
+    from tests import actor_scenarios as A
+    A.check_closed_loop_f32_obs_equals_f64("hip", ticks=400, n_envs=16)

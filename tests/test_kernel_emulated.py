@@ -52,3 +52,8 @@ def test_empty_env_and_exhausted_stream():
 
 def test_reset_replays_the_same_episode():
     scenarios.check_reset_reproducible(BACKEND)
+
+
+def test_float32_observation_rows():
+    scenarios.check_obs_f32(BACKEND, lane_num=12)
+    scenarios.check_obs_f32(BACKEND, lane_num=8, ticks=80)
