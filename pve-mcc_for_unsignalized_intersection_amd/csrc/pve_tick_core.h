@@ -364,8 +364,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         const size_t g = (size_t)env * CAP + t;
         r.alive = t < N;
         r.jerk = 0;
-        {   // unconditional (slots >= N hold zeros / stale values that are never used): the loads do not
-            // wait for n_alive, one memory latency instead of two
+        r.p = r.v = r.a = r.jerk_sum = r.vir_dis = r.closer_p = 0;
+        r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
+        // First wave: unconditional (slots >= N hold zeros / stale values that are never used), so that the loads do
+        // not wait for n_alive: one memory latency instead of two on the critical path.  Later waves (slots >= 64) are
+        // off the critical path and mostly empty: they wait for n_alive and read the live slots only.
+        if (t < 64 || t < N) {
             r.p = P.f64[F_P][g]; r.v = P.f64[F_V][g]; r.a = P.f64[F_A][g];
             r.jerk_sum = P.f64[F_JERK_SUM][g]; r.vir_dis = P.f64[F_VIR_DIS][g];
             r.closer_p = P.f64[F_CLOSER_P][g];
