@@ -63,7 +63,9 @@ typedef struct pve_config {
     int32_t flags;          /* PVE_CFG_* */
 } pve_config;
 
-/* Per-tick outputs.  Every pointer may be NULL (that output is skipped).
+/* Per-tick outputs.  Every pointer may be NULL (that output is skipped).  `flags` is written for every slot (0 = the
+ * slot held no vehicle); the other per-slot outputs are written only for the slots that held a vehicle at tick start
+ * (slots < env_out[PVE_EO_N_PRE]) and are unspecified elsewhere.
  * "pre" arrays are indexed by the slot a vehicle had when the tick started (= the `[lane, j]`
  * the reference reports in `ids`, ref :291); "post" arrays by the slot it has after compaction
  * and spawning (= where the next tick's action for it must be written). */
@@ -77,7 +79,8 @@ typedef struct pve_outputs {
     double  *reward;        /* [n_envs][cap]  pre; 0 for uncontrolled slots (ref :311-320, 346, 357) */
     int32_t *flags;         /* [n_envs][cap]  pre; PVE_F_* bits | collisions_per_veh << 8 (ref :339) */
     int32_t *lanej;         /* [n_envs][cap]  pre; lane << 16 | j  (the `ids` entry, ref :291) */
-    int32_t *nbr;           /* [n_envs][cap][6] pre; lane << 16 | j of the 6 nearest, -1 = none (ref :1391-1405) */
+    int32_t *nbr;           /* [n_envs][cap][6] pre; lane << 16 | j of the 6 nearest, -1 = none (ref :1391-1405);
+                               written for controlled vehicles (PVE_F_CTL) only */
     int32_t *new_slot;      /* [n_envs][cap]  pre -> post slot, -1 if deleted this tick (ref :435-444) */
     int32_t *env_out;       /* [n_envs][PVE_ENV_OUT_N] per-env scalars of this tick, see PVE_EO_* */
 } pve_outputs;

@@ -182,6 +182,8 @@ class BatchedIntersections:
         if self._obs is not None:
             for o in self._obs:
                 o.zero_()
+        for o in self.out.values():       # per-slot outputs of empty slots are not rewritten by the ticks
+            o.zero_()
         self.ticks = 0
         self._is_reset = True
 

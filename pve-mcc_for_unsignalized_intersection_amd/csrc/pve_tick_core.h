@@ -814,12 +814,20 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // writes +1 then -1; a vehicle is never its own predecessor, so cycles have length >= 2.
 
     // ============================================================== FIN: re-pack + write-back
-    template <class R> static PVE_HD void store_slot(const PVE_AS4 Params &P, size_t g, const R &r, int meta, int hdr_word)
+    // Bytes are time in the store burst of FIN, so a vehicle that keeps its slot does not rewrite what
+    // cannot have changed: with_ids = false skips the immutable fields (id, seq_in_lane, id_info[1]); with_carry = false
+    // (it was not controlled this tick either) also skips jerk_sum / vir_dis / closer_p / count, which only the
+    // controlled branch of scene_update touches (ref :292, :302, :321, :1348-1354).
+    template <class R> static PVE_HD void store_slot(const PVE_AS4 Params &P, size_t g, const R &r, int meta, int hdr_word,
+                                                     bool with_ids = true, bool with_carry = true)
     {
         P.f64[F_P][g] = r.p; P.f64[F_V][g] = r.v; P.f64[F_A][g] = r.a; P.f64[F_JERK][g] = r.jerk;
-        P.f64[F_JERK_SUM][g] = r.jerk_sum; P.f64[F_VIR_DIS][g] = r.vir_dis; P.f64[F_CLOSER_P][g] = r.closer_p;
-        P.i32[I_ID][g] = r.id; P.i32[I_SEQ][g] = r.seq; P.i32[I_VNUM][g] = r.vnum;
-        P.i32[I_STEP][g] = r.step; P.i32[I_COUNT][g] = r.count; P.i32[I_META][g] = meta;
+        if (with_carry) {
+            P.f64[F_JERK_SUM][g] = r.jerk_sum; P.f64[F_VIR_DIS][g] = r.vir_dis; P.f64[F_CLOSER_P][g] = r.closer_p;
+            P.i32[I_COUNT][g] = r.count;
+        }
+        if (with_ids) { P.i32[I_ID][g] = r.id; P.i32[I_SEQ][g] = r.seq; P.i32[I_VNUM][g] = r.vnum; }
+        P.i32[I_STEP][g] = r.step; P.i32[I_META][g] = meta;
         P.i32[I_HDR][g] = hdr_word;
     }
     static PVE_HD int pack_lanej(const Sh &sh, int slot)
@@ -869,7 +877,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             hdr_word = pack_lanej(sh, r.hdr);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
-                store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word);
+                store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
             }
         }
         // ---- new lane starts
@@ -911,7 +919,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             }
         }
         // ---- clear the tail so stale slots never look alive
-        if (t >= n_post) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
+        if (t >= n_post && t < N) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }   // slots >= N are clear already
         // ---- header
         if (t < NL) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
         const int n_ctl = mask_count<NW>(sh.m_ctl);
@@ -954,13 +962,15 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             }
             P.out.flags[gpre] = f;
         }
-        if (P.out.reward) P.out.reward[gpre] = (r.alive && r.ctl) ? r.reward : 0.0;
-        if (P.out.lanej) P.out.lanej[gpre] = r.alive ? ((r.lane << 16) | r.j) : -1;
-        if (P.out.new_slot) P.out.new_slot[gpre] = new_slot;
-        if (P.out.nbr) {
+        // per-slot outputs other than `flags` are written for the slots that held a vehicle only (`flags` = 0 marks
+        // the rest): 36 B x ~43 empty slots per env are 6 MB per launch, i.e. ~0.8 us of store burst
+        if (P.out.reward && r.alive) P.out.reward[gpre] = r.ctl ? r.reward : 0.0;
+        if (P.out.lanej && r.alive) P.out.lanej[gpre] = (r.lane << 16) | r.j;
+        if (P.out.new_slot && r.alive) P.out.new_slot[gpre] = new_slot;
+        if (P.out.nbr && r.alive && r.ctl) {           // controlled vehicles only (PVE_F_CTL in flags)
             int *nb = P.out.nbr + gpre * NNB;
 #pragma unroll
-            for (int k = 0; k < NNB; k++) nb[k] = (r.alive && r.ctl) ? pack_lanej(sh, r.kr[k]) : -1;
+            for (int k = 0; k < NNB; k++) nb[k] = pack_lanej(sh, r.kr[k]);
         }
         if (r.alive && r.ctl && (P.out.obs_pre || (P.out.obs_post && new_slot >= 0))) {
             // row 0 of the state, ref :1325-1337
@@ -1049,14 +1059,16 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (r.alive && !(r.meta & M_DEL)) {
             int ns = mask_below<NW>(sh.m_keep, t);
             size_t g = (size_t)env * CAP + ns;
-            store_slot(P, g, r, r.meta, r.hdr_word);
-            if (P.out.obs_post) {
-                double *o = P.out.obs_post + g * OBSW;
-                for (int k = 0; k < OBSW; k++) o[k] = r.obsrow[k];
+            if (ns != t) {                            // a vehicle that keeps its slot keeps everything
+                store_slot(P, g, r, r.meta, r.hdr_word);
+                if (P.out.obs_post) {
+                    double *o = P.out.obs_post + g * OBSW;
+                    for (int k = 0; k < OBSW; k++) o[k] = r.obsrow[k];
+                }
             }
         }
         if (t <= NL) gh.lane_start[t] = mask_below<NW>(sh.m_keep, sh.hd.lane_start[t]);
-        if (t >= n_post) { P.i32[I_META][(size_t)env * CAP + t] = 0; P.i32[I_ID][(size_t)env * CAP + t] = -1; }
+        if (t >= n_post && r.alive) { P.i32[I_META][(size_t)env * CAP + t] = 0; P.i32[I_ID][(size_t)env * CAP + t] = -1; }
         if (t == 0) gh.n_alive = n_post;
     }
 };

@@ -407,7 +407,7 @@ template <int CAP> struct TickGeo {
             hdr_word = pack_lanej(sh, r.hdr);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
-                Base::store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word);
+                Base::store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
             }
         }
         const int n_post = mask_below<NW>(keep, sh.hd.lane_start[NL]) + __builtin_popcount(sp);
@@ -439,7 +439,7 @@ template <int CAP> struct TickGeo {
             gh.veh_rec[t] = rec1;
             gh.next_arr[t] = (rec1 < P.rows) ? P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec1 * LN + t] : INFINITY;
         }
-        if (t >= n_post) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
+        if (t >= n_post && t < N) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
         if (t < ND) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
         const int n_ctl = mask_count<NW>(sh.m_ctl);
         const int n_lock = mask_count<NW>(sh.m_lead);
@@ -481,13 +481,13 @@ template <int CAP> struct TickGeo {
             }
             P.out.flags[gpre] = f;
         }
-        if (P.out.reward) P.out.reward[gpre] = (r.alive && r.ctl) ? r.reward : 0.0;
-        if (P.out.lanej) P.out.lanej[gpre] = r.alive ? ((r.lane << 16) | r.j) : -1;
-        if (P.out.new_slot) P.out.new_slot[gpre] = new_slot;
-        if (P.out.nbr) {
+        if (P.out.reward && r.alive) P.out.reward[gpre] = r.ctl ? r.reward : 0.0;
+        if (P.out.lanej && r.alive) P.out.lanej[gpre] = (r.lane << 16) | r.j;
+        if (P.out.new_slot && r.alive) P.out.new_slot[gpre] = new_slot;
+        if (P.out.nbr && r.alive && r.ctl) {           // controlled vehicles only (PVE_F_CTL in flags)
             int *nb = P.out.nbr + gpre * NNB;
 #pragma unroll
-            for (int k = 0; k < NNB; k++) nb[k] = (r.alive && r.ctl) ? pack_lanej(sh, r.kr[k]) : -1;
+            for (int k = 0; k < NNB; k++) nb[k] = pack_lanej(sh, r.kr[k]);
         }
         if (r.alive && r.ctl && (P.out.obs_pre || (P.out.obs_post && new_slot >= 0))) {
             double row[OBSW];                                                          // ref :1325-1337
