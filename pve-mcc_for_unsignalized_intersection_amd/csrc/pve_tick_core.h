@@ -201,6 +201,7 @@ struct Regs {
     int alive, ctl, del, fin;
     int cyc;                         // dead-lock cycle membership: bit0 | len << 1 | rank << 5 | leader slot << 9
     int intent, route, ord;          // general-geometry path only (intention, direction[lane][intention], processing order)
+    double act;                      // this tick's action of the slot (loaded with the state, used by S1)
 };
 struct CRegs {                       // MODE_COMPACT moves every persistent field verbatim
     double p, v, a, jerk, jerk_sum, vir_dis, closer_p;
@@ -369,7 +370,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         // First wave: unconditional (slots >= N hold zeros / stale values that are never used), so that the loads do
         // not wait for n_alive: one memory latency instead of two on the critical path.  Later waves (slots >= 64) are
         // off the critical path and mostly empty: they wait for n_alive and read the live slots only.
+        r.act = 0;
         if (t < 64 || t < N) {
+            if (P.actions) r.act = P.actions[g];          // with the state loads: one latency, not a second one in S1
             r.p = P.f64[F_P][g]; r.v = P.f64[F_V][g]; r.a = P.f64[F_A][g];
             r.jerk_sum = P.f64[F_JERK_SUM][g]; r.vir_dis = P.f64[F_VIR_DIS][g];
             r.closer_p = P.f64[F_CLOSER_P][g];
@@ -411,7 +414,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             r.lane = lane; r.j = t - sh.hd.lane_start[lane];
             sh.lane_of[t] = (uint8_t)lane;
             r.ctl = (r.meta & M_CONTROL) ? 1 : 0;
-            double act = P.actions ? P.actions[(size_t)env * CAP + t] : 0.0;
+            double act = r.act;
             if (P.mask_uncontrolled && !r.ctl) act = 0.0;   // main.py:401
             double target = clip_a(c, act);                                       // ref :1502
             if ((r.meta & M_LOCK) && (r.meta & (M_LOCKA_POS | M_LOCKA_NEG)) && r.p > 70)   // ref :1503-1505

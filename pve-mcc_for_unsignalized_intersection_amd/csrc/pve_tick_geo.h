@@ -91,6 +91,7 @@ template <int CAP> struct TickGeo {
         const size_t gi = (size_t)env * CAP + t;
         r.alive = t < N;
         r.jerk = 0;
+        r.act = P.actions ? P.actions[gi] : 0.0;
         r.p = P.f64[F_P][gi]; r.v = P.f64[F_V][gi]; r.a = P.f64[F_A][gi];
         r.jerk_sum = P.f64[F_JERK_SUM][gi]; r.vir_dis = P.f64[F_VIR_DIS][gi]; r.closer_p = P.f64[F_CLOSER_P][gi];
         r.id = P.i32[I_ID][gi]; r.seq = P.i32[I_SEQ][gi]; r.vnum = P.i32[I_VNUM][gi];
