@@ -71,6 +71,7 @@ __global__ __launch_bounds__(CAP) void k_tick(const Const c_arg, const Params P_
     T::ph_effects(c, t, sh, r);
     __syncthreads();
     PVE_PHASE_MARK(7)
+    T::ph_prefetch_arrival(P, env, t, sh, r, NL);
     T::ph_lock(c, t, sh, r);
     __syncthreads();
     T::ph_lock2(t, sh, r);
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(CAP) void k_tick_geo(const GeoConst g_arg, const Pa
     __syncthreads();
     T::ph_effects(g, t, sh, r);
     __syncthreads();
+    B::ph_prefetch_arrival(P, env, t, sh, r, g.lane_num);
     B::ph_lock(g.base, t, sh, r);
     __syncthreads();
     B::ph_lock2(t, sh, r);

@@ -202,6 +202,7 @@ struct Regs {
     int cyc;                         // dead-lock cycle membership: bit0 | len << 1 | rank << 5 | leader slot << 9
     int intent, route, ord;          // general-geometry path only (intention, direction[lane][intention], processing order)
     double act;                      // this tick's action of the slot (loaded with the state, used by S1)
+    double next_arr;                 // lane t < 12 that spawns: its next arrival time (loaded in LOCK, stored in FIN)
 };
 struct CRegs {                       // MODE_COMPACT moves every persistent field verbatim
     double p, v, a, jerk, jerk_sum, vir_dis, closer_p;
@@ -771,6 +772,16 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     }
 
     // ============================================================== LOCK: dead-lock scan + reductions
+    // the next arrival time of a lane that spawns this tick: the only global load of the kernel's tail is issued here,
+    // under the dead-lock scan, instead of in FIN where the first wave would sit out its latency
+    static PVE_HD void ph_prefetch_arrival(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r, int lane_num)
+    {
+        r.next_arr = INFINITY;
+        if (t < NL && ((sh.m_spawn[0] >> t) & 1)) {
+            const int rec1 = sh.hd.veh_rec[t] + 1;
+            if (rec1 < P.rows) r.next_arr = P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec1 * lane_num + t];
+        }
+    }
     static PVE_HD void ph_lock(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         if (r.alive && r.ctl && sh.rew_ovr[t]) r.reward = -10;                    // ref :346 via reward[-1]
@@ -907,7 +918,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             store_slot(P, gs, nv, M_CONTROL | M_ALIVE, -1);
             const int rec1 = sh.hd.veh_rec[t] + 1;
             gh.veh_rec[t] = rec1;
-            gh.next_arr[t] = (rec1 < P.rows) ? P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec1 * NL + t] : INFINITY;
+            gh.next_arr[t] = r.next_arr;
         }
         if (P.out.obs_post && sp) {
             // zero observation rows of the spawned vehicles (ref :380, :420): one coalesced 224-B store per spawn

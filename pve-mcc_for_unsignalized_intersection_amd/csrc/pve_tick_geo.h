@@ -438,7 +438,7 @@ template <int CAP> struct TickGeo {
             }
             const int rec1 = sh.hd.veh_rec[t] + 1;
             gh.veh_rec[t] = rec1;
-            gh.next_arr[t] = (rec1 < P.rows) ? P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec1 * LN + t] : INFINITY;
+            gh.next_arr[t] = r.next_arr;
         }
         if (t >= n_post && t < N) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
         if (t < ND) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }

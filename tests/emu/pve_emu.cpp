@@ -37,6 +37,7 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_scan(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_reward(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_effects(c, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_prefetch_arrival(P, env, t, sh, regs[t], NL);
         for (int t = 0; t < CAP; t++) T::ph_lock(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_final(c, P, env, t, sh, regs[t]);
@@ -65,6 +66,7 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_scan(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_reward(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_effects(g, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) B::ph_prefetch_arrival(P, env, t, sh, regs[t], g.lane_num);
         for (int t = 0; t < CAP; t++) B::ph_lock(g.base, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_lock2(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_final(g, P, env, t, sh, regs[t]);
