@@ -42,6 +42,7 @@ template <int CAP> struct SharedGeo {
     u64 m_ctl_ord[NW];               // "controlled" flags in processing order
     int8_t pos[ND][ND];              // pos[d][route] = index of route in lane2lane[d], or -1
     int8_t opp[ND];                  // lane2lane[d][1] (4-lane fix-up, ref :1303)
+    uint16_t mroutes[ND];            // bit r: route r can be a member of list d (same lane, or in lane2lane[d])
 };
 
 // XY position (ref :896-1249): every (lane, intention) branch of the reference is one of three canonical paths
@@ -106,7 +107,14 @@ template <int CAP> struct TickGeo {
             for (int q = 0; q < MAXK; q++) if (g.l2l[d][q] == rt) k = q;
             sh.pos[d][rt] = (int8_t)k;
         }
-        if (t < ND) sh.opp[t] = g.l2l[t][1];
+        if (t < ND) {
+            sh.opp[t] = g.l2l[t][1];
+            unsigned mr = 0;
+            const int li = g.dir_lane[t];
+            for (int q = 0; q < 3; q++) if (g.direction[li][q] >= 0) mr |= 1u << g.direction[li][q];
+            for (int q = 0; q < MAXK; q++) if (g.l2l[t][q] >= 0) mr |= 1u << g.l2l[t][q];
+            sh.mroutes[t] = (uint16_t)mr;
+        }
     }
 
     // ============================================================== S1..S3: step() -- the 12-lane phases; the head
@@ -198,10 +206,10 @@ template <int CAP> struct TickGeo {
         r.reward = 0; r.hit = 0; r.hdr = -1;
 #pragma unroll
         for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
-        // (a) thread d < dir_num: head of list d, persisted for next tick's step (ref :1517); lists are rebuilt only
+        // (a) one thread per list d: head of list d, persisted for next tick's step (ref :1517); lists are rebuilt only
         //     when their physical lane holds a vehicle (ref :234), otherwise the old head stays (stale by design)
-        if (t < g.dir_num) {
-            const int d = t, li = g.dir_lane[d], m = g.dir_index[d];
+        if (t >= CAP - ND && t - (CAP - ND) < g.dir_num) {     // the last 16 threads: the (mostly empty) tail of the last wave
+            const int d = t - (CAP - ND), li = g.dir_lane[d], m = g.dir_index[d];
             if (sh.hd.lane_start[li + 1] > sh.hd.lane_start[li]) {
                 double best = INFINITY; int bs = -1;
                 for (int w = 0; w < NW; w++)
@@ -227,6 +235,7 @@ template <int CAP> struct TickGeo {
         const bool fix = (g.lane_num == 4) && (d % 3 == 0);      // ref :1301
         const int opp = sh.opp[d];
         const int ls = sh.hd.lane_start[li], le = sh.hd.lane_start[li + 1];
+        const unsigned mroutes = sh.mroutes[d];                  // routes that can appear in list d (cheap early reject)
         double bvo = -INFINITY, bvc = 0; int bslot = -1;
         // the 6 nearest so far, sorted by |vd - vd_self|: only (distance, slot) travel through the insertion chain;
         // the build-time / current distances of the 6 winners are re-derived at the end, and the rare exact
@@ -238,7 +247,7 @@ template <int CAP> struct TickGeo {
             for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
                 const int x = w * 64 + __builtin_ctzll(bits);
                 double vo;
-                if (x == t || !member(g, sh, d, li, m, x, vo)) continue;
+                if (x == t || !((mroutes >> sh.route_of[x]) & 1u) || !member(g, sh, d, li, m, x, vo)) continue;
                 const double vc = (fix && sh.route_of[x] == opp) ? adjusted(g, sh, m, ls, le, t, vo) : vo;
                 // predecessor in list order = stable sort by the build-time distance (ref :271, :1353)
                 const bool before = vo < me || (vo == me && x < t);
