@@ -534,7 +534,14 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 pos += (w0 < vd) + (w1 < vd) + (w2 < vd) + (w3 < vd) + (w4 < vd) + (w5 < vd) + (w6 < vd) + (w7 < vd);
                 eq += (w0 == vd) + (w1 == vd) + (w2 == vd) + (w3 == vd) + (w4 == vd) + (w5 == vd) + (w6 == vd) + (w7 == vd);
             }
-            for (; f < hi; f++) { const double w = sh.u_vd[f]; pos += (w < vd); eq += (w == vd); }
+            if (f < hi) {                                 // tail (< 8 entries): one more round of independent reads,
+                const int n = hi - f;                     // out-of-range lanes re-read entry f and are masked out
+                double w[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) w[k] = sh.u_vd[f + (k < n ? k : 0)];
+#pragma unroll
+                for (int k = 0; k < 7; k++) { pos += (k < n) & (w[k] < vd); eq += (k < n) & (w[k] == vd); }
+            }
             // unchosen entries (vd = +inf) all land on the slot right after the finite ones: one shared
             // sentinel that ends the walks; their mutual order is irrelevant, so no tie-break for them
             if (eq > 1 && vd < INFINITY) {                // exact vd ties (rare): lower slot first
