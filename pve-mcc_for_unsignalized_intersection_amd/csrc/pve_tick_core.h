@@ -111,11 +111,14 @@ PVE_HD void lds_and(int *p, int v)
 PVE_HD int wave_incl_scan(int t, int x, int *emu_acc)
 {
 #if PVE_DEVICE_CODE
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o);
-        if ((t & 63) >= o) x += y;
-    }
+    // DPP row shifts + row broadcasts (VALU-rate data movement) instead of 6 dependent ds_bpermute round trips;
+    // lanes without a source add the `old` operand 0
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
     return x;
 #else
     *emu_acc += x;
