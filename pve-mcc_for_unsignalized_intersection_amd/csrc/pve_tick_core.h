@@ -163,13 +163,20 @@ template <int CAP> struct Shared {
         double u_vd[POOL];           // virtual distance of every list entry (segment order)
     };
     double virdis[CAP];
-    double red_reward[NW], red_jerk[NW];
     int cnt[CAP];                    // collision hits received: early | late << 16
     int acc_passed_steps, acc_collisions;
-    int16_t hdr[CAP];                // slot of the virtual header (predecessor) or -1
-    uint8_t bb[CAP];                 // brake bits: bit0 if front did not brake, bit1 if it did
-    uint8_t rew_ovr[CAP];
-    u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW];
+    // Arrays with disjoint lifetimes share storage: the CAP = 64 block must stay <= 10 KB so that 16 workgroups
+    // (all 4096 envs of BASELINE config 2) are resident per CU; LDS is allocated in 1 KB granules.
+    union {
+        int16_t pref[NL * 5];        // inclusive prefix of the 60 segment sizes (S2 .. S3 only)
+        int16_t hdr[CAP];            // slot of the virtual header (predecessor) or -1 (initialised in BUILD)
+    };
+    union {
+        uint8_t bb[CAP];             // brake bits: bit0 if front did not brake, bit1 if it did (S2 .. S3 only)
+        uint8_t rew_ovr[CAP];        // reward[-1] override (FX .. LOCK; zeroed in BUILD)
+    };
+    u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_coll[NW];
+    union { u64 m_lead[NW]; u64 m_keep[NW]; };   // tick kernel | compaction kernel
     u64 m_spawn[NW];
     // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
     // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
@@ -177,18 +184,25 @@ template <int CAP> struct Shared {
     uint8_t s_slot[POOL];
     uint8_t u_slot[POOL];
     uint8_t u_list[POOL];
-    int16_t mypos[CAP];              // position of each controlled vehicle inside its own lane's list
+    union {
+        int16_t mypos[CAP];          // position of each controlled vehicle inside its own lane's list (RANK .. WALK)
+        int16_t cyc_off[CAP];        // scratch offset of the dead-lock cycle led by slot t (LOCK .. FIN)
+    };
     int16_t lcnt[NL];                // controlled vehicles per lane
-    int16_t pref[NL * 5];            // inclusive prefix of the 60 segment sizes (list-major)
+#if !PVE_DEVICE_CODE
     int emu_scan;                    // emulator-only accumulator of wave_incl_scan
+#endif
     int16_t loff[NL + 1];            // list d occupies [loff[d], loff[d+1])
     int16_t segoff[NL][5];           // start of segment (own, conflict 0..3) inside list d
     uint8_t lane_of[CAP];            // lane of every alive slot
     float xy32[CAP][2];              // single-precision position of every controlled vehicle (collision pre-filter)
-    double tabA[2][4], tabB[2][4], tabC[2][4];   // get_virtual_distance table (copy of Const, lane-indexed reads)
+    union {
+        double tabA[2][4];           // get_virtual_distance table (copy of Const, lane-indexed reads; BUILD only)
+        struct { double red_reward[NW], red_jerk[NW]; };   // per-wave partial sums (LOCK .. FIN)
+    };
+    double tabB[2][4], tabC[2][4];
     int8_t l2l[NL][4], l2l_inv[NL][4];
     int lead_n;                      // scratch units claimed by the dead-lock cycles
-    int16_t cyc_off[CAP];            // scratch offset of the cycle led by slot t
 };
 
 struct Regs {
@@ -383,7 +397,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             r.id = P.i32[I_ID][g]; r.seq = P.i32[I_SEQ][g]; r.vnum = P.i32[I_VNUM][g];
             r.step = P.i32[I_STEP][g]; r.count = P.i32[I_COUNT][g]; r.meta = P.i32[I_META][g];
         }
-        sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
+        sh.cnt[t] = 0;                                    // (rew_ovr / hdr share storage with S2-S3 arrays: BUILD)
         if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
         if (t < 8) {
             sh.tabA[t >> 2][t & 3] = c.vdA[t >> 2][t & 3];
@@ -480,7 +494,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             if (L >= 0)
                 cnt = mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L + 1]) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L]);
         }
-        const int incl = wave_incl_scan(t, cnt, &sh.emu_scan);      // all 60 segments live in wave 0
+#if PVE_DEVICE_CODE
+        const int incl = wave_incl_scan(t, cnt, nullptr);           // all 60 segments live in wave 0
+#else
+        const int incl = wave_incl_scan(t, cnt, &sh.emu_scan);
+#endif
         if (t < NL * 5) sh.pref[t] = (int16_t)incl;
     }
     static PVE_HD void ph_lists_b(int t, Sh &sh)
@@ -499,6 +517,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // itself into its own lane's list and into the lists of the lanes it conflicts with (ref :240-270)
     static PVE_HD void ph_build(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
+        sh.rew_ovr[t] = 0; sh.hdr[t] = -1;                // their storage was bb / pref until the barrier before BUILD
         if (!(r.alive && r.ctl)) return;
         const int lane = r.lane;
         get_xy_f32(c, r.p, lane, sh.xy32[t][0], sh.xy32[t][1]);
