@@ -766,6 +766,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // ============================================================== FX: ordered effects
     static PVE_HD void ph_effects(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
+#if !PVE_DEVICE_CODE
+        if (t == 0) { sh.red_reward[0] = 0; sh.red_jerk[0] = 0; }   // emulator: block_sum accumulates; storage was tabA
+#endif
         r.del = 0; r.fin = 0; r.coll_seen = 0; r.coll_fin = 0;
         if (r.alive) {
             const int cc = sh.cnt[t];

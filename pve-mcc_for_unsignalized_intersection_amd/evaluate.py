@@ -12,7 +12,6 @@ import argparse
 import json
 
 import numpy as np
-import torch
 
 from .arrivals import load_arrival_mat, pad_stream, synthetic_arrivals, synthetic_intentions
 from .batched import BatchedIntersections

@@ -1,7 +1,6 @@
 """f1: MADDPG actor inference. CPU part: the NumPy restatement (oracle/actor_np.py) is pinned by the
 closed-loop known answers of SURVEY App. D; the C-ABI plumbing is exercised through the emulator."""
 import numpy as np
-import pytest
 
 from oracle.actor_np import actor_forward, flat_weights, load_weights
 from oracle.oracle import OracleEnv

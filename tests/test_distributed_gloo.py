@@ -3,7 +3,6 @@ Checks sharding arithmetic, that the single all-gather carries every rank's metr
 that the sharded job simulates exactly the same envs as one process (env-parallel => no data-path
 collective, results independent of the partition)."""
 import json
-import os
 import socket
 
 import numpy as np

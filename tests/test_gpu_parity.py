@@ -2,7 +2,6 @@
 the CPU oracle and the golden vectors. Integers bit-exact; floats within the north-star tolerance
 |x-y| <= 1e-5*max(1,|x|) (we assert 1e-9: the only non-IEEE-identical operations are
 tanh/log/sin/cos of the device math library, which feed rewards and the XY collision distance)."""
-import ctypes as C
 import os
 
 import numpy as np

@@ -2,13 +2,9 @@
 (csrc/pve_tick_core.h) are executed by the test emulator (tests/emu, same C ABI on host memory)
 and compared with the sequential oracle and the golden vectors. The `-m gpu` twin of this file
 (test_gpu_parity.py) runs the real kernels through libpveenv.so."""
-import numpy as np
 import pytest
-import torch
 
-from oracle.oracle import OracleEnv
-from oracle.record import compare_records, get_policy
-from tests.hip_adapter import SplitEnv, make_batch, state_snapshot
+from tests.hip_adapter import SplitEnv, make_batch
 from tests.parity_util import CASE_NAMES, GoldenCase, replay_case
 from tests import scenarios
 

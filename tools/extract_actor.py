@@ -8,7 +8,6 @@ messages (field 1 dtype, 2 shape, 4 offset, 5 size); `66.cptk.data-00000-of-0000
 little-endian tensors.  Build container only (needs /root/reference)."""
 import os
 import struct
-import sys
 
 import numpy as np
 
