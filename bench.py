@@ -88,12 +88,14 @@ def pmc_traffic(n_envs, cap, outputs, actor):
     command (tools/collect_profiles.sh -> profiles/r*_traffic.json); null when the config differs."""
     import glob
     default_outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
-    if actor or n_envs != 4096 or cap != 128 or tuple(outputs) != default_outputs:
+    if actor or cap != 128 or tuple(outputs) != default_outputs:
         return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
         return None, None
     t = json.load(open(files[-1]))
+    if int(t.get("envs_per_launch", 4096)) != n_envs:      # measured on launches of another size
+        return None, None
     return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
 
 
@@ -111,6 +113,9 @@ def main(argv=None, env_factory=None):
     ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
     ap.add_argument("--lane-num", type=int, default=12, choices=(12, 8, 4),
                     help="intersection layout; 12 = BASELINE metric (k_tick), 4 / 8 = SURVEY 8 f4 (k_tick_geo)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="free-running sub-batches per GPU, each on its own HIP stream (PipelinedIntersections); 1 = one "
+                         "launch over all envs per step")
     ap.add_argument("--obs-f32", action="store_true",
                     help="float32 observation rows (PVE_CFG_OBS_F32; SURVEY 8d's FP32-output variant, 268 B algorithmic); "
                          "the headline / BASELINE metric is the float64 parity layout (380 B)")
@@ -155,14 +160,23 @@ def main(argv=None, env_factory=None):
     choice = synthetic_intentions(n_envs, arr.shape[1], seed=20250213 + rank * n_envs) if lane_num == 8 else None
     pool_np = action_pool(n_envs, cap, seed=99 + rank)
     outputs = tuple(x for x in args.outputs.split(",") if x)
+    n_sub = max(1, min(args.pipeline, n_envs))
     if emu:
         env = env_factory(n_envs, cap, arr, outputs)
-    else:
+        n_sub = getattr(env, "n_sub", 1)
+    elif n_sub == 1:
         env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs, lane_num=lane_num,
                                                intentions=choice,
                                                obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+    else:
+        # the envs are independent: n_sub free-running sub-batches on their own streams pipeline the ticks (the chip-wide
+        # LOAD / FIN bursts of one sub-batch overlap the compute phases of the other), DESIGN.md 5
+        env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=n_sub, device=dev, outputs=outputs,
+                                                 lane_num=lane_num, intentions=choice,
+                                                 obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
     pool = torch.as_tensor(pool_np, device=dev)
     env.reset()
+    sub_streams = getattr(env, "streams", None) if not emu else None
     if args.actor:
         wpath = os.path.join(ROOT, "tests", "golden", "actor_66.npz")
         z = np.load(wpath)
@@ -181,21 +195,27 @@ def main(argv=None, env_factory=None):
         dist.barrier()
     sync()
     m0 = env.metrics()
+    # HIP events on the streams the kernels are launched on: torch's current stream for one batch, every sub-batch
+    # stream for the pipelined form (start / end of the K launches of that stream)
     if not emu:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev_streams = sub_streams if sub_streams else [torch.cuda.current_stream(dev)]
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ev_streams]
     t0 = time.perf_counter()
     if not emu:
-        ev0.record()                  # same stream the kernels are launched on (torch current stream)
+        for (e0, _), st in zip(evs, ev_streams):
+            e0.record(st)
     for t in range(W, W + K):
         one_step(t)
     if not emu:
-        ev1.record()
+        for (_, e1), st in zip(evs, ev_streams):
+            e1.record(st)
     sync()
     if world > 1:
         dist.barrier()
     sync()
     wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1) if not emu else wall * 1e3
+    # average duration of one launch on its stream (K back-to-back launches per stream)
+    gpu_ms = (sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)) if not emu else wall * 1e3
     if world > 1:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -207,10 +227,12 @@ def main(argv=None, env_factory=None):
     if rank == 0:
         slot_steps = float(cap) * n_envs * K * world
         value = slot_steps / wall
-        kern_s = gpu_ms * 1e-3 / K
+        kern_s = gpu_ms * 1e-3 / K                      # per launch (n_envs / n_sub envs), launches of the n_sub streams overlap
         b_alg = B_ALG_OBS_F32 if args.obs_f32 else B_ALG_FP64
-        achieved = b_alg * cap * n_envs / kern_s / 1e9
-        traffic, traffic_src = pmc_traffic(n_envs, cap, outputs, args.actor or lane_num != 12 or args.obs_f32)
+        envs_per_launch = n_envs / float(n_sub)
+        per_launch = b_alg * cap * envs_per_launch / kern_s / 1e9
+        achieved = per_launch * n_sub                    # n_sub launches of the kernel are in flight at any time
+        traffic, traffic_src = pmc_traffic(int(envs_per_launch), cap, outputs, args.actor or lane_num != 12 or args.obs_f32)
         line = {
             "metric": "env-steps/sec (vehicles x envs x steps/s) at 128 veh x 4096 envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -220,7 +242,9 @@ def main(argv=None, env_factory=None):
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
                                       if args.actor else "sin action pool"),
-                       "envs_per_gpu": n_envs, "capacity": cap, "parallelism": "env-parallel x%d" % world,
+                       "envs_per_gpu": n_envs, "capacity": cap,
+                       "parallelism": "env-parallel x%d" % world + (", %d stream-pipelined sub-batches of %d envs per GPU"
+                                                                   % (n_sub, int(envs_per_launch)) if n_sub > 1 else ""),
                        "outputs": list(outputs), "obs_dtype": "f32" if args.obs_f32 else "f64"},
             "alive_steps_per_s": tot["alive_steps"] / wall,
             "ctl_steps_per_s": tot["ctl_steps"] / wall,
@@ -230,7 +254,11 @@ def main(argv=None, env_factory=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "kernel": ("k_tick<%d>" if lane_num == 12 else "k_tick_geo<%d>") % cap, "kernel_ms": kern_s * 1e3,
-                         "alg_bytes_per_slot_step": b_alg},
+                         "alg_bytes_per_slot_step": b_alg, "envs_per_launch": int(envs_per_launch),
+                         "concurrent_launches": n_sub, "per_launch_achieved": per_launch,
+                         "definition": "achieved = algorithmic bytes per launch / average launch duration (HIP events on "
+                                       "the launching stream) x launches in flight; with one sub-batch this is the plain "
+                                       "per-launch figure"},
         }
         if args.actor:
             line["roofline"]["note"] = "kernel_ms = k_actor + k_tick per step; achieved uses the tick's algorithmic bytes only"

@@ -188,27 +188,44 @@ class BatchedIntersections:
         self._is_reset = True
 
     def _outputs_struct(self, flip_obs):
-        o = PveOutputs()
-        if self._obs is not None:
-            if len(self._obs) == 2:
-                if flip_obs:
-                    self._obs_cur ^= 1
-                o.obs_prev_post = self._obs[self._obs_cur ^ 1].data_ptr()
-            o.obs_post = self._obs[self._obs_cur].data_ptr()
-        for n, tns in self.out.items():
-            setattr(o, n, tns.data_ptr())
+        """pve_outputs for this call (cached per observation buffer: the host side of a tick is ~10 us of Python,
+        which matters once sub-batches are pipelined on several streams)."""
+        if self._obs is not None and len(self._obs) == 2 and flip_obs:
+            self._obs_cur ^= 1
+        cache = self.__dict__.setdefault("_out_structs", {})
+        o = cache.get(self._obs_cur)
+        if o is None:
+            o = PveOutputs()
+            if self._obs is not None:
+                if len(self._obs) == 2:
+                    o.obs_prev_post = self._obs[self._obs_cur ^ 1].data_ptr()
+                o.obs_post = self._obs[self._obs_cur].data_ptr()
+            for n, tns in self.out.items():
+                setattr(o, n, tns.data_ptr())
+            d = dict(self.out)
+            if self._obs is not None:
+                d["obs_post"] = self._obs[self._obs_cur]
+            cache[self._obs_cur] = o
+            self.__dict__.setdefault("_out_dicts", {})[self._obs_cur] = d
         return o
+
+    def _bind_stream(self):
+        """Kernels follow torch's current stream unless the batch was created with its own `stream`."""
+        if self._stream_obj is None:
+            self.lib.pve_set_stream(self._h, self._stream_ptr())
 
     def step(self, actions=None):
         """One fused tick for every env. actions: float64 [n_envs, capacity] indexed by current slot
         (None = zeros). Returns the dict of output tensors (views, overwritten by the next call)."""
         a = self._zero_actions if actions is None else actions
         assert a.dtype == torch.float64 and a.is_contiguous() and a.shape == (self.n_envs, self.capacity)
-        self.lib.pve_set_stream(self._h, self._stream_ptr())
+        self._bind_stream()
         o = self._outputs_struct(flip_obs=True)
-        check(self.lib, self.lib.pve_step_all(self._h, C.c_void_p(a.data_ptr()), C.byref(o)), "pve_step_all")
+        rc = self.lib.pve_step_all(self._h, a.data_ptr(), C.byref(o))
+        if rc != 0:
+            check(self.lib, rc, "pve_step_all")
         self.ticks += 1
-        return self.outputs()
+        return self._out_dicts[self._obs_cur]
 
     # ------------------------------------------------------------------ on-device MADDPG actor (SURVEY §8 f1)
     ACTOR_KEYS = ("ln0_gamma", "ln0_beta", "w1", "b1", "ln1_gamma", "ln1_beta", "w2", "b2", "ln2_gamma",
@@ -237,7 +254,7 @@ class BatchedIntersections:
     def step_with_actor(self):
         """One closed-loop tick entirely on the device: actor(obs) -> fused tick (two launches, no host
         round trip; main.py:398-441 with the actor of model_agent_maddpg.py)."""
-        self.lib.pve_set_stream(self._h, self._stream_ptr())
+        self._bind_stream()
         obs_in = self._obs[self._obs_cur]
         o = self._outputs_struct(flip_obs=True)
         check(self.lib, self.lib.pve_step_all_actor(self._h, C.c_void_p(self._actor_w.data_ptr()),
@@ -264,10 +281,8 @@ class BatchedIntersections:
         check(self.lib, self.lib.pve_compact(self._h, obs), "pve_compact")
 
     def outputs(self):
-        d = dict(self.out)
-        if self._obs is not None:
-            d["obs_post"] = self._obs[self._obs_cur]
-        return d
+        self._outputs_struct(flip_obs=False)
+        return self._out_dicts[self._obs_cur]
 
     def synchronize(self):
         check(self.lib, self.lib.pve_synchronize(self._h), "pve_synchronize")
@@ -289,3 +304,102 @@ class BatchedIntersections:
         out = (C.c_double * _capi.PVE_N_METRICS)()
         check(self.lib, self.lib.pve_get_metrics(self._h, out), "pve_get_metrics")
         return dict(zip(_capi.METRIC_NAMES, [float(x) for x in out]))
+
+
+
+class PipelinedIntersections:
+    """`n_envs` environments as `n_sub` sub-batches, each a BatchedIntersections on its own HIP stream.
+
+    The environments are independent, so the sub-batches never synchronise with each other: tick t+1 of one is in
+    flight while tick t of another still runs.  One launch over all envs runs its workgroups in lock-step (every
+    workgroup loads, computes and stores at the same time, and 4096 envs are exactly two rounds of the 2048 resident
+    workgroups); two free-running populations interleave instead, the chip-wide LOAD / FIN bursts of one overlap the
+    compute phases of the other: 4096 x 128 slots take 39 us per tick of ALL envs instead of 54 us (MI355X).
+
+    Ordering is per sub-batch: `step()` enqueues on `streams[k]`; produce the actions of sub-batch k on that stream (or
+    call `wait_stream()` after producing them elsewhere) and consume its outputs on that stream or after
+    `synchronize()`.  This is the usual two-batch pipelining of an RL loop: policy inference for one half while the
+    environment steps the other.
+    """
+
+    def __init__(self, n_envs, capacity, arrivals, n_sub=2, device=None, outputs=DEFAULT_OUTPUTS, intentions=None,
+                 _lib=None, **config):
+        if n_sub < 1 or n_sub > n_envs:
+            raise PveError("n_sub must be in 1 .. n_envs")
+        self.device = torch.device("cuda" if device is None else device)
+        self.n_envs, self.capacity, self.n_sub = int(n_envs), int(capacity), int(n_sub)
+        base, rem = divmod(self.n_envs, self.n_sub)
+        sizes = [base + (1 if k < rem else 0) for k in range(self.n_sub)]
+        self.bounds = [0]
+        for z in sizes:
+            self.bounds.append(self.bounds[-1] + z)
+        on_gpu = self.device.type == "cuda"
+        self.streams = [torch.cuda.Stream(self.device) if on_gpu else None for _ in range(self.n_sub)]
+
+        def part(x, k):
+            if x is None:
+                return None
+            x = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+            return x if x.dim() == 2 else x[self.bounds[k]:self.bounds[k + 1]]
+        self.subs = []
+        for k in range(self.n_sub):
+            with self._on(k):
+                self.subs.append(BatchedIntersections(sizes[k], capacity, part(arrivals, k), device=self.device,
+                                                      outputs=outputs, stream=self.streams[k],
+                                                      intentions=part(intentions, k), _lib=_lib, **config))
+        self.synchronize()
+
+    def _on(self, k):
+        import contextlib
+        return torch.cuda.stream(self.streams[k]) if self.streams[k] is not None else contextlib.nullcontext()
+
+    def _parts(self, x):
+        if x is None:
+            return [None] * self.n_sub
+        if isinstance(x, (list, tuple)):
+            return list(x)
+        return [x[self.bounds[k]:self.bounds[k + 1]] for k in range(self.n_sub)]     # contiguous row ranges
+
+    def reset(self):
+        for k, sub in enumerate(self.subs):
+            with self._on(k):
+                sub.reset()
+
+    def wait_stream(self, stream=None):
+        """Every sub-batch stream waits for what has been enqueued on `stream` (default: torch's current stream)."""
+        if self.device.type != "cuda":
+            return
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        for s in self.streams:
+            s.wait_stream(stream)
+
+    def step(self, actions=None):
+        """One fused tick of every sub-batch, each on its own stream.  actions: [n_envs, capacity] float64 (or a list of
+        per-sub-batch tensors, or None).  Returns the list of per-sub-batch output dicts."""
+        return [sub.step(a) for sub, a in zip(self.subs, self._parts(actions))]
+
+    def set_actor(self, weights):
+        for k, sub in enumerate(self.subs):
+            with self._on(k):
+                sub.set_actor(weights)
+
+    def step_with_actor(self):
+        return [sub.step_with_actor() for sub in self.subs]
+
+    def synchronize(self):
+        for sub in self.subs:
+            sub.synchronize()
+
+    def metrics(self):
+        tot = None
+        for sub in self.subs:
+            m = sub.metrics()
+            tot = m if tot is None else {k: tot[k] + m[k] for k in m}
+        return tot
+
+    def sub_of(self, env):
+        """(sub-batch index, local env index) of a global env index."""
+        for k in range(self.n_sub):
+            if env < self.bounds[k + 1]:
+                return k, env - self.bounds[k]
+        raise IndexError(env)

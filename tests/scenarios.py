@@ -408,3 +408,38 @@ def check_obs_f32(backend, lane_num=12, n_envs=3, capacity=128, ticks=120, seed=
         raise AssertionError("obs_pre must be refused with float32 observations")
     except PveError:
         pass
+
+
+def check_pipelined_equals_single(backend, n_envs=7, n_sub=3, capacity=128, ticks=150, seed=61, actor=False):
+    """PipelinedIntersections (sub-batches on their own streams) evolves every env exactly like one batch."""
+    from pve_mcc_amd.batched import PipelinedIntersections
+    from tests.hip_adapter import emulator_lib
+    rng = np.random.default_rng(seed)
+    arr = synthetic_arrivals(n_envs, rate=1100.0, horizon_s=ticks * 0.1 + 30, seed=seed)
+    outs = ("obs_post", "reward", "flags", "env_out", "new_slot")
+    one = make_batch(arr, n_envs, capacity, backend, outputs=outs)
+    kw = dict(device="cpu", _lib=emulator_lib()) if backend == "emu" else dict(device="cuda")
+    pipe = PipelinedIntersections(n_envs, capacity, arr, n_sub=n_sub, outputs=outs, **kw)
+    assert pipe.bounds[-1] == n_envs and len(pipe.subs) == n_sub
+    one.reset(); pipe.reset()
+    if actor:
+        from oracle.actor_np import flat_weights, load_weights
+        w = flat_weights(load_weights())
+        one.set_actor(w); pipe.set_actor(w)
+    for t in range(ticks):
+        if actor:
+            one.step_with_actor(); pipe.step_with_actor()
+        else:
+            a = torch.as_tensor(rng.uniform(-2, 2, size=(n_envs, capacity))).to(one.device)
+            pipe.wait_stream()                     # the actions were produced on the current stream
+            one.step(a); pipe.step(a)
+    pipe.synchronize(); one.synchronize()
+    for k in STATE_F + STATE_I:
+        x = _np(one.state_field(k))
+        y = np.concatenate([_np(sub.state_field(k)) for sub in pipe.subs], 0)
+        assert np.array_equal(x, y), "state %s differs between the pipelined and the single batch" % k
+    assert np.array_equal(_np(one.obs), np.concatenate([_np(sub.obs) for sub in pipe.subs], 0))
+    m1, m2 = one.metrics(), pipe.metrics()
+    for k in m1:                                   # float sums differ in summation order only
+        assert abs(m1[k] - m2[k]) <= 1e-9 * max(1.0, abs(m1[k])), (k, m1[k], m2[k])
+    assert pipe.sub_of(n_envs - 1) == (n_sub - 1, pipe.subs[-1].n_envs - 1)

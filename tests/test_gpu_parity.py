@@ -261,3 +261,9 @@ def test_gpu_float32_observation_rows():
 def test_gpu_closed_loop_on_float32_observations_is_bit_identical():
     from tests import actor_scenarios as A
     A.check_closed_loop_f32_obs_equals_f64("hip", ticks=400, n_envs=16)
+
+
+def test_gpu_pipelined_sub_batches_equal_one_batch():
+    """Two / three free-running sub-batches on their own HIP streams == one launch over all envs, bit for bit."""
+    scenarios.check_pipelined_equals_single(BACKEND, n_envs=64, n_sub=2, ticks=300)
+    scenarios.check_pipelined_equals_single(BACKEND, n_envs=37, n_sub=3, ticks=200, actor=True)

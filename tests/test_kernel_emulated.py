@@ -53,3 +53,8 @@ def test_reset_replays_the_same_episode():
 def test_float32_observation_rows():
     scenarios.check_obs_f32(BACKEND, lane_num=12)
     scenarios.check_obs_f32(BACKEND, lane_num=8, ticks=80)
+
+
+def test_pipelined_sub_batches_equal_one_batch():
+    scenarios.check_pipelined_equals_single(BACKEND, n_envs=7, n_sub=3, ticks=120)
+    scenarios.check_pipelined_equals_single(BACKEND, n_envs=4, n_sub=2, ticks=80, actor=True)

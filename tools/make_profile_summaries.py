@@ -46,8 +46,14 @@ try:
     fetch = last_avg(os.path.join(src, "fetch", "r_results.db"), "FETCH_SIZE", "k_tick", 30)
     write = last_avg(os.path.join(src, "write", "r_results.db"), "WRITE_SIZE", "k_tick", 30)
     corr = known_kib / probe
+    try:
+        bl = json.load(open(os.path.join(src, "bench_default.json")))
+        envs_per_launch = int(bl["roofline"].get("envs_per_launch", 4096))
+    except Exception:  # noqa
+        envs_per_launch = 4096
     traffic = dict(
-        kernel="k_tick<128>", workload="4096 envs x 128 slots, default bench outputs, steady state (last 30 launches)",
+        kernel="k_tick<128>", envs_per_launch=envs_per_launch,
+        workload="%d envs x 128 slots per launch, default bench outputs, steady state (last 30 launches)" % envs_per_launch,
         fetch_size_kib_reported=fetch, write_size_kib_reported=write,
         fetch_calibration=dict(kernel="k_probe<128>", known_kib=known_kib, reported_kib=probe, correction=corr,
                                note="same 8 B / 4 B per-lane SoA load pattern as the tick's load phase; gfx950 FETCH_SIZE "
