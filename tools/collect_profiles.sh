@@ -7,6 +7,8 @@ export TMPDIR=/tmp
 O=gpurun_out/$R
 mkdir -p $O
 timeout 400 python bench.py 2>&1 | tail -1 > $O/bench_default.json
+timeout 400 python bench.py --pipeline 1 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_single_launch.json
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_single -o r -- python bench.py --pipeline 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o r -- python bench.py --no-cpu-baseline > $O/stats.log 2>&1
 # PMC counters in their own passes (kernel-trace only), FETCH_SIZE and WRITE_SIZE cannot share a pass
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o r -- python bench.py --steps 40 --warmup 300 --no-cpu-baseline > /dev/null 2>&1

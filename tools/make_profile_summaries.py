@@ -21,12 +21,13 @@ def summary(db, out, tail):
 
 
 summary(os.path.join(src, "stats", "r_results.db"), prefix + "_kernel_stats.txt", 1000)
+summary(os.path.join(src, "stats_single", "r_results.db"), prefix + "_kernel_stats_single_launch.txt", 1000)
 summary(os.path.join(src, "stats_actor", "r_results.db"), prefix + "_kernel_stats_actor.txt", 300)
 summary(os.path.join(src, "stats_lanes8", "r_results.db"), prefix + "_kernel_stats_lanes8.txt", 300)
 summary(os.path.join(src, "fetch", "r_results.db"), prefix + "_pmc_fetch.txt", 30)
 summary(os.path.join(src, "write", "r_results.db"), prefix + "_pmc_write.txt", 30)
 summary(os.path.join(src, "probe", "r_results.db"), prefix + "_pmc_probe_calibration.txt", 10)
-for f in ("bench_default.json", "bench_cap64.json", "bench_actor.json", "phase_profile.txt", "bench_lanes8.json",
+for f in ("bench_default.json", "bench_single_launch.json", "bench_cap64.json", "bench_actor.json", "phase_profile.txt", "bench_lanes8.json",
           "bench_lanes4.json"):
     p = os.path.join(src, f)
     if os.path.isfile(p):
