@@ -376,7 +376,12 @@ class PipelinedIntersections:
     def step(self, actions=None):
         """One fused tick of every sub-batch, each on its own stream.  actions: [n_envs, capacity] float64 (or a list of
         per-sub-batch tensors, or None).  Returns the list of per-sub-batch output dicts."""
-        return [sub.step(a) for sub, a in zip(self.subs, self._parts(actions))]
+        outs = []
+        for k, (sub, a) in enumerate(zip(self.subs, self._parts(actions))):
+            if a is not None and self.streams[k] is not None:
+                a.record_stream(self.streams[k])       # the caching allocator must not recycle it under the kernel
+            outs.append(sub.step(a))
+        return outs
 
     def set_actor(self, weights):
         for k, sub in enumerate(self.subs):

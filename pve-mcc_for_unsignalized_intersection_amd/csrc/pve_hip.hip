@@ -29,8 +29,10 @@ typedef __attribute__((address_space(4))) const char *KernargPtr;
         tprev_ = now_;                                                                   \
     }
 
+// 5 waves per SIMD (<= 96 VGPR) + the 15.1 KB LDS block = 10 workgroups of 128 threads per CU instead of 8: with the
+// sub-batches pipelined on several streams the tick scales almost linearly with the resident workgroups.
 template <int CAP>
-__global__ __launch_bounds__(CAP) void k_tick(const Const c_arg, const Params P_arg)
+__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tick(const Const c_arg, const Params P_arg)
 {
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka0_;

@@ -180,10 +180,13 @@ template <int CAP> struct Shared {
     u64 m_spawn[NW];
     // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
     // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
-    double s_vd[POOL];               // the same entries sorted by (vd, slot)
-    uint8_t s_slot[POOL];
+    uint16_t s_idx[POOL];            // the same entries sorted by (vd, slot): index into u_vd / u_slot (no second
+                                     // copy of the distances: 4.4 KB less LDS = 10 instead of 8 workgroups per CU)
     uint8_t u_slot[POOL];
-    uint8_t u_list[POOL];
+    union {
+        uint8_t u_list[POOL];        // list of every entry (BUILD .. RANK)
+        uint8_t lk_slot[POOL];       // dead-lock scratch: slot of the record filed at each rank (LOCK2 .. FIN)
+    };
     union {
         int16_t mypos[CAP];          // position of each controlled vehicle inside its own lane's list (RANK .. WALK)
         int16_t cyc_off[CAP];        // scratch offset of the dead-lock cycle led by slot t (LOCK .. FIN)
@@ -571,8 +574,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
             }
             const int myslot = sh.u_slot[e];
-            sh.s_vd[lo + pos] = vd;
-            sh.s_slot[lo + pos] = (uint8_t)myslot;
+            sh.s_idx[lo + pos] = (uint16_t)e;
             if (e - lo < sh.lcnt[d]) sh.mypos[myslot] = (int16_t)pos;   // own-lane segment comes first
         }
     }
@@ -590,8 +592,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         const double ps = r.p;
         const int base = sh.loff[lane], n = sh.loff[lane + 1] - base;
         if (head_thread) {                                // persisted for next tick's step (ref :1517)
-            if (n > 0 && sh.s_vd[base] < INFINITY) {
-                const int hr = sh.s_slot[base];
+            const int e0 = sh.s_idx[base];
+            if (n > 0 && sh.u_vd[n > 0 ? e0 : 0] < INFINITY) {
+                const int hr = sh.u_slot[e0];
                 lds_or(&sh.hd.head_valid, 1 << lane);
                 int hl = sh.lane_of[hr];
                 sh.hd.head_lane[lane] = hl;
@@ -602,10 +605,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
         if (!ctl) return;
         const int s = sh.mypos[t];
-        const double *sv = sh.s_vd + base;
-        const uint8_t *ss = sh.s_slot + base;
+        const uint16_t *sidx = sh.s_idx + base;      // sorted position -> entry
+#define sv(pos_) sh.u_vd[sidx[pos_]]
+#define ss(pos_) sh.u_slot[sidx[pos_]]
         int pr = -1; double pvd = 0;
-        if (s > 0) { pr = ss[s - 1]; pvd = sv[s - 1]; }                             // ref :1353-1354
+        if (s > 0) { pr = ss(s - 1); pvd = sv(s - 1); }                             // ref :1353-1354
         // The 6 nearest in the reference's stable |vd - vd_self| sort = the 6 smallest keys (|d|, vd, slot) (ref
         // :1383-1397).  Both sides of our own position are already sorted by |d|: left = keys below ours (walking
         // left), right = keys above (walking right); on equal |d| the left entry comes first (smaller vd, or equal
@@ -619,18 +623,18 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 #pragma unroll
         for (int i = 0; i < NNB + 1; i++) {
             const int pos = s - 1 - i;
-            lv[i] = (pos >= 0) ? sv[pos] : -INFINITY;
-            if (i < NNB) lsl[i] = (pos >= 0) ? (int)ss[pos] : -1;
+            lv[i] = (pos >= 0) ? sv(pos) : -INFINITY;
+            if (i < NNB) lsl[i] = (pos >= 0) ? (int)ss(pos) : -1;
             if (i > 0) tie = tie || (pos >= 0 && lv[i] == lv[i - 1]);
         }
         bool rvalid = true;                                            // everything after the +inf sentinel is stale
 #pragma unroll
         for (int i = 0; i < NNB; i++) {
             const int pos = s + 1 + i;
-            const double w = (pos < n) ? sv[pos] : INFINITY;
+            const double w = (pos < n) ? sv(pos) : INFINITY;
             rvalid = rvalid && (w < INFINITY);
             rv[i] = rvalid ? w : INFINITY;
-            rsl[i] = rvalid ? (int)ss[pos < n ? pos : 0] : -1;
+            rsl[i] = rvalid ? (int)ss(pos < n ? pos : 0) : -1;
         }
         // candidate = (d, code): code = walking index on the left (0..5) or 8 + index on the right.  min(L_i, R_5-i)
         // (left wins equal d) are the 6 smallest overall; they are then sorted by d alone with a 12-comparator
@@ -666,35 +670,35 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 const bool ok = cd[k] < INFINITY;
                 const int code = cc[k];
                 const int pos = (code < 8) ? (s - 1 - code) : (s + 1 + (code - 8));
-                r.kr[k] = ok ? (int)ss[ok ? pos : 0] : -1;
-                r.kv[k] = ok ? sv[ok ? pos : 0] : 0.0;
+                r.kr[k] = ok ? (int)ss(ok ? pos : 0) : -1;
+                r.kv[k] = ok ? sv(ok ? pos : 0) : 0.0;
             }
         } else {
             // GENERAL PATH: pointer walk; a run of equal vd on the left is emitted in ascending slot
             int hi = s - 1, lo = hi, cur, rr = s + 1;
-            if (hi >= 0) { const double vh = pvd; while (lo > 0 && sv[lo - 1] == vh) lo--; }
+            if (hi >= 0) { const double vh = pvd; while (lo > 0 && sv(lo - 1) == vh) lo--; }
             cur = lo;
             for (int k = 0; k < NNB; k++) {
                 const bool hasL = hi >= 0;
                 double vR = INFINITY;
-                if (rr < n) vR = sv[rr];
+                if (rr < n) vR = sv(rr);
                 const bool hasR = vR < INFINITY;
                 if (!(hasL || hasR)) break;
                 double vL = 0;
-                if (hasL) vL = sv[cur];
+                if (hasL) vL = sv(cur);
                 const double dL = fabs(vL - ps), dR = fabs(vR - ps);              // ref :1388
                 const bool takeL = hasL && (!hasR || dL <= dR);
                 int slot; double vv;
                 if (takeL) {
-                    slot = ss[cur]; vv = vL;
+                    slot = ss(cur); vv = vL;
                     cur++;
                     if (cur > hi) {
                         hi = lo - 1; lo = hi;
-                        if (hi >= 0) { const double vh = sv[hi]; while (lo > 0 && sv[lo - 1] == vh) lo--; }
+                        if (hi >= 0) { const double vh = sv(hi); while (lo > 0 && sv(lo - 1) == vh) lo--; }
                         cur = lo;
                     }
                 } else {
-                    slot = ss[rr]; vv = vR;
+                    slot = ss(rr); vv = vR;
                     rr++;
                 }
                 // static register indices only (no scratch): select the destination by k
@@ -708,6 +712,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         sh.hdr[t] = (int16_t)pr;
         sh.virdis[t] = r.vir_dis;
         r.count += 1;                                                             // ref :292
+#undef sv
+#undef ss
     }
 
     // ============================================================== REWARD: reward terms + XY collision test
@@ -847,13 +853,13 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         vote<NW>(sh.m_lead, t, lead);
     }
     // LOCK2 (after a barrier): every cycle member files its record at its rank inside the cycle's scratch range
-    // (u_vd / s_slot are dead after the walk phase) = the reference's record_.sort() (ref :1492)
+    // (u_vd / u_list are dead after the walk phase) = the reference's record_.sort() (ref :1492)
     static PVE_HD void ph_lock2(int t, Sh &sh, Regs &r)
     {
         if (r.cyc & 1) {
             const int e = sh.cyc_off[r.cyc >> 9] + ((r.cyc >> 5) & 15);
             sh.u_vd[e] = sh.virdis[t];
-            sh.s_slot[e] = (uint8_t)t;
+            sh.lk_slot[e] = (uint8_t)t;
         }
     }
     // NOTE: if the tightest record's header is the tightest vehicle itself (1-cycle) the reference
@@ -911,7 +917,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 double sum = 0;
 #pragma unroll
                 for (int q = 0; q < 10; q++) if (q < len) sum = sum + sh.u_vd[off + q];
-                const int best_o = sh.s_slot[off];
+                const int best_o = sh.lk_slot[off];
                 meta |= M_LOCK;                                                    // ref :1482
                 lockf = 1;
                 if (sh.u_vd[off] < c.collision_thr || sum / (double)len < c.lock_mean_thr) {

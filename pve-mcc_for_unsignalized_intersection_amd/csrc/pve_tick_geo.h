@@ -36,7 +36,7 @@ template <int CAP> struct SharedGeo {
     int cnt[CAP];
     int acc_passed_steps, acc_collisions, lead_n, emu_scan;
     int16_t hdr[CAP], cyc_off[CAP], ord[CAP], slot_at[CAP];
-    uint8_t bb[CAP], rew_ovr[CAP], lane_of[CAP], route_of[CAP], intent_of[CAP], s_slot[CAP];
+    uint8_t bb[CAP], rew_ovr[CAP], lane_of[CAP], route_of[CAP], intent_of[CAP], lk_slot[CAP];
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW], m_spawn[NW];
     u64 m_int[3][NW];                // alive slots by intention
     u64 m_ctl_ord[NW];               // "controlled" flags in processing order
@@ -405,7 +405,7 @@ template <int CAP> struct TickGeo {
                 double sum = 0;
 #pragma unroll
                 for (int q = 0; q < 10; q++) if (q < len) sum = sum + sh.u_vd[off + q];
-                const int best_o = sh.s_slot[off];
+                const int best_o = sh.lk_slot[off];
                 meta |= M_LOCK;
                 lockf = 1;
                 if (sh.u_vd[off] < c.collision_thr || sum / (double)len < c.lock_mean_thr) {
