@@ -400,6 +400,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             r.id = P.i32[I_ID][g]; r.seq = P.i32[I_SEQ][g]; r.vnum = P.i32[I_VNUM][g];
             r.step = P.i32[I_STEP][g]; r.count = P.i32[I_COUNT][g]; r.meta = P.i32[I_META][g];
         }
+        sh.virdis[t] = r.vir_dis;                         // carried in LDS, not in a register (WALK overwrites it for the
+                                                          // controlled vehicles, FIN reads it back): 2 VGPRs less across the phases
         sh.cnt[t] = 0;                                    // (rew_ovr / hdr share storage with S2-S3 arrays: BUILD)
         if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
         if (t < 8) {
@@ -926,6 +928,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 }
             }
             if (r.del) meta |= M_DEL;
+            r.hdr = sh.hdr[t];                             // (kept in LDS since WALK / FX)
+            r.vir_dis = sh.virdis[t];
             hdr_word = pack_lanej(sh, r.hdr);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
