@@ -97,7 +97,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // General-geometry tick (lane_num 4 / 8): same workgroup-per-intersection structure, phases of
 // pve_tick_geo.h.  Correctness-first (per-vehicle scans instead of sorted lists).
 template <int CAP>
-__global__ __launch_bounds__(CAP) void k_tick_geo(const GeoConst g_arg, const Params P_arg)
+__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tick_geo(const GeoConst g_arg, const Params P_arg)
 {
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const PVE_AS4 GeoConst &g = *(const PVE_AS4 GeoConst *)ka0_;
