@@ -180,8 +180,13 @@ template <int CAP> struct Shared {
     u64 m_spawn[NW];
     // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
     // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
-    uint16_t s_idx[POOL];            // the same entries sorted by (vd, slot): index into u_vd / u_slot (no second
-                                     // copy of the distances: 4.4 KB less LDS = 10 instead of 8 workgroups per CU)
+    // CAP = 128: the entries sorted by (vd, slot) are an index array into u_vd / u_slot (no second copy of the
+    // distances: 4.4 KB less LDS = 10 instead of 8 workgroups per CU).  CAP = 64: LDS does not limit residency there
+    // (16 one-wave workgroups per CU either way), so the sorted copy is kept and WALK reads it without the index hop.
+    static constexpr bool DIRECT = (CAP == 64);
+    uint16_t s_idx[DIRECT ? 1 : POOL];
+    double s_vd[DIRECT ? POOL : 1];
+    uint8_t s_slot[DIRECT ? POOL : 1];
     uint8_t u_slot[POOL];
     union {
         uint8_t u_list[POOL];        // list of every entry (BUILD .. RANK)
@@ -576,7 +581,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
             }
             const int myslot = sh.u_slot[e];
-            sh.s_idx[lo + pos] = (uint16_t)e;
+            if (Sh::DIRECT) { sh.s_vd[lo + pos] = vd; sh.s_slot[lo + pos] = (uint8_t)myslot; }
+            else sh.s_idx[lo + pos] = (uint16_t)e;
             if (e - lo < sh.lcnt[d]) sh.mypos[myslot] = (int16_t)pos;   // own-lane segment comes first
         }
     }
@@ -594,9 +600,10 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         const double ps = r.p;
         const int base = sh.loff[lane], n = sh.loff[lane + 1] - base;
         if (head_thread) {                                // persisted for next tick's step (ref :1517)
-            const int e0 = sh.s_idx[base];
-            if (n > 0 && sh.u_vd[n > 0 ? e0 : 0] < INFINITY) {
-                const int hr = sh.u_slot[e0];
+            const int e0 = Sh::DIRECT ? 0 : sh.s_idx[base];
+            const double hvd = Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base : 0] : sh.u_vd[n > 0 ? e0 : 0];
+            if (n > 0 && hvd < INFINITY) {
+                const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[e0];
                 lds_or(&sh.hd.head_valid, 1 << lane);
                 int hl = sh.lane_of[hr];
                 sh.hd.head_lane[lane] = hl;
@@ -608,8 +615,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (!ctl) return;
         const int s = sh.mypos[t];
         const uint16_t *sidx = sh.s_idx + base;      // sorted position -> entry
-#define sv(pos_) sh.u_vd[sidx[pos_]]
-#define ss(pos_) sh.u_slot[sidx[pos_]]
+#define sv(pos_) (Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base + (pos_) : 0] : sh.u_vd[sidx[pos_]])
+#define ss(pos_) (Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base + (pos_) : 0] : sh.u_slot[sidx[pos_]])
         int pr = -1; double pvd = 0;
         if (s > 0) { pr = ss(s - 1); pvd = sv(s - 1); }                             // ref :1353-1354
         // The 6 nearest in the reference's stable |vd - vd_self| sort = the 6 smallest keys (|d|, vd, slot) (ref
