@@ -5,29 +5,36 @@
 one RCCL all-gather of the metrics vector after the timed region).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one fused tick (all step() calls + scene_update() + delete_vehicle()) of every env of the
-rank = one kernel launch.  Inputs (arrival streams, action pool) are resident in HBM before the timed
-region.  Rank 0 prints ONE JSON line.
+N > 1 without an outer launcher: bench.py starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a child process (before anything touches the GPU) and forwards rank 0's JSON line and the children's exit code.
+
+Protocol (reference loop main.py:397): the intersections are first filled to steady state by an
+UN-TIMED prefill (>= 300 ticks, continued until the mean population moves < 1 % over 50 ticks) whatever --warmup
+says; then W un-timed warm-up steps, then EXACTLY K timed steps between barrier + synchronize pairs.  A "step" =
+one fused tick (all step() calls + scene_update() + delete_vehicle()) of every env of the rank.  Inputs (arrival
+streams, action pool) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_ALG_FP64 = 380.0      # algorithmic bytes per vehicle-slot-step, FP64 layout (SURVEY.md §8d, DESIGN.md §4)
+B_ALG_FP64 = 380.0      # algorithmic bytes per vehicle-slot-step, FP64 layout (SURVEY.md §8d, DESIGN.md §3)
 B_ALG_OBS_F32 = 268.0   # the same with float32 observation rows (--obs-f32): 380 - 28 x 4 (SURVEY.md §8d, FP32 output)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
 N_POOL = 16
+PREFILL_MIN, PREFILL_CHUNK, PREFILL_MAX = 300, 50, 1000
+CPU_WARM, CPU_TICKS = 300, 200           # cpu_baseline sample: fixed, independent of --steps / --warmup
 
 
 def action_pool(n_envs, cap, seed):
@@ -40,63 +47,131 @@ def action_pool(n_envs, cap, seed):
     return a.astype(np.float32).astype(np.float64)
 
 
-def cpu_baseline(arr, pool, cap, warm, ticks, lane_num=12, choice=None):
-    """The CPU oracle (oracle/pve_oracle.c, a plain-C port of the reference algorithm) timed on this
-    host's cores on a bounded sample of the same workload: the first `n` envs of the same arrival
-    tensor with the same action pool, one env per thread-task, all cores busy."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(arr, pool, cap, lane_num=12, choice=None):
+    """The CPU oracle (oracle/pve_oracle.c, a plain-C port of the reference algorithm) timed on this host's cores on a
+    BOUNDED sample of the same workload: the first n envs of the same arrival tensor with the same action pool, 300
+    warm-up ticks (steady population) + 200 timed ticks each, independent of --steps / --warmup.  Two figures: every
+    hardware thread busy (envs statically dealt to the threads, one C call per env: the GIL is released inside), and one
+    thread alone."""
     from oracle.oracle import OracleEnv
     cores = os.cpu_count() or 1
-    n = min(arr.shape[0], max(cores * 8, 16))
-    if lane_num == 12:
-        envs = [OracleEnv(arr[e]) for e in range(n)]
-    else:
+
+    def make(e):
+        if lane_num == 12:
+            return OracleEnv(arr[e])
         from oracle.oracle_geo import OracleGeoEnv
-        envs = [OracleGeoEnv(arr[e], lane_num, choice=None if choice is None else choice[e]) for e in range(n)]
-    res = [None] * n
-    nxt = [0]
-    lock = threading.Lock()
+        return OracleGeoEnv(arr[e], lane_num, choice=None if choice is None else choice[e])
 
-    def worker(phase, nt, t0):
-        while True:
-            with lock:
-                i = nxt[0]
-                nxt[0] += 1
-            if i >= n:
-                return
-            res[i] = envs[i].run_pool(nt, pool[:, i, :], t0)
+    def timed(envs, n_threads):
+        res = [None] * len(envs)
 
-    def run(nt, t0):
-        nxt[0] = 0
-        ths = [threading.Thread(target=worker, args=(0, nt, t0)) for _ in range(cores)]
-        t = time.perf_counter()
-        [x.start() for x in ths]
-        [x.join() for x in ths]
-        return time.perf_counter() - t
+        def worker(k, nt, t0):
+            for i in range(k, len(envs), n_threads):
+                res[i] = envs[i][1].run_pool(nt, pool[:, envs[i][0], :], t0)
 
-    run(warm, 0)
-    dt = run(ticks, warm)
-    alive = sum(r[0] for r in res)
-    return dict(value=n * cap * ticks / dt, unit="env-steps/s", cores=cores, kind="port",
-                alive_steps_per_s=alive / dt,
-                sample="%d envs x %d ticks (after %d warm-up ticks) of the same synthetic workload, %d threads, "
-                       "%.2f s wall" % (n, ticks, warm, cores, dt))
+        def run(nt, t0):
+            ths = [threading.Thread(target=worker, args=(k, nt, t0)) for k in range(n_threads)]
+            t = time.perf_counter()
+            [x.start() for x in ths]
+            [x.join() for x in ths]
+            return time.perf_counter() - t
+
+        run(CPU_WARM, 0)
+        dt = run(CPU_TICKS, CPU_WARM)
+        return dt, sum(r[0] for r in res)
+
+    n = min(arr.shape[0], max(cores * 4, 16))
+    dt, alive = timed([(e, make(e)) for e in range(n)], min(cores, n))
+    n1 = min(arr.shape[0], 8)
+    dt1, alive1 = timed([(e, make(e)) for e in range(n1)], 1)
+    return dict(value=n * cap * CPU_TICKS / dt, unit="env-steps/s", cores=min(cores, n), kind="port",
+                cpu_model=cpu_model(), alive_steps_per_s=alive / dt,
+                mean_alive_per_env=alive / float(n * CPU_TICKS),
+                single_thread=dict(value=n1 * cap * CPU_TICKS / dt1, alive_steps_per_s=alive1 / dt1,
+                                   sample="%d envs x %d ticks, 1 thread, %.2f s wall" % (n1, CPU_TICKS, dt1)),
+                sample="%d envs x %d timed ticks (after %d un-timed warm-up ticks: steady population) of the same synthetic "
+                       "workload and action pool, %d threads, %.2f s wall" % (n, CPU_TICKS, CPU_WARM, min(cores, n), dt))
 
 
-def pmc_traffic(n_envs, cap, outputs, actor):
-    """HBM bytes per k_tick launch from the PMC counters (FETCH_SIZE x gfx950 correction + WRITE_SIZE). Counters
-    cannot be read from inside the process, so they come from the committed rocprofv3 passes of this very
-    command (tools/collect_profiles.sh -> profiles/r*_traffic.json); null when the config differs."""
+def csrc_sha():
+    """Fingerprint of the kernel sources: a committed PMC traffic figure only applies to the build it was measured on."""
+    d = os.path.join(ROOT, "pve-mcc_for_unsignalized_intersection_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".inc")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(envs_per_launch, cap, outputs, mode, other):
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x gfx950 correction + WRITE_SIZE).
+    Counters cannot be read from inside the process, so they come from the committed rocprofv3 passes of this very
+    command (tools/collect_profiles.sh -> profiles/r*_traffic.json); null unless kernel sources, config and launch
+    shape are the profiled ones."""
     import glob
+    import re
     default_outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
-    if actor or cap != 128 or tuple(outputs) != default_outputs:
+    if other or cap != 128 or tuple(outputs) != default_outputs:
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))
     if not files:
         return None, None
+    files.sort(key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)))
     t = json.load(open(files[-1]))
-    if int(t.get("envs_per_launch", 4096)) != n_envs:      # measured on launches of another size
+    if int(t.get("envs_per_launch", 4096)) != envs_per_launch or t.get("csrc_sha") != csrc_sha() \
+            or t.get("mode", "step") != mode:
         return None, None
-    return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return t, os.path.relpath(files[-1], ROOT)
+
+
+def self_launch(args_list, n):
+    """--gpus N without an outer torchrun: start the N ranks as a child process group (this process has not touched the
+    GPU), forward stdout (rank 0's JSON line) and return the children's exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + list(args_list)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    for l in (lines[-1:] if lines else p.stdout.splitlines()):
+        print(l, flush=True)
+    return p.returncode
+
+
+def measured_copy_peak(torch, dev):
+    """Device-to-device copy of 1 GiB (read + write counted): the bandwidth a streaming kernel reaches on this chip."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.zero_()
+    best = None
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * n / (best * 1e-3) / 1e9
 
 
 def main(argv=None, env_factory=None):
@@ -108,27 +183,38 @@ def main(argv=None, env_factory=None):
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--capacity", type=int, default=128)
-    ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default 1100 at cap 128, 500 at cap 64)")
+    ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default 1100 at cap 128, 450 at cap 64)")
+    ap.add_argument("--prefill", type=int, default=PREFILL_MIN,
+                    help="un-timed ticks that fill the intersections before warm-up (continued in chunks of 50 until the "
+                         "mean population moves < 1 %%); < 300 marks the line population=cold")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-copy-peak", action="store_true")
     ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
     ap.add_argument("--lane-num", type=int, default=12, choices=(12, 8, 4),
                     help="intersection layout; 12 = BASELINE metric (k_tick), 4 / 8 = SURVEY 8 f4 (k_tick_geo)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="free-running sub-batches per GPU, each on its own HIP stream (PipelinedIntersections); 1 = one "
                          "launch over all envs per step")
+    ap.add_argument("--mode", default=None, choices=("step", "rollout"),
+                    help="step: one pve_step_all launch per tick and sub-batch, enqueued from Python (the reference's "
+                         "caller protocol, main.py:397-441); rollout: pve_step_many -- the K ticks of the timed region are "
+                         "one call per sub-batch with the action source (pool / actor) on the device")
     ap.add_argument("--obs-f32", action="store_true",
                     help="float32 observation rows (PVE_CFG_OBS_F32; SURVEY 8d's FP32-output variant, 268 B algorithmic); "
                          "the headline / BASELINE metric is the float64 parity layout (380 B)")
     ap.add_argument("--actor", action="store_true",
-                    help="BASELINE config 5: close the loop on the device (k_actor -> k_tick per step) instead of the action pool")
+                    help="BASELINE config 5: close the loop on the device (actor -> tick per step) instead of the action pool")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nothing has touched the GPU yet (torch is imported below): children, never exec
+        sys.exit(self_launch(sys.argv[1:] if argv is None else argv, args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        sys.exit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
     import torch.distributed as dist
     emu = env_factory is not None
     if world > 1:
@@ -152,51 +238,90 @@ def main(argv=None, env_factory=None):
     from pve_mcc_amd.distributed import gather_metrics
 
     cap, n_envs, lane_num = args.capacity, args.envs, args.lane_num
-    rate = args.rate or {12: (1100.0 if cap == 128 else 500.0), 8: 1500.0, 4: 1800.0}[lane_num]
+    # capacity 64: 450 veh/h/lane keeps the peak population under 64 slots (no deferred spawns in the timed run)
+    rate = args.rate or {12: (1100.0 if cap == 128 else 450.0), 8: 1500.0, 4: 1800.0}[lane_num]
     K, W = args.steps, args.warmup
-    horizon = (K + W) * 0.1 + 20.0
+    prefill_min = max(0, args.prefill)
+    prefill_cap = max(prefill_min, PREFILL_MAX) if prefill_min >= PREFILL_MIN else prefill_min
+    horizon = (K + W + prefill_cap) * 0.1 + 20.0
     # weak scaling: every rank owns its own n_envs environments (global env index = rank*n_envs + e)
     arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=horizon, seed=20250213 + rank * n_envs, lane_num=lane_num)
     choice = synthetic_intentions(n_envs, arr.shape[1], seed=20250213 + rank * n_envs) if lane_num == 8 else None
     pool_np = action_pool(n_envs, cap, seed=99 + rank)
     outputs = tuple(x for x in args.outputs.split(",") if x)
     n_sub = max(1, min(args.pipeline, n_envs))
+    obs_dtype = torch.float32 if args.obs_f32 else torch.float64
     if emu:
         env = env_factory(n_envs, cap, arr, outputs)
         n_sub = getattr(env, "n_sub", 1)
     elif n_sub == 1:
         env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs, lane_num=lane_num,
-                                               intentions=choice,
-                                               obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+                                               intentions=choice, obs_dtype=obs_dtype)
     else:
         # the envs are independent: n_sub free-running sub-batches on their own streams pipeline the ticks (the chip-wide
         # LOAD / FIN bursts of one sub-batch overlap the compute phases of the other), DESIGN.md 5
         env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=n_sub, device=dev, outputs=outputs,
-                                                 lane_num=lane_num, intentions=choice,
-                                                 obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+                                                 lane_num=lane_num, intentions=choice, obs_dtype=obs_dtype)
+    mode = args.mode or ("rollout" if hasattr(env, "step_many") and lane_num == 12 else "step")
+    if mode == "rollout" and not hasattr(env, "step_many"):
+        sys.exit("--mode rollout: this build has no pve_step_many")
     pool = torch.as_tensor(pool_np, device=dev)
+    sync()                                            # the pool upload precedes every sub-batch stream's first launch
     env.reset()
     sub_streams = getattr(env, "streams", None) if not emu else None
     if args.actor:
         wpath = os.path.join(ROOT, "tests", "golden", "actor_66.npz")
         z = np.load(wpath)
         env.set_actor({k: z[k] for k in z.files})       # the reference's pretrained actor (model_data/baseline/66.cptk)
+    if mode == "rollout" and not args.actor:
+        env.set_action_pool(pool)
+    tick = [0]
+    step_kw = {"wait": False} if sub_streams else {}     # the pool upload was synchronised above
 
-    def one_step(t):
-        if args.actor:
-            env.step_with_actor()
+    def run_ticks(n):
+        """n ticks of every env of this rank, enqueued (not synchronised)."""
+        if n <= 0:
+            return
+        if mode == "rollout":
+            env.step_many(n, actor=args.actor)
+        elif args.actor:
+            for _ in range(n):
+                env.step_with_actor()
         else:
-            env.step(pool[t % N_POOL])
+            for t in range(tick[0], tick[0] + n):
+                env.step(pool[t % N_POOL], **step_kw)
+        tick[0] += n
 
-    for t in range(W):
-        one_step(t)
+    # ---- un-timed prefill to steady state (vehicle lifetime ~270 ticks): never part of --warmup
+    def alive_steps():
+        sync()
+        return env.metrics()["alive_steps"]
+
+    prefill, drift = 0, None
+    a_prev = alive_steps()
+    chunk_means = []
+    while True:
+        if prefill >= prefill_min and (prefill_min < PREFILL_MIN or prefill >= prefill_cap or
+                                       (drift is not None and drift < 0.01)):
+            break
+        n = min(PREFILL_CHUNK, prefill_min - prefill) if prefill < prefill_min else PREFILL_CHUNK
+        run_ticks(n)
+        prefill += n
+        a_now = alive_steps()
+        chunk_means.append((a_now - a_prev) / float(n * n_envs))
+        a_prev = a_now
+        if len(chunk_means) >= 2 and chunk_means[-1] > 0:
+            drift = abs(chunk_means[-1] - chunk_means[-2]) / chunk_means[-1]
+    steady = prefill >= PREFILL_MIN and drift is not None and drift < 0.01
+
+    run_ticks(W)
     sync()
     if world > 1:
         dist.barrier()
     sync()
     m0 = env.metrics()
     # HIP events on the streams the kernels are launched on: torch's current stream for one batch, every sub-batch
-    # stream for the pipelined form (start / end of the K launches of that stream)
+    # stream for the pipelined form (start / end of the K ticks of that stream)
     if not emu:
         ev_streams = sub_streams if sub_streams else [torch.cuda.current_stream(dev)]
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ev_streams]
@@ -204,8 +329,7 @@ def main(argv=None, env_factory=None):
     if not emu:
         for (e0, _), st in zip(evs, ev_streams):
             e0.record(st)
-    for t in range(W, W + K):
-        one_step(t)
+    run_ticks(K)
     if not emu:
         for (_, e1), st in zip(evs, ev_streams):
             e1.record(st)
@@ -214,7 +338,7 @@ def main(argv=None, env_factory=None):
         dist.barrier()
     sync()
     wall = time.perf_counter() - t0
-    # average duration of one launch on its stream (K back-to-back launches per stream)
+    # average duration of one tick of one sub-batch on its stream (K back-to-back ticks per stream)
     gpu_ms = (sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)) if not emu else wall * 1e3
     if world > 1:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -227,12 +351,19 @@ def main(argv=None, env_factory=None):
     if rank == 0:
         slot_steps = float(cap) * n_envs * K * world
         value = slot_steps / wall
-        kern_s = gpu_ms * 1e-3 / K                      # per launch (n_envs / n_sub envs), launches of the n_sub streams overlap
         b_alg = B_ALG_OBS_F32 if args.obs_f32 else B_ALG_FP64
         envs_per_launch = n_envs / float(n_sub)
+        # per GPU: algorithmic bytes of one tick of all the rank's envs / wall-clock per tick (NOT per-launch x launches)
+        achieved = b_alg * cap * n_envs / (wall / K) / 1e9
+        kern_s = gpu_ms * 1e-3 / K                      # one tick of one sub-batch (n_envs / n_sub envs) on its stream
         per_launch = b_alg * cap * envs_per_launch / kern_s / 1e9
-        achieved = per_launch * n_sub                    # n_sub launches of the kernel are in flight at any time
-        traffic, traffic_src = pmc_traffic(int(envs_per_launch), cap, outputs, args.actor or lane_num != 12 or args.obs_f32)
+        kname = (("k_rollout<%d>" if mode == "rollout" else "k_tick<%d>") if lane_num == 12 else "k_tick_geo<%d>") % cap
+        tr, traffic_src = (None, None) if (emu or not steady) else pmc_traffic(
+            int(envs_per_launch), cap, outputs, mode, args.actor or lane_num != 12 or args.obs_f32)
+        traffic = tr["hbm_bytes_per_launch"] if tr else None
+        counter_rate = (traffic * n_sub / (wall / K) / 1e9) if traffic else None
+        peak_meas = None if (emu or args.no_copy_peak) else measured_copy_peak(torch, dev)
+        mean_alive = tot["alive_steps"] / (K * n_envs * world)
         line = {
             "metric": "env-steps/sec (vehicles x envs x steps/s) at 128 veh x 4096 envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -242,28 +373,41 @@ def main(argv=None, env_factory=None):
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
                                       if args.actor else "sin action pool"),
-                       "envs_per_gpu": n_envs, "capacity": cap,
+                       "envs_per_gpu": n_envs, "capacity": cap, "mode": mode,
                        "parallelism": "env-parallel x%d" % world + (", %d stream-pipelined sub-batches of %d envs per GPU"
                                                                    % (n_sub, int(envs_per_launch)) if n_sub > 1 else ""),
                        "outputs": list(outputs), "obs_dtype": "f32" if args.obs_f32 else "f64"},
+            "population": "steady" if steady else "cold",
+            "prefill_ticks": prefill, "prefill_drift": drift,
             "alive_steps_per_s": tot["alive_steps"] / wall,
             "ctl_steps_per_s": tot["ctl_steps"] / wall,
-            "mean_alive_per_env": tot["alive_steps"] / (K * n_envs * world),
+            "mean_alive_per_env": mean_alive,
+            "mean_ctl_per_env": tot["ctl_steps"] / (K * n_envs * world),
             "overflow": tot["overflow"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
-                         "kernel": ("k_tick<%d>" if lane_num == 12 else "k_tick_geo<%d>") % cap, "kernel_ms": kern_s * 1e3,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_profiled_in": traffic_src,
+                         "achieved_counter_bytes": counter_rate,
+                         "frac_counter_bytes": (counter_rate / HBM_PEAK_GBS) if counter_rate else None,
+                         "peak_measured": peak_meas,
+                         "frac_of_peak_measured": (achieved / peak_meas) if peak_meas else None,
+                         "kernel": kname, "kernel_ms": kern_s * 1e3,
                          "alg_bytes_per_slot_step": b_alg, "envs_per_launch": int(envs_per_launch),
                          "concurrent_launches": n_sub, "per_launch_achieved": per_launch,
-                         "definition": "achieved = algorithmic bytes per launch / average launch duration (HIP events on "
-                                       "the launching stream) x launches in flight; with one sub-batch this is the plain "
-                                       "per-launch figure"},
+                         "definition": "achieved = algorithmic bytes (380 B x capacity x envs of the GPU, every slot counted, "
+                                       "SURVEY 8d) / wall-clock per tick; per_launch_achieved = the bytes of one sub-batch / "
+                                       "its tick time on its own stream (HIP events), sub-batches overlap; "
+                                       "achieved_counter_bytes = HBM bytes the PMC counters saw (traffic, profiled on this "
+                                       "very build and config, else null) / wall-clock per tick; peak_measured = 1 GiB "
+                                       "device copy, read + write"},
         }
         if args.actor:
-            line["roofline"]["note"] = "kernel_ms = k_actor + k_tick per step; achieved uses the tick's algorithmic bytes only"
+            line["roofline"]["note"] = "closed loop: actor + tick per step; achieved uses the tick's algorithmic bytes only"
+        if peak_meas and achieved > peak_meas:
+            line["roofline"]["note_above_copy_peak"] = ("algorithmic bytes exceed what a copy kernel moves in the same time: "
+                                                        "empty slots are counted but not moved")
         if not args.no_cpu_baseline and not args.actor and world == 1:      # reported at N=1 only
-            line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, min(W, 300), min(K, 200), lane_num, choice)
+            line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, lane_num, choice)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()                # every rank leaves together (rank 0 may still be timing the CPU baseline)

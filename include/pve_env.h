@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PVE_ABI_VERSION 2
+#define PVE_ABI_VERSION 3
 #define PVE_LANES 12          /* physical lanes: lane_num = 4, 8 or 12 (arrays are padded to 12) */
 #define PVE_MAX_DIRS 16       /* virtual-lane lists (routes): 12 for lane_num 4 / 12, 16 for lane_num 8 (ref :86, :132, :167) */
 #define PVE_OBS_WIDTH 28      /* (o_agent_num + 1) * 4, ref :1295 */
@@ -189,6 +189,35 @@ int pve_actor_forward(pve_handle h, const float *weights, const void *obs /* flo
  * never reads observations) unless out->state_pre is requested, which needs the previous rows (obs_prev_post). */
 int pve_step_all_actor(pve_handle h, const float *weights, const void *obs_in, double *actions,
                        const pve_outputs *out);
+
+/* MANY TICKS, host out of the loop: the reference's episode loop `for i in range(1000): ... step / scene_update /
+ * delete_vehicle` (main.py:397-441) with the action source on the device, as ONE call.  Tick k of the call is exactly
+ * pve_step_all() with
+ *   PVE_SRC_ZERO   actions = 0 (the zero policy of SURVEY.md 8d)
+ *   PVE_SRC_POOL   actions = pool[(pool_tick0 + k) % n_pool], pool = DEVICE float64 [n_pool][n_envs][capacity]
+ *   PVE_SRC_ACTOR  actions = pve_actor_forward(actor_weights, observation rows the previous tick stored), i.e. the closed
+ *                  loop of main.py:398-441 with the actor of model_agent_maddpg.py:23-49; the first tick reads
+ *                  `actor_obs` (zeros after pve_reset, ref :380), later ticks the rows written through out->obs_post,
+ *                  which is therefore required (and may be the same buffer as actor_obs when trajectory = 0)
+ * and the results are bit-identical to n_ticks separate calls (tested).  For lane_num = 12 the ticks run inside one
+ * kernel launch with the intersection state resident on the chip between ticks (k_rollout: no state traffic to HBM, only
+ * the per-tick outputs); other layouts enqueue n_ticks launches from C.
+ * trajectory = 0: every tick overwrites the `out` buffers (the last tick's outputs remain; metrics accumulate in the
+ * handle as usual); trajectory = 1: every non-NULL `out` buffer holds n_ticks consecutive per-tick blocks
+ * ([n_ticks][n_envs][cap]...), the roll-out a trainer consumes.  obs_pre / state_pre are not available here. */
+enum { PVE_SRC_ZERO = 0, PVE_SRC_POOL = 1, PVE_SRC_ACTOR = 2 };
+typedef struct pve_rollout {
+    int32_t n_ticks;
+    int32_t source;               /* PVE_SRC_* */
+    const double *pool;           /* PVE_SRC_POOL */
+    int32_t n_pool, pool_tick0;
+    const float *actor_weights;   /* PVE_SRC_ACTOR: DEVICE float32[PVE_ACTOR_N_WEIGHTS] */
+    const void *actor_obs;        /* PVE_SRC_ACTOR: rows the first tick's actor reads (float64, or float32 with PVE_CFG_OBS_F32) */
+    double *actor_actions;        /* PVE_SRC_ACTOR: DEVICE scratch float64 [n_envs][capacity] (holds the last tick's actions) */
+    int32_t trajectory;
+    int32_t reserved;
+} pve_rollout;
+int pve_step_many(pve_handle h, const pve_rollout *ro, const pve_outputs *out);
 
 /* Host read-back (synchronises the stream). */
 int pve_read_env(pve_handle h, int env, pve_env_info *out);

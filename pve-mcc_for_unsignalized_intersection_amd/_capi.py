@@ -20,7 +20,8 @@ PVE_NBR = 6
 PVE_N_METRICS = 12
 PVE_ENV_OUT_N = 8
 PVE_ACTOR_N_WEIGHTS = 6393
-ABI_VERSION = 2
+ABI_VERSION = 3
+SRC_ZERO, SRC_POOL, SRC_ACTOR = 0, 1, 2
 
 F_ALIVE, F_CTL, F_DONE, F_DELETED, F_FINISHED, F_LOCK = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
 F_INTENT_SHIFT = 6
@@ -46,6 +47,12 @@ class PveOutputs(C.Structure):
                 ("lanej", C.c_void_p), ("nbr", C.c_void_p), ("new_slot", C.c_void_p), ("env_out", C.c_void_p)]
 
 
+class PveRollout(C.Structure):
+    _fields_ = [("n_ticks", C.c_int32), ("source", C.c_int32), ("pool", C.c_void_p), ("n_pool", C.c_int32),
+                ("pool_tick0", C.c_int32), ("actor_weights", C.c_void_p), ("actor_obs", C.c_void_p),
+                ("actor_actions", C.c_void_p), ("trajectory", C.c_int32), ("reserved", C.c_int32)]
+
+
 class PveVehicle(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("p", "v", "a", "jerk", "jerk_sum", "vir_dis", "closer_p")] + \
                [(n, C.c_int32) for n in ("lane", "j", "id", "vnum", "seq_in_lane", "control", "finish", "done",
@@ -65,7 +72,7 @@ EXPORTS = ("pve_abi_version", "pve_last_error", "pve_default_config", "pve_works
            "pve_destroy", "pve_set_stream", "pve_set_arrivals", "pve_reset", "pve_step_all",
            "pve_scene_update", "pve_compact", "pve_read_env", "pve_read_vehicles", "pve_get_metrics",
            "pve_state_field", "pve_synchronize", "pve_debug_phase_cycles", "pve_actor_forward",
-           "pve_step_all_actor", "pve_debug_traffic_probe", "pve_set_intentions")
+           "pve_step_all_actor", "pve_debug_traffic_probe", "pve_set_intentions", "pve_step_many")
 
 
 def _declare(L):
@@ -93,6 +100,7 @@ def _declare(L):
     L.pve_debug_traffic_probe.argtypes = [vp, vp]
     L.pve_actor_forward.argtypes = [vp, vp, vp, vp]
     L.pve_step_all_actor.argtypes = [vp, vp, vp, vp, C.POINTER(PveOutputs)]
+    L.pve_step_many.argtypes = [vp, C.POINTER(PveRollout), C.POINTER(PveOutputs)]
     for name in EXPORTS:
         if name not in ("pve_last_error", "pve_workspace_bytes", "pve_default_config"):
             getattr(L, name).restype = C.c_int

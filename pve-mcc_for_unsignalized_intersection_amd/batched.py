@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import PveConfig, PveEnvInfo, PveOutputs, PveVehicle, PveError, check
+from ._capi import PveConfig, PveEnvInfo, PveOutputs, PveRollout, PveVehicle, PveError, check
 
 ALL_OUTPUTS = ("obs_post", "obs_pre", "reward", "flags", "lanej", "nbr", "new_slot", "env_out", "state_pre")
 DEFAULT_OUTPUTS = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
@@ -264,6 +264,68 @@ class BatchedIntersections:
         self.ticks += 1
         return self.outputs()
 
+    # ------------------------------------------------------------------ many ticks per call (pve_step_many)
+    def set_action_pool(self, pool):
+        """Action tape resident on the device: float64 [n_pool, n_envs, capacity]; tick number k since reset() uses
+        pool[k % n_pool] (what `step(pool[k % n_pool])` would pass)."""
+        p = torch.as_tensor(pool, dtype=torch.float64).contiguous().to(self.device)
+        if p.dim() != 3 or tuple(p.shape[1:]) != (self.n_envs, self.capacity):
+            raise PveError("action pool must be [n_pool, %d, %d]" % (self.n_envs, self.capacity))
+        self._pool = p
+
+    _TRAJ_SHAPES = dict(reward=(), flags=(), lanej=(), new_slot=(), nbr=(6,))
+
+    def step_many(self, n_ticks, actor=False, source=None, trajectory=False):
+        """n_ticks fused ticks in ONE call, the action source on the device (the reference's episode loop
+        main.py:397-441 without the host in it): source = "pool" (set_action_pool), "actor" (set_actor; closed loop)
+        or "zero".  Bit-identical to n_ticks step() / step_with_actor() calls.
+        trajectory=False: returns the usual output dict holding the LAST tick's outputs.
+        trajectory=True: returns a dict of [n_ticks, ...] tensors with every tick's outputs (a roll-out)."""
+        n_ticks = int(n_ticks)
+        if source is None:
+            source = "actor" if actor else ("pool" if getattr(self, "_pool", None) is not None else "zero")
+        self._bind_stream()
+        ro = PveRollout()
+        ro.n_ticks = n_ticks
+        ro.trajectory = 1 if trajectory else 0
+        if source == "pool":
+            if getattr(self, "_pool", None) is None:
+                raise PveError("step_many(source='pool'): call set_action_pool first")
+            ro.source, ro.pool, ro.n_pool = _capi.SRC_POOL, self._pool.data_ptr(), self._pool.shape[0]
+            ro.pool_tick0 = self.ticks % self._pool.shape[0]
+        elif source == "actor":
+            if getattr(self, "_actor_w", None) is None:
+                raise PveError("step_many(source='actor'): call set_actor first")
+            ro.source, ro.actor_weights = _capi.SRC_ACTOR, self._actor_w.data_ptr()
+            ro.actor_obs, ro.actor_actions = self._obs[self._obs_cur].data_ptr(), self._actor_actions.data_ptr()
+        elif source == "zero":
+            ro.source = _capi.SRC_ZERO
+        else:
+            raise PveError("unknown action source %r" % (source,))
+        if "obs_pre" in self.out or "state_pre" in self.out:
+            raise PveError("step_many: obs_pre / state_pre are single-tick outputs (use step())")
+        if not trajectory:
+            o = self._outputs_struct(flip_obs=False)
+            check(self.lib, self.lib.pve_step_many(self._h, C.byref(ro), C.byref(o)), "pve_step_many")
+            self.ticks += n_ticks
+            return self._out_dicts[self._obs_cur]
+        E, K, dev = self.n_envs, self.capacity, self.device
+        traj, o = {}, PveOutputs()
+        if self._obs is not None:
+            traj["obs_post"] = torch.zeros(n_ticks, E, K, 28, dtype=self.obs_dtype, device=dev)
+        for n, tns in self.out.items():
+            traj[n] = torch.zeros((n_ticks,) + tuple(tns.shape), dtype=tns.dtype, device=dev)
+        for n, tns in traj.items():
+            setattr(o, n, tns.data_ptr())
+        check(self.lib, self.lib.pve_step_many(self._h, C.byref(ro), C.byref(o)), "pve_step_many")
+        self.ticks += n_ticks
+        if n_ticks > 0:                      # the handle's single-tick views keep showing the latest tick
+            if self._obs is not None:
+                self._obs[self._obs_cur].copy_(traj["obs_post"][-1])
+            for n, tns in self.out.items():
+                tns.copy_(traj[n][-1])
+        return traj
+
     def scene_update(self, actions=None):
         """Split protocol, part 1: all step() calls + scene_update(); Done vehicles stay in place."""
         a = self._zero_actions if actions is None else actions
@@ -373,12 +435,18 @@ class PipelinedIntersections:
         for s in self.streams:
             s.wait_stream(stream)
 
-    def step(self, actions=None):
+    def step(self, actions=None, wait=True):
         """One fused tick of every sub-batch, each on its own stream.  actions: [n_envs, capacity] float64 (or a list of
-        per-sub-batch tensors, or None).  Returns the list of per-sub-batch output dicts."""
+        per-sub-batch tensors, or None).  Returns the list of per-sub-batch output dicts.
+        wait=True orders every sub-batch stream after torch's current stream (where `actions` are normally produced);
+        pass wait=False when the actions are known to be complete (e.g. a tape uploaded and synchronised earlier)."""
         outs = []
         for k, (sub, a) in enumerate(zip(self.subs, self._parts(actions))):
             if a is not None and self.streams[k] is not None:
+                # device-produced actions (a policy forward on torch's current stream) must be complete before the
+                # tick of sub-batch k reads them: an event wait, no host synchronisation
+                if wait:
+                    self.streams[k].wait_stream(torch.cuda.current_stream(self.device))
                 a.record_stream(self.streams[k])       # the caching allocator must not recycle it under the kernel
             outs.append(sub.step(a))
         return outs
@@ -390,6 +458,18 @@ class PipelinedIntersections:
 
     def step_with_actor(self):
         return [sub.step_with_actor() for sub in self.subs]
+
+    def set_action_pool(self, pool):
+        pool = torch.as_tensor(pool, dtype=torch.float64)
+        for k, sub in enumerate(self.subs):
+            with self._on(k):
+                sub.set_action_pool(pool[:, self.bounds[k]:self.bounds[k + 1]].contiguous())
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def step_many(self, n_ticks, actor=False, source=None, trajectory=False):
+        """n_ticks of every sub-batch, one pve_step_many call each (on its own stream)."""
+        return [sub.step_many(n_ticks, actor=actor, source=source, trajectory=trajectory) for sub in self.subs]
 
     def synchronize(self):
         for sub in self.subs:

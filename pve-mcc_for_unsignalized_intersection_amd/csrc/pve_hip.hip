@@ -237,6 +237,10 @@ struct Backend {
         else hipLaunchKernelGGL(k_tick<128>, dim3(P.n_envs), dim3(128), 0, s, c, P);
         return check_launch(err);
     }
+    static int launch_rollout(const Const &c, const Params &P, const RolloutArgs &R, int cap, void *stream, std::string &err)
+    {
+        return 1;
+    }
     static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)
     {
         hipStream_t s = (hipStream_t)stream;

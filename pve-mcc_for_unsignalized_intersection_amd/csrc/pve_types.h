@@ -115,6 +115,14 @@ struct Params {
     Outputs out;
 };
 
+// pve_step_many: action source and output addressing of a multi-tick launch (k_rollout)
+struct RolloutArgs {
+    const double *pool;          // PVE_SRC_POOL: [n_pool][n_envs][cap]
+    const float *actor_w;        // PVE_SRC_ACTOR
+    const void *actor_obs;
+    int32_t n_ticks, source, n_pool, pool_tick0, trajectory, pad_;
+};
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {

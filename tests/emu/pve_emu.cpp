@@ -100,6 +100,10 @@ struct Backend {
         if (cap == 64) emu_tick<64>(c, P); else emu_tick<128>(c, P);
         return 0;
     }
+    static int launch_rollout(const Const &c, const Params &P, const RolloutArgs &R, int cap, void *, std::string &)
+    {
+        return 1;
+    }
     static int launch_compact(const Params &P, int cap, void *, std::string &)
     {
         if (cap == 64) emu_compact<64>(P); else emu_compact<128>(P);

@@ -443,3 +443,172 @@ def check_pipelined_equals_single(backend, n_envs=7, n_sub=3, capacity=128, tick
     for k in m1:                                   # float sums differ in summation order only
         assert abs(m1[k] - m2[k]) <= 1e-9 * max(1.0, abs(m1[k])), (k, m1[k], m2[k])
     assert pipe.sub_of(n_envs - 1) == (n_sub - 1, pipe.subs[-1].n_envs - 1)
+
+
+def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1, 7, 40, 3, 60), rate=1100.0,
+                    prefill=0, trajectory_chunk=12):
+    """pve_step_many (n ticks per call, action source on the device) == n single-tick calls, bit for bit: persistent
+    state, headers, observation rows, last-tick outputs and -- trajectory mode -- the outputs of every tick."""
+    from pve_mcc_amd._capi import PveError
+    n_pool = 5
+    rng = np.random.default_rng(seed)
+    total = prefill + sum(chunks) + trajectory_chunk
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed)
+    outs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out", "lanej")
+    one = make_batch(arr, n_envs, capacity, backend, outputs=outs)
+    many = make_batch(arr, n_envs, capacity, backend, outputs=outs)
+    one.reset(); many.reset()
+    pool = torch.as_tensor(rng.uniform(-3, 3, size=(n_pool, n_envs, capacity))).to(one.device)
+    if source == "pool":
+        many.set_action_pool(pool)
+    if source == "actor":
+        from oracle.actor_np import flat_weights, load_weights
+        w = flat_weights(load_weights())
+        one.set_actor(w); many.set_actor(w)
+
+    def single():
+        if source == "pool":
+            return one.step(pool[one.ticks % n_pool])
+        if source == "actor":
+            return one.step_with_actor()
+        return one.step(None)
+
+    def same_outputs(o1, o2, what):
+        f = _np(o1["flags"])
+        assert np.array_equal(f, _np(o2["flags"])), what + ": flags"
+        alive, ctl = (f & 1) != 0, (f & 2) != 0
+        for k in ("reward", "new_slot", "lanej"):
+            assert np.array_equal(_np(o1[k])[alive], _np(o2[k])[alive]), what + ": " + k
+        assert np.array_equal(_np(o1["nbr"])[ctl], _np(o2["nbr"])[ctl]), what + ": nbr"
+        assert np.array_equal(_np(o1["env_out"]), _np(o2["env_out"])), what + ": env_out"
+
+    if prefill:
+        for _ in range(prefill):
+            single()
+        many.step_many(prefill, source=source)
+        batches_equal(one, many, "after prefill")
+    for n in chunks:
+        for _ in range(n):
+            o1 = single()
+        o2 = many.step_many(n, source=source)
+        one.synchronize(); many.synchronize()
+        assert many.ticks == one.ticks
+        batches_equal(one, many, "%s, chunk of %d" % (source, n))
+        same_outputs(o1, o2, "%s, chunk of %d" % (source, n))
+    # trajectory mode: every tick's outputs
+    traj = many.step_many(trajectory_chunk, source=source, trajectory=True)
+    for k in range(trajectory_chunk):
+        o1 = single()
+        same_outputs(o1, {n: traj[n][k] for n in traj}, "trajectory tick %d" % k)
+        post_ctl = (_np(one.state_field("meta")) & 1) != 0
+        assert np.array_equal(_np(one.obs)[post_ctl], _np(traj["obs_post"][k])[post_ctl]), "trajectory obs, tick %d" % k
+    batches_equal(one, many, "after the trajectory chunk")
+    assert np.array_equal(_np(many.out["flags"]), _np(one.out["flags"]))
+    m1, m2 = one.metrics(), many.metrics()
+    for k in m1:
+        assert m1[k] == m2[k], (k, m1[k], m2[k])
+    assert m1["ctl_steps"] > 0
+    assert many.step_many(0, source=source) is not None          # zero ticks: a no-op
+    batches_equal(one, many, "after a zero-tick call")
+    # misuse
+    bad = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "flags"))
+    bad.reset()
+    for fn in (lambda: bad.step_many(2, source="zero"), lambda: one.step_many(2, source="pool"),
+               lambda: many.step_many(2, source="nope")):
+        try:
+            fn()
+            raise AssertionError("misuse accepted")
+        except PveError:
+            pass
+
+
+def check_step_many_pipelined(backend, n_envs=5, n_sub=2, capacity=128, ticks=40, seed=73):
+    """PipelinedIntersections.step_many (one call per sub-batch, each on its own stream) == one batch stepped tick by tick."""
+    from pve_mcc_amd.batched import PipelinedIntersections
+    from tests.hip_adapter import emulator_lib
+    rng = np.random.default_rng(seed)
+    arr = synthetic_arrivals(n_envs, rate=1100.0, horizon_s=ticks * 0.1 + 30, seed=seed)
+    outs = ("obs_post", "reward", "flags", "env_out", "new_slot")
+    pool = torch.as_tensor(rng.uniform(-3, 3, size=(4, n_envs, capacity)))
+    one = make_batch(arr, n_envs, capacity, backend, outputs=outs)
+    kw = dict(device="cpu", _lib=emulator_lib()) if backend == "emu" else dict(device="cuda")
+    pipe = PipelinedIntersections(n_envs, capacity, arr, n_sub=n_sub, outputs=outs, **kw)
+    one.reset(); pipe.reset()
+    pipe.set_action_pool(pool)
+    pool_d = pool.to(one.device)
+    for t in range(ticks):
+        one.step(pool_d[t % 4])
+    pipe.step_many(ticks // 2)
+    pipe.step_many(ticks - ticks // 2)
+    pipe.synchronize(); one.synchronize()
+    for k in STATE_F + STATE_I:
+        x = _np(one.state_field(k))
+        y = np.concatenate([_np(sub.state_field(k)) for sub in pipe.subs], 0)
+        assert np.array_equal(x, y), "state %s differs" % k
+    assert np.array_equal(_np(one.obs), np.concatenate([_np(sub.obs) for sub in pipe.subs], 0))
+
+
+def check_full_size_vs_oracle(backend, n_envs, capacity, rate, ticks=420, n_sample=16, seed=20250213, many=0,
+                              n_pool=8):
+    """BASELINE-size batch (thousands of envs) past the 300-tick fill: `n_sample` envs spread over the batch are each
+    shadowed by their own CPU oracle on the same arrival stream and the same slot-indexed action tape, compared EVERY
+    tick (controlled set, rewards, collision / lock counters, neighbour ids, observation rows) and field by field at the
+    end; no deferred spawn anywhere in the batch.  many > 0: the batch is advanced by pve_step_many in chunks of `many`
+    ticks (trajectory outputs) instead of one pve_step_all per tick."""
+    rng = np.random.default_rng(seed)
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed)
+    outs = ("obs_post", "reward", "flags", "nbr", "env_out", "new_slot", "lanej")
+    b = make_batch(arr, n_envs, capacity, backend, outputs=outs)
+    b.reset()
+    sample = sorted(set(np.linspace(0, n_envs - 1, n_sample).astype(int).tolist()))
+    idx = torch.as_tensor(sample, device=b.device)
+    oracles = {e: OracleEnv(arr[e]) for e in sample}
+    pool_np = rng.uniform(-3, 3, size=(n_pool, n_envs, capacity)).astype(np.float32).astype(np.float64)
+    pool = torch.as_tensor(pool_np).to(b.device)
+    if many:
+        b.set_action_pool(pool)
+    peak = 0
+
+    def compare(t, rew, flags, eo, nbr, obs_post, new_slot):
+        nonlocal peak
+        for q, e in enumerate(sample):
+            o = oracles[e]
+            n = o.n_alive
+            peak = max(peak, n)
+            _vid, ctlm, _ = o.alive_view()
+            rec = o.tick(np.where(ctlm != 0, pool_np[t % n_pool, e, :n], 0.0))
+            ctl = (flags[q, :n] & 2) != 0
+            assert int(eo[q, 0]) == n and int(ctl.sum()) == len(rec["ids"]), "controlled set: tick %d env %d" % (t, e)
+            assert int(eo[q, 2]) == rec["collisions"] and int(eo[q, 3]) == rec["lock"], "counters: tick %d env %d" % (t, e)
+            assert np.array_equal(flags[q, :n][ctl] >> 8, rec["coll_pv"]), "coll_pv: tick %d env %d" % (t, e)
+            nb = nbr[q, :n][ctl].astype(np.int64)
+            nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)
+            assert np.array_equal(nb, rec["nbr"]), "neighbours: tick %d env %d" % (t, e)
+            assert close(rec["reward"], rew[q, :n][ctl], 1e-9), "reward: tick %d env %d" % (t, e)
+            ns = new_slot[q, :n][ctl]
+            kept = ns >= 0                                      # rows are stored at the post-compaction slot
+            assert close(rec["obs0"][kept], obs_post[q][ns[kept]], 1e-9), "obs rows: tick %d env %d" % (t, e)
+
+    t = 0
+    while t < ticks:
+        if many:
+            n = min(many, ticks - t)
+            traj = b.step_many(n, source="pool", trajectory=True)
+            host = {k: _np(traj[k].index_select(1, idx)) for k in ("reward", "flags", "env_out", "nbr", "obs_post", "new_slot")}
+            for k in range(n):
+                compare(t + k, *(host[x][k] for x in ("reward", "flags", "env_out", "nbr", "obs_post", "new_slot")))
+            t += n
+        else:
+            out = b.step(pool[t % n_pool])
+            compare(t, *(_np(out[x].index_select(0, idx)) for x in ("reward", "flags", "env_out", "nbr")),
+                    _np(b.obs.index_select(0, idx)), _np(out["new_slot"].index_select(0, idx)))
+            t += 1
+    for e in sample:
+        info, vi, vf = state_snapshot(b, e)
+        ovi, ovf, _ = oracles[e].vehicles()
+        assert np.array_equal(vi[:, :13], ovi[:, :13]), "final state ints, env %d" % e
+        assert close(ovf[:, :5], vf[:, :5], 1e-9), "final state floats, env %d" % e
+    m = b.metrics()
+    assert m["ticks"] == ticks * n_envs
+    assert m["overflow"] == 0, "deferred spawns at %g veh/h/lane x %d slots (peak of the sampled envs: %d)" % (rate, capacity, peak)
+    return m, peak

@@ -37,19 +37,47 @@ def check_line(out, n):
     else:
         assert "cpu_baseline" not in d
     assert abs(d["value"] - 64 * 12 * 6 * n / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6
+    # roofline.achieved follows from the line's own wall clock: B_alg x slots of ONE GPU / time per tick
+    assert abs(r["achieved"] - 380.0 * 64 * 12 / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
+    assert d["population"] in ("steady", "cold") and "mean_alive_per_env" in d and "prefill_ticks" in d
     return d
 
 
 def test_bench_single_process_emulated():
     out = subprocess.check_output([sys.executable, "tests/bench_emulated_launcher.py", "--envs", "12", "--capacity", "64",
-                                   "--steps", "6", "--warmup", "3"], cwd=ROOT, text=True, timeout=600)
-    check_line(out, 1)
+                                   "--steps", "6", "--warmup", "3", "--prefill", "0"], cwd=ROOT, text=True, timeout=600)
+    d = check_line(out, 1)
+    assert d["population"] == "cold" and d["prefill_ticks"] == 0
+    c = d["cpu_baseline"]
+    assert c["single_thread"]["value"] > 0 and c["cpu_model"] and "300 un-timed warm-up" in c["sample"]
+
+
+def test_bench_prefill_is_untimed_and_reported():
+    """--prefill runs before (and is not part of) --warmup; a short prefill marks the line cold."""
+    out = subprocess.check_output([sys.executable, "tests/bench_emulated_launcher.py", "--envs", "4", "--capacity", "64",
+                                   "--steps", "6", "--warmup", "3", "--prefill", "20", "--no-cpu-baseline"],
+                                  cwd=ROOT, text=True, timeout=600)
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    d = json.loads(lines[0])
+    assert d["prefill_ticks"] == 20 and d["population"] == "cold" and d["warmup"] == 3 and d["steps"] == 6
 
 
 def test_bench_two_ranks_gloo_emulated():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "tests/bench_emulated_launcher.py", "--gpus", "2",
-           "--envs", "12", "--capacity", "64", "--steps", "6", "--warmup", "3"]
+           "--envs", "12", "--capacity", "64", "--steps", "6", "--warmup", "3", "--prefill", "0"]
     out = subprocess.check_output(cmd, cwd=ROOT, text=True, timeout=900, stderr=subprocess.DEVNULL)
     d = check_line(out, 2)
+    assert d["config"]["parallelism"] == "env-parallel x2"
+
+
+def test_bench_self_launches_two_ranks():
+    """`bench.py --gpus 2` with no outer launcher starts its own ranks (the driver calls it that way) and forwards
+    rank 0's line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "tests/bench_emulated_launcher.py", "--gpus", "2", "--envs", "12", "--capacity", "64",
+                        "--steps", "6", "--warmup", "3", "--prefill", "0"], cwd=ROOT, text=True, timeout=900, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    assert p.returncode == 0
+    d = check_line(p.stdout, 2)
     assert d["config"]["parallelism"] == "env-parallel x2"

@@ -267,3 +267,51 @@ def test_gpu_pipelined_sub_batches_equal_one_batch():
     """Two / three free-running sub-batches on their own HIP streams == one launch over all envs, bit for bit."""
     scenarios.check_pipelined_equals_single(BACKEND, n_envs=64, n_sub=2, ticks=300)
     scenarios.check_pipelined_equals_single(BACKEND, n_envs=37, n_sub=3, ticks=200, actor=True)
+
+
+@pytest.mark.parametrize("source", ["pool", "zero", "actor"])
+def test_gpu_step_many_equals_single_ticks(source):
+    """pve_step_many (many ticks per call, action source on the device) == single pve_step_all ticks, bit for bit,
+    from a cold start, and again from a filled population (prefill)."""
+    scenarios.check_step_many(BACKEND, source, n_envs=6, chunks=(1, 7, 40, 3, 60), trajectory_chunk=12)
+    if source == "pool":
+        scenarios.check_step_many(BACKEND, source, n_envs=4, prefill=320, chunks=(25,), trajectory_chunk=10, seed=5)
+        scenarios.check_step_many(BACKEND, source, n_envs=5, capacity=64, rate=450.0, chunks=(5, 30, 90), trajectory_chunk=8)
+
+
+def test_gpu_step_many_pipelined():
+    scenarios.check_step_many_pipelined(BACKEND, n_envs=37, n_sub=3, ticks=120)
+
+
+@pytest.mark.parametrize("cap,rate,many", [(128, 1100.0, 0), (64, 450.0, 0), (128, 1100.0, 30), (64, 450.0, 35)])
+def test_gpu_full_size_oracle_spot_checks(cap, rate, many):
+    """BASELINE configs 2 / 3 (and config 4's per-GPU shard) at FULL size, steady state: 4096 envs, 420 ticks (past the
+    300-tick fill), 16 envs spread over the batch compared with their oracles every tick; overflow == 0."""
+    m, peak = scenarios.check_full_size_vs_oracle(BACKEND, 4096, cap, rate, ticks=420, n_sample=16, many=many)
+    assert m["alive_steps"] / m["ticks"] > (60 if cap == 128 else 20)      # the batch really is at steady state
+    assert peak <= cap
+
+
+def test_gpu_full_size_actor_closed_loop_matches_small_batch():
+    """step_with_actor on 4096 envs == the same streams stepped as a 16-env batch (config 5 at full size)."""
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    from oracle.actor_np import flat_weights, load_weights
+    n, ticks = 4096, 330
+    arr = synthetic_arrivals(n, rate=1100.0, horizon_s=ticks * 0.1 + 30, seed=4242)
+    sample = np.linspace(0, n - 1, 16).astype(int)
+    outs = ("obs_post", "reward", "flags", "env_out", "new_slot")
+    big = make_batch(arr, n, 128, BACKEND, outputs=outs)
+    small = make_batch(arr[sample], len(sample), 128, BACKEND, outputs=outs)
+    w = flat_weights(load_weights())
+    for b in (big, small):
+        b.reset()
+        b.set_actor(w)
+    for t in range(ticks):
+        big.step_with_actor()
+        small.step_with_actor()
+    idx = torch.as_tensor(sample, device="cuda")
+    for k in ("p", "v", "a", "jerk_sum", "vir_dis", "closer_p", "id", "step", "count", "meta"):
+        assert torch.equal(big.state_field(k).index_select(0, idx), small.state_field(k)), k
+    assert torch.equal(big.obs.index_select(0, idx), small.obs)
+    m = big.metrics()
+    assert m["overflow"] == 0 and m["alive_steps"] / m["ticks"] > 40

@@ -58,3 +58,13 @@ def test_float32_observation_rows():
 def test_pipelined_sub_batches_equal_one_batch():
     scenarios.check_pipelined_equals_single(BACKEND, n_envs=7, n_sub=3, ticks=120)
     scenarios.check_pipelined_equals_single(BACKEND, n_envs=4, n_sub=2, ticks=80, actor=True)
+
+
+@pytest.mark.parametrize("source", ["pool", "zero", "actor"])
+def test_step_many_equals_single_ticks(source):
+    scenarios.check_step_many(BACKEND, source, n_envs=3, chunks=(1, 7, 40, 3), trajectory_chunk=6)
+
+
+def test_step_many_capacity_64_and_pipelined():
+    scenarios.check_step_many(BACKEND, "pool", n_envs=3, capacity=64, rate=450.0, chunks=(5, 30), trajectory_chunk=4)
+    scenarios.check_step_many_pipelined(BACKEND)
