@@ -183,7 +183,7 @@ def main(argv=None, env_factory=None):
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--capacity", type=int, default=128)
-    ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default 1100 at cap 128, 450 at cap 64)")
+    ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default 1100 at cap 128, 350 at cap 64)")
     ap.add_argument("--prefill", type=int, default=PREFILL_MIN,
                     help="un-timed ticks that fill the intersections before warm-up (continued in chunks of 50 until the "
                          "mean population moves < 1 %%); < 300 marks the line population=cold")
@@ -238,8 +238,9 @@ def main(argv=None, env_factory=None):
     from pve_mcc_amd.distributed import gather_metrics
 
     cap, n_envs, lane_num = args.capacity, args.envs, args.lane_num
-    # capacity 64: 450 veh/h/lane keeps the peak population under 64 slots (no deferred spawns in the timed run)
-    rate = args.rate or {12: (1100.0 if cap == 128 else 450.0), 8: 1500.0, 4: 1800.0}[lane_num]
+    # capacity 64: 350 veh/h/lane keeps the peak population of 4096 envs x 2300 ticks at 57 of 64 slots (oracle run): no deferred
+    # spawn ever enters a timed run (400 peaks at 62, 450 at 64+, 500 overflowed 4539 times in round 1)
+    rate = args.rate or {12: (1100.0 if cap == 128 else 350.0), 8: 1500.0, 4: 1800.0}[lane_num]
     K, W = args.steps, args.warmup
     prefill_min = max(0, args.prefill)
     prefill_cap = max(prefill_min, PREFILL_MAX) if prefill_min >= PREFILL_MIN else prefill_min

@@ -29,10 +29,11 @@ typedef __attribute__((address_space(4))) const char *KernargPtr;
         tprev_ = now_;                                                                   \
     }
 
-// 5 waves per SIMD (<= 96 VGPR) + the 15.1 KB LDS block = 10 workgroups of 128 threads per CU instead of 8: with the
-// sub-batches pipelined on several streams the tick scales almost linearly with the resident workgroups.
+// CAP = 128: 5 waves per SIMD (<= 96 VGPR) + the 15.1 KB LDS block = 10 workgroups of 128 threads per CU instead of 8: with
+// the sub-batches pipelined on several streams the tick scales almost linearly with the resident workgroups.
+// CAP = 64: one wave per workgroup, LDS (10 KB) admits 16 workgroups per CU = 4 waves per SIMD (<= 128 VGPR).
 template <int CAP>
-__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tick(const Const c_arg, const Params P_arg)
+__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(CAP == 64 ? 4 : 5, CAP == 64 ? 4 : 5))) void k_tick(const Const c_arg, const Params P_arg)
 {
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka0_;
@@ -91,6 +92,95 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         unsigned long long *row = P.phase_cycles + ((size_t)env * (CAP / 64) + (t >> 6)) * 16;
 #pragma unroll
         for (int k = 0; k < 12; k++) row[k] += pc_[k];
+    }
+}
+
+// LDS-only workgroup barrier: orders LDS accesses (lgkmcnt) but does not wait for this wave's outstanding global
+// loads / stores (no vmcnt(0)), so that prefetches and the output stores of one tick stay in flight across the phases
+// of the next.  __syncthreads() remains where global memory must be ordered.
+__device__ __forceinline__ void lds_barrier_x()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+// pve_step_many: R.n_ticks ticks of one intersection per workgroup, the state resident in registers / LDS between the
+// ticks (pve_tick_core.h, "k_rollout").  Per tick only the outputs go to HBM; the action of the next tick (pool) and
+// the next arrival times are prefetched under the tail of the current one.
+// WPE = waves per SIMD the register allocation is held to: 4 (<= 128 VGPR, no spills: 8 workgroups of 128 threads per CU,
+// i.e. 4096 intersections in exactly two rounds) or 5 (<= 96 VGPR, 10 per CU for stream-pipelined sub-batches).
+template <int CAP, int WPE>
+__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout(const Const c_arg, const Params P_arg,
+                                                                                               const RolloutArgs R_arg)
+{
+    KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
+    __shared__ Shared<CAP> sh;
+    const int t0_ = threadIdx.x;
+    const int env0_ = blockIdx.x;
+    Regs r;
+    FinCarry fc;
+    typedef Tick<CAP> T;
+    int pool_idx, n_ticks;
+    {
+        const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka0_;
+        const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
+        const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
+        pool_idx = R.pool_tick0;
+        n_ticks = R.n_ticks;
+        T::ph_load(c, P, env0_, t0_, sh, r);            // P.actions = the first tick's actions
+    }
+    for (int k = 0; k < n_ticks; k++) {
+        // The loop body is one tick of the single-tick kernel.  Without the two opaque copies below the compiler's
+        // loop-invariant code motion hoists every kernel-argument load and every per-thread address out of the loop
+        // (~150 scalar + ~140 vector registers live across the whole tick -> spills / 2 waves per SIMD).
+        KernargPtr ka = ka0_;
+        int t = t0_, env = env0_;
+        asm volatile("" : "+s"(ka), "+v"(t), "+s"(env));
+        const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka;
+        const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka + OFF_P);
+        const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka + OFF_R);
+        lds_barrier();
+        if (k > 0) T::ph_tick_init(c, t, sh, r);
+        T::ph_step1(c, P, env, t, sh, r);
+        lds_barrier();
+        T::ph_step2(c, t, sh, r);
+        T::ph_lists_a(c, t, sh);
+        lds_barrier();
+        T::ph_step3(c, t, sh, r);
+        T::ph_step3_publish(t, sh, r);
+        T::ph_lists_b(t, sh);
+        lds_barrier();
+        T::ph_build(c, t, sh, r);
+        lds_barrier();
+        T::ph_rank(t, sh);
+        lds_barrier();
+        T::ph_scan(c, t, sh, r);
+        T::ph_reward(c, t, sh, r);
+        lds_barrier();
+        int nx = -1;
+        if (k + 1 < n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
+        T::ph_prefetch_action(P, R, env, t, nx, r);
+        T::ph_effects(c, t, sh, r);
+        lds_barrier();
+        T::ph_prefetch_arrival(P, env, t, sh, r, NL);
+        T::ph_lock(c, t, sh, r);
+        lds_barrier();
+        T::ph_lock2(t, sh, r);
+        __syncthreads();                              // vmcnt(0): the previous tick's output stores precede this tick's
+        T::ph_park_action(t, sh, r);
+        const Outputs O = T::tick_outputs(P, R, k);
+        T::template ph_final<true>(c, P, O, env, t, sh, r, fc);
+        lds_barrier();                                // A: nobody reads the tick's work arrays any more
+        T::ph_stage(c, t, sh, r, fc);
+        lds_barrier();                                // B: the staging area is complete
+        if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
+    }
+    {
+        const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
+        T::ph_flush(P, env0_, t0_, sh);
     }
 }
 
@@ -237,9 +327,22 @@ struct Backend {
         else hipLaunchKernelGGL(k_tick<128>, dim3(P.n_envs), dim3(128), 0, s, c, P);
         return check_launch(err);
     }
-    static int launch_rollout(const Const &c, const Params &P, const RolloutArgs &R, int cap, void *stream, std::string &err)
+    static int launch_rollout(const Const &c, const Params &P_in, const RolloutArgs &R, int cap, void *stream, std::string &err)
     {
-        return 1;
+        static const bool off = getenv("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
+        if (off || R.source == 2 /* PVE_SRC_ACTOR: actor + tick launches */) return 1;
+        hipStream_t s = (hipStream_t)stream;
+        Params P = P_in;
+        RolloutArgs Rk = R;
+        if (R.source == 1) {
+            Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
+            P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
+        } else P.actions = nullptr;
+        static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
+        if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
+        else if (w5) hipLaunchKernelGGL((k_rollout<128, 5>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
+        else hipLaunchKernelGGL((k_rollout<128, 4>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
+        return check_launch(err);
     }
     static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)
     {

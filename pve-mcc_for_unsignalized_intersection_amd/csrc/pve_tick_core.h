@@ -155,15 +155,41 @@ PVE_HD void block_sum(double *red, int t, double x)
 // ------------------------------------------------------------------ shared (LDS) block of one env
 template <int CAP> struct Shared {
     static constexpr int NW = CAP / 64;
+    static constexpr int POOL = 5 * CAP;
+    // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
+    // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
+    // CAP = 128: the entries sorted by (vd, slot) are an index array into u_vd / u_slot (no second copy of the
+    // distances: 4.4 KB less LDS = 10 instead of 8 workgroups per CU).  CAP = 64: LDS does not limit residency there
+    // (16 one-wave workgroups per CU either way), so the sorted copy is kept and WALK reads it without the index hop.
+    static constexpr bool DIRECT = (CAP == 64);
     EnvHeader hd;
     double p[CAP], v[CAP], a[CAP];   // post-step kinematics of every slot
-    static constexpr int POOL = 5 * CAP;
     union {                          // p1/v1 die at the barrier after S3, the lists are born after it
         struct { double p1[CAP], v1[CAP]; };   // step outcome "if braking" (S1-S3 only)
         double u_vd[POOL];           // virtual distance of every list entry (segment order)
     };
     double virdis[CAP];
     int cnt[CAP];                    // collision hits received: early | late << 16
+    alignas(8) uint16_t s_idx[DIRECT ? 1 : POOL];
+    double s_vd[DIRECT ? POOL : 1];
+    alignas(8) uint8_t u_slot[POOL];
+    // k_rollout keeps the state on the chip between two ticks: every persistent field of every vehicle moves to its
+    // new slot through LDS.  The staging arrays live in storage that is dead by then:
+    //   EARLY (written at the top of FIN, the tick's work arrays still being read): jerk, jerk_sum, vir_dis, closer_p in
+    //         u_vd[CAP .. 5 CAP) (the dead-lock records only use u_vd[0 .. CAP)); the 7 ints in s_idx / p / cnt / u_slot /
+    //         u_list[CAP ..) (CAP = 128; the dead-lock scratch lk_slot only uses the first CAP bytes) or s_vd (CAP = 64) -- all dead after WALK / REWARD / FX;
+    //   LATE  (after the barrier behind FIN): p in u_vd[0 .. CAP), v and a in place.
+    // so that FIN holds no more registers than in the single-tick kernel while it builds the observation rows.
+    enum { SF_JERK = 0, SF_JERK_SUM, SF_VIR_DIS, SF_CLOSER_P, SF_P, SF_V, SF_A };
+    template <int K> PVE_HD double *stf()
+    {
+        return K < 4 ? u_vd + (K + 1) * CAP : (K == SF_P ? u_vd : (K == SF_V ? v : a));
+    }
+    template <int K> PVE_HD int *sti()   // K = I_ID .. I_HDR
+    {
+        if (DIRECT) return (int *)s_vd + K * CAP;
+        return K < 2 ? (int *)s_idx + K * CAP : (K < 4 ? (int *)p + (K - 2) * CAP : (K == 4 ? cnt : (K == 5 ? (int *)u_slot : (int *)(u_list + CAP))));
+    }
     int acc_passed_steps, acc_collisions;
     // Arrays with disjoint lifetimes share storage: the CAP = 64 block must stay <= 10 KB so that 16 workgroups
     // (all 4096 envs of BASELINE config 2) are resident per CU; LDS is allocated in 1 KB granules.
@@ -178,18 +204,9 @@ template <int CAP> struct Shared {
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_coll[NW];
     union { u64 m_lead[NW]; u64 m_keep[NW]; };   // tick kernel | compaction kernel
     u64 m_spawn[NW];
-    // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
-    // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
-    // CAP = 128: the entries sorted by (vd, slot) are an index array into u_vd / u_slot (no second copy of the
-    // distances: 4.4 KB less LDS = 10 instead of 8 workgroups per CU).  CAP = 64: LDS does not limit residency there
-    // (16 one-wave workgroups per CU either way), so the sorted copy is kept and WALK reads it without the index hop.
-    static constexpr bool DIRECT = (CAP == 64);
-    uint16_t s_idx[DIRECT ? 1 : POOL];
-    double s_vd[DIRECT ? POOL : 1];
     uint8_t s_slot[DIRECT ? POOL : 1];
-    uint8_t u_slot[POOL];
     union {
-        uint8_t u_list[POOL];        // list of every entry (BUILD .. RANK)
+        alignas(8) uint8_t u_list[POOL];   // list of every entry (BUILD .. RANK)
         uint8_t lk_slot[POOL];       // dead-lock scratch: slot of the record filed at each rank (LOCK2 .. FIN)
     };
     union {
@@ -203,7 +220,10 @@ template <int CAP> struct Shared {
     int16_t loff[NL + 1];            // list d occupies [loff[d], loff[d+1])
     int16_t segoff[NL][5];           // start of segment (own, conflict 0..3) inside list d
     uint8_t lane_of[CAP];            // lane of every alive slot
-    float xy32[CAP][2];              // single-precision position of every controlled vehicle (collision pre-filter)
+    union {
+        float xy32[CAP][2];          // single-precision position of every controlled vehicle (collision pre-filter; BUILD .. REWARD)
+        double act_next[CAP];        // k_rollout: the NEXT tick's action of every slot, prefetched under the tail of this tick
+    };
     union {
         double tabA[2][4];           // get_virtual_distance table (copy of Const, lane-indexed reads; BUILD only)
         struct { double red_reward[NW], red_jerk[NW]; };   // per-wave partial sums (LOCK .. FIN)
@@ -228,6 +248,16 @@ struct Regs {
     int intent, route, ord;          // general-geometry path only (intention, direction[lane][intention], processing order)
     double act;                      // this tick's action of the slot (loaded with the state, used by S1)
     double next_arr;                 // lane t < 12 that spawns: its next arrival time (loaded in LOCK, stored in FIN)
+    double act_nx;                   // k_rollout: next tick's action of this slot (global load in flight under FX .. LOCK2)
+};
+// k_rollout: what FIN hands over to the staging step behind the next barrier (values read from the header / the work
+// arrays before anybody rewrites them)
+struct FinCarry {
+    int new_slot;                    // of the vehicle in slot t (< 0: deleted or empty)
+    int ls;                          // t <= NL: lane_start[t] after re-pack + spawn
+    int sp_slot, sp_id, sp_vnum;     // t < NL: slot / id / id_info[1] of the vehicle lane t spawns (sp_slot < 0: none)
+    int n_post, n_sp, n_over, n_fin, n_ctl, n_lock, n_coll, n_pre;
+    double sr, sj;
 };
 struct CRegs {                       // MODE_COMPACT moves every persistent field verbatim
     double p, v, a, jerk, jerk_sum, vir_dis, closer_p;
@@ -898,12 +928,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         return (l << 16) | (slot - sh.hd.lane_start[l]);
     }
 
-    static PVE_HD void ph_final(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    // RES = false: the tick kernel -- state and header go back to HBM (`O` = P.out).
+    // RES = true:  k_rollout -- outputs only (`O` = this tick's block of the output buffers); the persistent fields and
+    //              the header updates are handed to ph_stage through `fc` and stay on the chip.
+    template <bool RES, class OutT>
+    static PVE_HD void ph_final(const PVE_AS4 Const &c, const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh,
+                                Regs &r, FinCarry &fc)
     {
         EnvHeader &gh = P.headers[env];
         const int N = sh.hd.n_alive;
         const size_t gpre = (size_t)env * CAP + t;
-        const bool fused = (P.mode == MODE_FUSED);
+        const bool fused = RES || (P.mode == MODE_FUSED);
         // ---- spawn set (ref :361, :378-433); a full env defers the spawn (cursor not advanced)
         const unsigned want = (unsigned)(sh.m_spawn[0] & 0xFFFull);
         unsigned sp = 0; int room = CAP - N;
@@ -940,7 +975,16 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             hdr_word = pack_lanej(sh, r.hdr);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
-                store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
+                if (!RES)
+                    store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
+                else {                     // EARLY staging: these registers die here, as in the single-tick kernel
+                    const int s = new_slot;
+                    sh.template stf<Sh::SF_JERK>()[s] = r.jerk; sh.template stf<Sh::SF_JERK_SUM>()[s] = r.jerk_sum;
+                    sh.template stf<Sh::SF_VIR_DIS>()[s] = r.vir_dis; sh.template stf<Sh::SF_CLOSER_P>()[s] = r.closer_p;
+                    sh.template sti<I_ID>()[s] = r.id; sh.template sti<I_SEQ>()[s] = r.seq; sh.template sti<I_VNUM>()[s] = r.vnum;
+                    sh.template sti<I_STEP>()[s] = r.step; sh.template sti<I_COUNT>()[s] = r.count;
+                    sh.template sti<I_META>()[s] = meta; sh.template sti<I_HDR>()[s] = hdr_word;
+                }
             }
         }
         // ---- new lane starts
@@ -949,46 +993,55 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             int ls12 = mask_below<NW>(keep, sh.hd.lane_start[NL]) + __builtin_popcount(sp);
             n_post = ls12;
         }
+        fc.new_slot = new_slot;
+        fc.ls = 0; fc.sp_slot = -1; fc.sp_id = 0; fc.sp_vnum = 0;
         if (t <= NL) {
             int ls = mask_below<NW>(keep, sh.hd.lane_start[t]) + __builtin_popcount(sp & ((1u << t) - 1u));
-            gh.lane_start[t] = ls;
+            if (RES) fc.ls = ls; else gh.lane_start[t] = ls;
         }
         // ---- spawned vehicles (one per lane at most), ref :395-433
         if (t < NL && ((sp >> t) & 1)) {
             int slot = mask_below<NW>(keep, sh.hd.lane_start[t + 1]) + __builtin_popcount(sp & ((1u << t) - 1u));
-            Regs nv;
-            nv.p = c.spawn_p[t % 3]; nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
-            nv.vir_dis = 100; nv.closer_p = 150;
-            nv.id = sh.hd.id_seq + __builtin_popcount(sp & ((1u << t) - 1u));
-            nv.seq = sh.hd.veh_rec[t];
-            nv.vnum = sh.hd.lane_start[t + 1] - sh.hd.lane_start[t];
-            nv.step = 0; nv.count = 0;
-            size_t gs = (size_t)env * CAP + slot;
-            store_slot(P, gs, nv, M_CONTROL | M_ALIVE, -1);
-            const int rec1 = sh.hd.veh_rec[t] + 1;
-            gh.veh_rec[t] = rec1;
-            gh.next_arr[t] = r.next_arr;
+            const int nid = sh.hd.id_seq + __builtin_popcount(sp & ((1u << t) - 1u));
+            const int nvnum = sh.hd.lane_start[t + 1] - sh.hd.lane_start[t];
+            if (RES) { fc.sp_slot = slot; fc.sp_id = nid; fc.sp_vnum = nvnum; }
+            else {
+                Regs nv;
+                nv.p = c.spawn_p[t % 3]; nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
+                nv.vir_dis = 100; nv.closer_p = 150;
+                nv.id = nid;
+                nv.seq = sh.hd.veh_rec[t];
+                nv.vnum = nvnum;
+                nv.step = 0; nv.count = 0;
+                size_t gs = (size_t)env * CAP + slot;
+                store_slot(P, gs, nv, M_CONTROL | M_ALIVE, -1);
+                const int rec1 = sh.hd.veh_rec[t] + 1;
+                gh.veh_rec[t] = rec1;
+                gh.next_arr[t] = r.next_arr;
+            }
         }
-        if (P.out.obs_post && sp) {
+        if (O.obs_post && sp) {
             // zero observation rows of the spawned vehicles (ref :380, :420): one coalesced 224-B store per spawn
             // by 28 lanes instead of 28 stores by the spawning lane; the loop over the set bits is wave-uniform
             for (unsigned rem = sp; rem; rem &= rem - 1) {
                 const int l = __builtin_ctz(rem);
                 const int slot = mask_below<NW>(keep, sh.hd.lane_start[l + 1]) + __builtin_popcount(sp & ((1u << l) - 1u));
                 if (t < OBSW) {
-                    if (P.obs_f32) ((float *)P.out.obs_post)[((size_t)env * CAP + slot) * OBSW + t] = 0.0f;
-                    else P.out.obs_post[((size_t)env * CAP + slot) * OBSW + t] = 0.0;
+                    if (P.obs_f32) ((float *)O.obs_post)[((size_t)env * CAP + slot) * OBSW + t] = 0.0f;
+                    else O.obs_post[((size_t)env * CAP + slot) * OBSW + t] = 0.0;
                 }
             }
         }
         // ---- clear the tail so stale slots never look alive
-        if (t >= n_post && t < N) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }   // slots >= N are clear already
+        if (!RES && t >= n_post && t < N) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }   // slots >= N are clear already
         // ---- header
-        if (t < NL) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
+        if (!RES && t < NL) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
         const int n_ctl = mask_count<NW>(sh.m_ctl);
         const int n_lock = mask_count<NW>(sh.m_lead);
         const int n_fin = mask_count<NW>(sh.m_fin);
         const int n_del = mask_count<NW>(sh.m_del);
+        fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp); fc.n_over = n_over; fc.n_fin = n_fin; fc.n_ctl = n_ctl;
+        fc.n_lock = n_lock; fc.n_coll = mask_count<NW>(sh.m_coll); fc.n_pre = N; fc.sr = 0; fc.sj = 0;
         if (t == 0) {
             double sr = 0, sj = 0;
 #if PVE_DEVICE_CODE
@@ -996,46 +1049,49 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 #else
             sr = sh.red_reward[0]; sj = sh.red_jerk[0];
 #endif
-            gh.current_time = sh.hd.current_time;
-            gh.n_alive = n_post;
-            gh.id_seq = sh.hd.id_seq + __builtin_popcount(sp);
-            gh.passed = sh.hd.passed + n_fin;                                     // ref :356
-            gh.passed_step_total = sh.hd.passed_step_total + sh.acc_passed_steps; // ref :359
-            gh.head_valid = sh.hd.head_valid;
-            gh.sum_reward = sh.hd.sum_reward + sr;
-            gh.sum_jerk = sh.hd.sum_jerk + sj;
-            gh.alive_steps = sh.hd.alive_steps + N;
-            gh.ctl_steps = sh.hd.ctl_steps + n_ctl;
-            gh.ticks = sh.hd.ticks + 1;
-            gh.collided = sh.hd.collided + mask_count<NW>(sh.m_coll);
-            gh.locks = sh.hd.locks + n_lock;
-            gh.overflow = sh.hd.overflow + n_over;
-            if (P.out.env_out) {
-                int *eo = P.out.env_out + (size_t)env * 8;
+            fc.sr = sr; fc.sj = sj;
+            if (!RES) {
+                gh.current_time = sh.hd.current_time;
+                gh.n_alive = n_post;
+                gh.id_seq = sh.hd.id_seq + __builtin_popcount(sp);
+                gh.passed = sh.hd.passed + n_fin;                                     // ref :356
+                gh.passed_step_total = sh.hd.passed_step_total + sh.acc_passed_steps; // ref :359
+                gh.head_valid = sh.hd.head_valid;
+                gh.sum_reward = sh.hd.sum_reward + sr;
+                gh.sum_jerk = sh.hd.sum_jerk + sj;
+                gh.alive_steps = sh.hd.alive_steps + N;
+                gh.ctl_steps = sh.hd.ctl_steps + n_ctl;
+                gh.ticks = sh.hd.ticks + 1;
+                gh.collided = sh.hd.collided + fc.n_coll;
+                gh.locks = sh.hd.locks + n_lock;
+                gh.overflow = sh.hd.overflow + n_over;
+            }
+            if (O.env_out) {
+                int *eo = O.env_out + (size_t)env * 8;
                 eo[0] = N; eo[1] = n_ctl; eo[2] = sh.acc_collisions;
                 eo[3] = n_lock; eo[4] = n_del; eo[5] = n_fin; eo[6] = __builtin_popcount(sp); eo[7] = n_post;
             }
         }
         // ---- per-tick outputs, pre-compaction indexing
-        if (P.out.flags) {
+        if (O.flags) {
             int f = 0;
             if (r.alive) {
                 f = 0x01 | (r.ctl ? 0x02 : 0) | ((r.meta & M_DONE) ? 0x04 : 0) | (r.del ? 0x08 : 0) |
                     (r.fin ? 0x10 : 0) | (lockf ? 0x20 : 0) | (r.ctl ? (r.coll_seen << 8) : 0);
             }
-            P.out.flags[gpre] = f;
+            O.flags[gpre] = f;
         }
         // per-slot outputs other than `flags` are written for the slots that held a vehicle only (`flags` = 0 marks
         // the rest): 36 B x ~43 empty slots per env are 6 MB per launch, i.e. ~0.8 us of store burst
-        if (P.out.reward && r.alive) P.out.reward[gpre] = r.ctl ? r.reward : 0.0;
-        if (P.out.lanej && r.alive) P.out.lanej[gpre] = (r.lane << 16) | r.j;
-        if (P.out.new_slot && r.alive) P.out.new_slot[gpre] = new_slot;
-        if (P.out.nbr && r.alive && r.ctl) {           // controlled vehicles only (PVE_F_CTL in flags)
-            int *nb = P.out.nbr + gpre * NNB;
+        if (O.reward && r.alive) O.reward[gpre] = r.ctl ? r.reward : 0.0;
+        if (O.lanej && r.alive) O.lanej[gpre] = (r.lane << 16) | r.j;
+        if (O.new_slot && r.alive) O.new_slot[gpre] = new_slot;
+        if (O.nbr && r.alive && r.ctl) {           // controlled vehicles only (PVE_F_CTL in flags)
+            int *nb = O.nbr + gpre * NNB;
 #pragma unroll
             for (int k = 0; k < NNB; k++) nb[k] = pack_lanej(sh, r.kr[k]);
         }
-        if (r.alive && r.ctl && (P.out.obs_pre || (P.out.obs_post && new_slot >= 0))) {
+        if (r.alive && r.ctl && (O.obs_pre || (O.obs_post && new_slot >= 0))) {
             // row 0 of the state, ref :1325-1337
             double row[OBSW];
             row[0] = r.p; row[1] = r.v; row[2] = r.a; row[3] = (double)r.lane;
@@ -1049,24 +1105,142 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                     row[4 + 4 * k] = 0; row[5 + 4 * k] = 0; row[6 + 4 * k] = 0; row[7 + 4 * k] = 0;
                 }
             }
-            if (P.out.obs_pre) {
-                double *o = P.out.obs_pre + gpre * OBSW;
+            if (O.obs_pre) {
+                double *o = O.obs_pre + gpre * OBSW;
 #pragma unroll
                 for (int k = 0; k < OBSW; k++) o[k] = row[k];
             }
-            if (P.out.obs_post && new_slot >= 0) {
+            if (O.obs_post && new_slot >= 0) {
                 if (P.obs_f32) {                    // uniform: float32 rows (half the bytes of the largest output)
-                    float *o = (float *)P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+                    float *o = (float *)O.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
 #pragma unroll
                     for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
                 } else {
-                    double *o = P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+                    double *o = O.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
 #pragma unroll
                     for (int k = 0; k < OBSW; k++) o[k] = row[k];
                 }
             }
         }
     }
+    // the tick kernel's FIN
+    static PVE_HD void ph_final(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        FinCarry fc;
+        ph_final<false>(c, P, P.out, env, t, sh, r, fc);
+    }
+
+    // ============================================================== k_rollout: many ticks per launch, state on the chip
+    // Per tick:  [RELOAD | first tick: LOAD]  S1 .. LOCK2  FIN<RES>  | barrier A |  STAGE  | barrier B |
+    // and FLUSH after the last tick.  Only the per-tick outputs (and the prefetched actions / arrival times) touch HBM.
+    //
+    // this tick's block of the output buffers (trajectory roll-outs: block k; else the same buffers every tick)
+    static PVE_HD Outputs tick_outputs(const PVE_AS4 Params &P, const PVE_AS4 RolloutArgs &R, int k)
+    {
+        Outputs o;
+        const long long s = R.trajectory ? (long long)k * P.n_envs * CAP : 0;
+        o.obs_post = P.out.obs_post ? (P.obs_f32 ? (double *)((float *)P.out.obs_post + s * OBSW) : P.out.obs_post + s * OBSW) : nullptr;
+        o.obs_pre = nullptr; o.state_pre = nullptr; o.obs_prev_post = nullptr;
+        o.reward = P.out.reward ? P.out.reward + s : nullptr;
+        o.flags = P.out.flags ? P.out.flags + s : nullptr;
+        o.lanej = P.out.lanej ? P.out.lanej + s : nullptr;
+        o.nbr = P.out.nbr ? P.out.nbr + s * NNB : nullptr;
+        o.new_slot = P.out.new_slot ? P.out.new_slot + s : nullptr;
+        o.env_out = P.out.env_out ? P.out.env_out + (R.trajectory ? (long long)k * P.n_envs * 8 : 0) : nullptr;
+        return o;
+    }
+    // next tick's action of slot t: the load is issued under FX .. LOCK2 and parked in LDS at the start of FIN
+    static PVE_HD void ph_prefetch_action(const PVE_AS4 Params &P, const PVE_AS4 RolloutArgs &R, int env, int t, int pool_idx,
+                                          Regs &r)
+    {
+        r.act_nx = 0;
+        if (R.source == 1 /* PVE_SRC_POOL */ && pool_idx >= 0)
+            r.act_nx = R.pool[((size_t)pool_idx * P.n_envs + env) * CAP + t];
+    }
+    static PVE_HD void ph_park_action(int t, Sh &sh, Regs &r) { sh.act_next[t] = r.act_nx; }   // xy32 is dead after REWARD
+    // STAGE (after barrier A: nobody reads this tick's work arrays any more): every kept vehicle moves to its new slot,
+    // the spawned ones are born, the header advances in place
+    static PVE_HD void ph_stage(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r, const FinCarry &fc)
+    {
+        if (fc.new_slot >= 0) {                          // LATE staging (the rest went at the top of FIN)
+            const int s = fc.new_slot;
+            sh.template stf<Sh::SF_P>()[s] = r.p; sh.template stf<Sh::SF_V>()[s] = r.v; sh.template stf<Sh::SF_A>()[s] = r.a;
+        }
+        if (fc.sp_slot >= 0) {                           // t < NL: the vehicle lane t spawns (ref :395-433)
+            const int s = fc.sp_slot;
+            sh.template stf<Sh::SF_P>()[s] = c.spawn_p[t % 3]; sh.template stf<Sh::SF_V>()[s] = c.v0;
+            sh.template stf<Sh::SF_A>()[s] = 0; sh.template stf<Sh::SF_JERK>()[s] = 0; sh.template stf<Sh::SF_JERK_SUM>()[s] = 0;
+            sh.template stf<Sh::SF_VIR_DIS>()[s] = 100; sh.template stf<Sh::SF_CLOSER_P>()[s] = 150;
+            sh.template sti<I_ID>()[s] = fc.sp_id; sh.template sti<I_SEQ>()[s] = sh.hd.veh_rec[t];
+            sh.template sti<I_VNUM>()[s] = fc.sp_vnum; sh.template sti<I_STEP>()[s] = 0; sh.template sti<I_COUNT>()[s] = 0;
+            sh.template sti<I_META>()[s] = M_CONTROL | M_ALIVE; sh.template sti<I_HDR>()[s] = -1;
+            sh.hd.veh_rec[t] += 1;
+            sh.hd.next_arr[t] = r.next_arr;
+        }
+        if (t <= NL) sh.hd.lane_start[t] = fc.ls;
+        if (t == 0) {
+            sh.hd.n_alive = fc.n_post;
+            sh.hd.id_seq += fc.n_sp;
+            sh.hd.passed += fc.n_fin;                                             // ref :356
+            sh.hd.passed_step_total += sh.acc_passed_steps;                       // ref :359
+            sh.hd.sum_reward = sh.hd.sum_reward + fc.sr;
+            sh.hd.sum_jerk = sh.hd.sum_jerk + fc.sj;
+            sh.hd.alive_steps += fc.n_pre;
+            sh.hd.ctl_steps += fc.n_ctl;
+            sh.hd.ticks += 1;
+            sh.hd.collided += fc.n_coll;
+            sh.hd.locks += fc.n_lock;
+            sh.hd.overflow += fc.n_over;
+        }
+    }
+    // RELOAD (after barrier B): slot t's vehicle from the staging arrays, its action from the prefetch
+    static PVE_HD void ph_reload(int t, Sh &sh, Regs &r)
+    {
+        const int N = sh.hd.n_alive;
+        r.alive = t < N;
+        r.jerk = 0;
+        r.p = r.v = r.a = r.jerk_sum = r.vir_dis = r.closer_p = 0;
+        r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
+        if (t < N) {
+            r.p = sh.template stf<Sh::SF_P>()[t]; r.v = sh.template stf<Sh::SF_V>()[t]; r.a = sh.template stf<Sh::SF_A>()[t];
+            r.jerk_sum = sh.template stf<Sh::SF_JERK_SUM>()[t]; r.vir_dis = sh.template stf<Sh::SF_VIR_DIS>()[t];
+            r.closer_p = sh.template stf<Sh::SF_CLOSER_P>()[t];
+            r.id = sh.template sti<I_ID>()[t]; r.seq = sh.template sti<I_SEQ>()[t]; r.vnum = sh.template sti<I_VNUM>()[t];
+            r.step = sh.template sti<I_STEP>()[t]; r.count = sh.template sti<I_COUNT>()[t]; r.meta = sh.template sti<I_META>()[t];
+        }
+        r.act = sh.act_next[t];
+    }
+    // work-array initialisation of a resident tick (what LOAD does besides loading), after the barrier behind RELOAD
+    static PVE_HD void ph_tick_init(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
+    {
+        sh.virdis[t] = r.vir_dis;
+        sh.cnt[t] = 0;
+        if (t == 0) {
+            sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0;
+            sh.hd.current_time = sh.hd.current_time + c.deltaT;                   // ref :223 (repeated +=, not tick*dt)
+        }
+        if (t < 8) sh.tabA[t >> 2][t & 3] = c.vdA[t >> 2][t & 3];                // its storage held the reward / jerk sums
+    }
+    // FLUSH (after the last tick's barrier B): staging area + header -> HBM
+    static PVE_HD void ph_flush(const PVE_AS4 Params &P, int env, int t, Sh &sh)
+    {
+        const int N = sh.hd.n_alive;
+        const size_t g = (size_t)env * CAP + t;
+        if (t < N) {
+            P.f64[F_P][g] = sh.template stf<Sh::SF_P>()[t]; P.f64[F_V][g] = sh.template stf<Sh::SF_V>()[t];
+            P.f64[F_A][g] = sh.template stf<Sh::SF_A>()[t]; P.f64[F_JERK][g] = sh.template stf<Sh::SF_JERK>()[t];
+            P.f64[F_JERK_SUM][g] = sh.template stf<Sh::SF_JERK_SUM>()[t]; P.f64[F_VIR_DIS][g] = sh.template stf<Sh::SF_VIR_DIS>()[t];
+            P.f64[F_CLOSER_P][g] = sh.template stf<Sh::SF_CLOSER_P>()[t];
+            P.i32[I_ID][g] = sh.template sti<I_ID>()[t]; P.i32[I_SEQ][g] = sh.template sti<I_SEQ>()[t];
+            P.i32[I_VNUM][g] = sh.template sti<I_VNUM>()[t]; P.i32[I_STEP][g] = sh.template sti<I_STEP>()[t];
+            P.i32[I_COUNT][g] = sh.template sti<I_COUNT>()[t]; P.i32[I_META][g] = sh.template sti<I_META>()[t];
+            P.i32[I_HDR][g] = sh.template sti<I_HDR>()[t];
+        } else { P.i32[I_META][g] = 0; P.i32[I_ID][g] = -1; }                     // stale slots never look alive
+        int *dst = (int *)&P.headers[env];
+        const int *src = (const int *)&sh.hd;
+        for (int w = t; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];
+    }
+
     // ============================================================== STATE: full 7x28 state (training outputs)
     // rows 1..6 = the neighbour's own latest row 0 (ref :1332): already recomputed this tick if the
     // neighbour precedes us in (lane, j) order ("fresh", read back from obs_pre written in FIN), else

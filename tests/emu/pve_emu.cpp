@@ -47,6 +47,51 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
     delete shp;
 }
 
+// k_rollout: the resident multi-tick form, phase by phase exactly as the kernel orders them
+template <int CAP> static void emu_rollout(const Const &c, const Params &P, const RolloutArgs &R)
+{
+    typedef Tick<CAP> T;
+    std::vector<Regs> regs(CAP);
+    std::vector<FinCarry> fcs(CAP);
+    Shared<CAP> *shp = new Shared<CAP>();
+    for (int env = 0; env < P.n_envs; env++) {
+        Shared<CAP> &sh = *shp;
+        memset(&sh, 0, sizeof(sh));
+        int pool_idx = R.pool_tick0;
+        for (int t = 0; t < CAP; t++) T::ph_load(c, P, env, t, sh, regs[t]);
+        for (int k = 0; k < R.n_ticks; k++) {
+            for (int w = 0; w < CAP / 64; w++)      // the emulator's vote() ORs bits: start every tick from empty masks
+                sh.m_alive[w] = sh.m_ctl[w] = sh.m_del[w] = sh.m_fin[w] = sh.m_ctlnow[w] = sh.m_coll[w] = sh.m_lead[w] = sh.m_spawn[w] = 0;
+            sh.emu_scan = 0;
+            if (k > 0) for (int t = 0; t < CAP; t++) T::ph_tick_init(c, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_step1(c, P, env, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_step2(c, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_lists_a(c, t, sh);
+            for (int t = 0; t < CAP; t++) T::ph_step3(c, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_step3_publish(t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_lists_b(t, sh);
+            for (int t = 0; t < CAP; t++) T::ph_build(c, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
+            for (int t = 0; t < CAP; t++) T::ph_scan(c, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_reward(c, t, sh, regs[t]);
+            int nx = -1;
+            if (k + 1 < R.n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
+            for (int t = 0; t < CAP; t++) T::ph_prefetch_action(P, R, env, t, nx, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_effects(c, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_prefetch_arrival(P, env, t, sh, regs[t], NL);
+            for (int t = 0; t < CAP; t++) T::ph_lock(c, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_park_action(t, sh, regs[t]);
+            const Outputs O = T::tick_outputs(P, R, k);
+            for (int t = 0; t < CAP; t++) T::template ph_final<true>(c, P, O, env, t, sh, regs[t], fcs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_stage(c, t, sh, regs[t], fcs[t]);
+            if (k + 1 < R.n_ticks) for (int t = 0; t < CAP; t++) T::ph_reload(t, sh, regs[t]);
+        }
+        for (int t = 0; t < CAP; t++) T::ph_flush(P, env, t, sh);
+    }
+    delete shp;
+}
+
 template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
 {
     typedef TickGeo<CAP> T;
@@ -100,9 +145,17 @@ struct Backend {
         if (cap == 64) emu_tick<64>(c, P); else emu_tick<128>(c, P);
         return 0;
     }
-    static int launch_rollout(const Const &c, const Params &P, const RolloutArgs &R, int cap, void *, std::string &)
+    static int launch_rollout(const Const &c, const Params &P_in, const RolloutArgs &R, int cap, void *, std::string &)
     {
-        return 1;
+        if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2) return 1;
+        Params P = P_in;
+        RolloutArgs Rk = R;
+        if (R.source == 1) {
+            Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
+            P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
+        } else P.actions = nullptr;
+        if (cap == 64) emu_rollout<64>(c, P, Rk); else emu_rollout<128>(c, P, Rk);
+        return 0;
     }
     static int launch_compact(const Params &P, int cap, void *, std::string &)
     {

@@ -276,19 +276,19 @@ def test_gpu_step_many_equals_single_ticks(source):
     scenarios.check_step_many(BACKEND, source, n_envs=6, chunks=(1, 7, 40, 3, 60), trajectory_chunk=12)
     if source == "pool":
         scenarios.check_step_many(BACKEND, source, n_envs=4, prefill=320, chunks=(25,), trajectory_chunk=10, seed=5)
-        scenarios.check_step_many(BACKEND, source, n_envs=5, capacity=64, rate=450.0, chunks=(5, 30, 90), trajectory_chunk=8)
+        scenarios.check_step_many(BACKEND, source, n_envs=5, capacity=64, rate=350.0, chunks=(5, 30, 90), trajectory_chunk=8)
 
 
 def test_gpu_step_many_pipelined():
     scenarios.check_step_many_pipelined(BACKEND, n_envs=37, n_sub=3, ticks=120)
 
 
-@pytest.mark.parametrize("cap,rate,many", [(128, 1100.0, 0), (64, 450.0, 0), (128, 1100.0, 30), (64, 450.0, 35)])
+@pytest.mark.parametrize("cap,rate,many", [(128, 1100.0, 0), (64, 350.0, 0), (128, 1100.0, 30), (64, 350.0, 35)])
 def test_gpu_full_size_oracle_spot_checks(cap, rate, many):
     """BASELINE configs 2 / 3 (and config 4's per-GPU shard) at FULL size, steady state: 4096 envs, 420 ticks (past the
     300-tick fill), 16 envs spread over the batch compared with their oracles every tick; overflow == 0."""
     m, peak = scenarios.check_full_size_vs_oracle(BACKEND, 4096, cap, rate, ticks=420, n_sample=16, many=many)
-    assert m["alive_steps"] / m["ticks"] > (60 if cap == 128 else 20)      # the batch really is at steady state
+    assert m["alive_steps"] / m["ticks"] > (60 if cap == 128 else 15)      # the batch really is at steady state
     assert peak <= cap
 
 
