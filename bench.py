@@ -199,6 +199,8 @@ def main(argv=None, env_factory=None):
                     help="step: one pve_step_all launch per tick and sub-batch, enqueued from Python (the reference's "
                          "caller protocol, main.py:397-441); rollout: pve_step_many -- the K ticks of the timed region are "
                          "one call per sub-batch with the action source (pool / actor) on the device")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="rollout mode: ticks per kernel launch (0 = the whole call in one launch)")
     ap.add_argument("--obs-f32", action="store_true",
                     help="float32 observation rows (PVE_CFG_OBS_F32; SURVEY 8d's FP32-output variant, 268 B algorithmic); "
                          "the headline / BASELINE metric is the float64 parity layout (380 B)")
@@ -263,7 +265,13 @@ def main(argv=None, env_factory=None):
         # LOAD / FIN bursts of one sub-batch overlap the compute phases of the other), DESIGN.md 5
         env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=n_sub, device=dev, outputs=outputs,
                                                  lane_num=lane_num, intentions=choice, obs_dtype=obs_dtype)
-    mode = args.mode or ("rollout" if hasattr(env, "step_many") and lane_num == 12 else "step")
+    # auto: pve_step_many (state resident on the chip, host out of the loop) where it is the faster product path --
+    # capacity 64 always (one wave per intersection, all 4096 resident at once: 16.3 vs 21.9 us per tick); capacity 128
+    # when the timed region is long enough for launches of 25 ticks per sub-batch to keep the chip full (36.1 vs 36.9 us);
+    # short runs use one pve_step_all launch per tick and sub-batch (finer launch granularity, shorter tail)
+    mode = args.mode or ("rollout" if (not emu and lane_num == 12 and not args.actor and (cap == 64 or K >= 100)) else "step")
+    if mode == "rollout" and args.chunk == 0 and cap == 128:
+        args.chunk = 25
     if mode == "rollout" and not hasattr(env, "step_many"):
         sys.exit("--mode rollout: this build has no pve_step_many")
     pool = torch.as_tensor(pool_np, device=dev)
@@ -284,7 +292,7 @@ def main(argv=None, env_factory=None):
         if n <= 0:
             return
         if mode == "rollout":
-            env.step_many(n, actor=args.actor)
+            env.step_many(n, actor=args.actor, chunk=args.chunk)
         elif args.actor:
             for _ in range(n):
                 env.step_with_actor()

@@ -215,7 +215,11 @@ typedef struct pve_rollout {
     const void *actor_obs;        /* PVE_SRC_ACTOR: rows the first tick's actor reads (float64, or float32 with PVE_CFG_OBS_F32) */
     double *actor_actions;        /* PVE_SRC_ACTOR: DEVICE scratch float64 [n_envs][capacity] (holds the last tick's actions) */
     int32_t trajectory;
-    int32_t reserved;
+    int32_t chunk_ticks;          /* 0: all n_ticks in one launch; > 0: launches of at most chunk_ticks ticks each (same results).
+                                     Every workgroup of a launch runs its intersection for all the ticks of the launch, so a
+                                     launch lasts as long as its slowest intersection: with several handles stepped on their
+                                     own streams, shorter launches let the other handles' workgroups fill the slots that the
+                                     fast intersections free (bench.py --chunk). */
 } pve_rollout;
 int pve_step_many(pve_handle h, const pve_rollout *ro, const pve_outputs *out);
 

@@ -50,7 +50,7 @@ class PveOutputs(C.Structure):
 class PveRollout(C.Structure):
     _fields_ = [("n_ticks", C.c_int32), ("source", C.c_int32), ("pool", C.c_void_p), ("n_pool", C.c_int32),
                 ("pool_tick0", C.c_int32), ("actor_weights", C.c_void_p), ("actor_obs", C.c_void_p),
-                ("actor_actions", C.c_void_p), ("trajectory", C.c_int32), ("reserved", C.c_int32)]
+                ("actor_actions", C.c_void_p), ("trajectory", C.c_int32), ("chunk_ticks", C.c_int32)]
 
 
 class PveVehicle(C.Structure):

@@ -88,6 +88,7 @@ class BatchedIntersections:
         if "state_pre" in names:
             names.update(("obs_pre", "obs_post"))
         self._obs = None
+        self._obs_cur = 0
         if "obs_post" in names:
             # state_pre reads the rows the previous tick stored (stale neighbour rows, ref :1332): ping-pong pair.
             # Otherwise ONE buffer: the tick never reads observations, and 117 MB less working set per 4096 envs
@@ -275,7 +276,7 @@ class BatchedIntersections:
 
     _TRAJ_SHAPES = dict(reward=(), flags=(), lanej=(), new_slot=(), nbr=(6,))
 
-    def step_many(self, n_ticks, actor=False, source=None, trajectory=False):
+    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0):
         """n_ticks fused ticks in ONE call, the action source on the device (the reference's episode loop
         main.py:397-441 without the host in it): source = "pool" (set_action_pool), "actor" (set_actor; closed loop)
         or "zero".  Bit-identical to n_ticks step() / step_with_actor() calls.
@@ -288,6 +289,7 @@ class BatchedIntersections:
         ro = PveRollout()
         ro.n_ticks = n_ticks
         ro.trajectory = 1 if trajectory else 0
+        ro.chunk_ticks = int(chunk)
         if source == "pool":
             if getattr(self, "_pool", None) is None:
                 raise PveError("step_many(source='pool'): call set_action_pool first")
@@ -467,9 +469,11 @@ class PipelinedIntersections:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
-    def step_many(self, n_ticks, actor=False, source=None, trajectory=False):
-        """n_ticks of every sub-batch, one pve_step_many call each (on its own stream)."""
-        return [sub.step_many(n_ticks, actor=actor, source=source, trajectory=trajectory) for sub in self.subs]
+    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0):
+        """n_ticks of every sub-batch, one pve_step_many call each (on its own stream).  chunk > 0 splits every call into
+        launches of `chunk` ticks: a launch lasts as long as its slowest intersection, and the other sub-batches'
+        workgroups fill the slots its fast ones free, so short launches keep the chip full."""
+        return [sub.step_many(n_ticks, actor=actor, source=source, trajectory=trajectory, chunk=chunk) for sub in self.subs]
 
     def synchronize(self):
         for sub in self.subs:

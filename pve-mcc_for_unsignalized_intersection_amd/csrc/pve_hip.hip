@@ -111,18 +111,29 @@ __device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 // the next arrival times are prefetched under the tail of the current one.
 // WPE = waves per SIMD the register allocation is held to: 4 (<= 128 VGPR, no spills: 8 workgroups of 128 threads per CU,
 // i.e. 4096 intersections in exactly two rounds) or 5 (<= 96 VGPR, 10 per CU for stream-pipelined sub-batches).
-template <int CAP, int WPE>
+// PROF: the diagnostics build (pve_debug_phase_cycles) accumulates per-phase clock ticks over the ticks of the launch.
+template <int CAP, int WPE, bool PROF = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout(const Const c_arg, const Params P_arg,
                                                                                                const RolloutArgs R_arg)
 {
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     __shared__ Shared<CAP> sh;
-    const int t0_ = threadIdx.x;
-    const int env0_ = blockIdx.x;
+    int t0_ = threadIdx.x;
+    int env0_ = blockIdx.x;
+    KernargPtr kav_ = ka0_;
     Regs r;
     FinCarry fc;
     typedef Tick<CAP> T;
+    unsigned long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = PROF ? wall_clock64() : 0ull;
+#undef PVE_PHASE_MARK
+#define PVE_PHASE_MARK(idx)                                                              \
+    if (PROF) {                                                                          \
+        unsigned long long now_ = wall_clock64();                                        \
+        pc_[idx] += now_ - tprev_;                                                       \
+        tprev_ = now_;                                                                   \
+    }
     int pool_idx, n_ticks;
     {
         const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka0_;
@@ -136,51 +147,69 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         // The loop body is one tick of the single-tick kernel.  Without the two opaque copies below the compiler's
         // loop-invariant code motion hoists every kernel-argument load and every per-thread address out of the loop
         // (~150 scalar + ~140 vector registers live across the whole tick -> spills / 2 waves per SIMD).
-        KernargPtr ka = ka0_;
-        int t = t0_, env = env0_;
-        asm volatile("" : "+s"(ka), "+v"(t), "+s"(env));
+        // (the SAME variables are re-defined every iteration: a loop-carried value in one register, not an invariant plus a copy)
+        asm volatile("" : "+s"(kav_), "+v"(t0_), "+s"(env0_));
+        const KernargPtr ka = kav_;
+        const int t = t0_, env = env0_;
         const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka;
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka + OFF_P);
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka + OFF_R);
         lds_barrier();
+        PVE_PHASE_MARK(0)
         if (k > 0) T::ph_tick_init(c, t, sh, r);
         T::ph_step1(c, P, env, t, sh, r);
         lds_barrier();
+        PVE_PHASE_MARK(1)
         T::ph_step2(c, t, sh, r);
         T::ph_lists_a(c, t, sh);
         lds_barrier();
+        PVE_PHASE_MARK(2)
         T::ph_step3(c, t, sh, r);
         T::ph_step3_publish(t, sh, r);
         T::ph_lists_b(t, sh);
         lds_barrier();
+        PVE_PHASE_MARK(3)
         T::ph_build(c, t, sh, r);
         lds_barrier();
+        PVE_PHASE_MARK(4)
         T::ph_rank(t, sh);
         lds_barrier();
+        PVE_PHASE_MARK(5)
         T::ph_scan(c, t, sh, r);
+        PVE_PHASE_MARK(11)
         T::ph_reward(c, t, sh, r);
         lds_barrier();
+        PVE_PHASE_MARK(6)
         int nx = -1;
         if (k + 1 < n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
         T::ph_prefetch_action(P, R, env, t, nx, r);
         T::ph_effects(c, t, sh, r);
         lds_barrier();
+        PVE_PHASE_MARK(7)
         T::ph_prefetch_arrival(P, env, t, sh, r, NL);
         T::ph_lock(c, t, sh, r);
         lds_barrier();
         T::ph_lock2(t, sh, r);
         __syncthreads();                              // vmcnt(0): the previous tick's output stores precede this tick's
+        PVE_PHASE_MARK(8)
         T::ph_park_action(t, sh, r);
         const Outputs O = T::tick_outputs(P, R, k);
         T::template ph_final<true>(c, P, O, env, t, sh, r, fc);
+        PVE_PHASE_MARK(9)
         lds_barrier();                                // A: nobody reads the tick's work arrays any more
         T::ph_stage(c, t, sh, r, fc);
         lds_barrier();                                // B: the staging area is complete
         if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
+        PVE_PHASE_MARK(10)
     }
     {
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
         T::ph_flush(P, env0_, t0_, sh);
+        if (PROF && P.phase_cycles && (t0_ & 63) == 0) {
+            unsigned long long *row = P.phase_cycles + ((size_t)env0_ * (CAP / 64) + (t0_ >> 6)) * 16;
+#pragma unroll
+            for (int k = 0; k < 12; k++) row[k] += pc_[k];
+        }
     }
 }
 
@@ -290,9 +319,19 @@ struct Backend {
         if (e != hipSuccess || n <= 0) { err = "no HIP device visible (libpveenv.so needs an AMD GPU; there is no CPU fallback)"; return -1; }
         if (dev < 0 || dev >= n) { err = "device_id out of range"; return -1; }
         if (const char *g = getenv("PVE_ACTOR_GRID")) { int v = atoi(g); if (v > 0) actor_grid = v; }
-        e = hipSetDevice(dev);
-        if (e != hipSuccess) { err = hip_err("hipSetDevice", e); return -1; }
         return 0;
+    }
+    static int enter_device(int dev)
+    {
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        return prev;
+    }
+    static void leave_device(int prev)
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
     }
     static void *dmalloc(size_t n)
     {
@@ -339,7 +378,10 @@ struct Backend {
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
         static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
-        if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
+        if (P.phase_cycles) {
+            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
+            else hipLaunchKernelGGL((k_rollout<128, 4, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
+        } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
         else if (w5) hipLaunchKernelGGL((k_rollout<128, 5>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         else hipLaunchKernelGGL((k_rollout<128, 4>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         return check_launch(err);

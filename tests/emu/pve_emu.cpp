@@ -136,6 +136,8 @@ template <int CAP> static void emu_compact(const Params &P)
 
 struct Backend {
     static int set_device(int, std::string &) { return 0; }
+    static int enter_device(int) { return 0; }
+    static void leave_device(int) {}
     static void *dmalloc(size_t n) { return calloc(1, n); }
     static void dfree(void *p) { free(p); }
     static int d2h(void *dst, const void *src, size_t n, void *) { memcpy(dst, src, n); return 0; }

@@ -288,7 +288,7 @@ def test_gpu_full_size_oracle_spot_checks(cap, rate, many):
     """BASELINE configs 2 / 3 (and config 4's per-GPU shard) at FULL size, steady state: 4096 envs, 420 ticks (past the
     300-tick fill), 16 envs spread over the batch compared with their oracles every tick; overflow == 0."""
     m, peak = scenarios.check_full_size_vs_oracle(BACKEND, 4096, cap, rate, ticks=420, n_sample=16, many=many)
-    assert m["alive_steps"] / m["ticks"] > (60 if cap == 128 else 15)      # the batch really is at steady state
+    assert m["alive_steps"] / m["ticks"] > (50 if cap == 128 else 12)      # the batch really is at steady state
     assert peak <= cap
 
 

@@ -15,6 +15,9 @@ from pve_mcc_amd.arrivals import synthetic_arrivals  # noqa: E402
 
 PHASES = ("load", "step1", "step2+listsA", "step3+listsB", "build", "rank", "reward+xy", "effects", "lock",
           "final", "state", "walk(merge)")
+# k_rollout (--many): column 0 = barrier behind RELOAD (first tick: LOAD), 9 = FIN, 10 = barrier A + STAGE + barrier B + RELOAD
+PHASES_MANY = ("reload barrier", "init+step1", "step2+listsA", "step3+listsB", "build", "rank", "reward+xy", "effects",
+               "lock", "final", "stage+reload", "walk(merge)")
 
 
 def main():
@@ -24,9 +27,10 @@ def main():
     ap.add_argument("--ticks", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
+    ap.add_argument("--many", action="store_true", help="profile k_rollout (pve_step_many: all ticks in one launch)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    rate = 1100.0 if a.capacity == 128 else 500.0
+    rate = 1100.0 if a.capacity == 128 else 350.0
     arr = synthetic_arrivals(a.envs, rate=rate, horizon_s=(a.ticks + a.warmup) * 0.1 + 20)
     env = pve_mcc_amd.BatchedIntersections(a.envs, a.capacity, arr, device=dev,
                                            outputs=tuple(x for x in a.outputs.split(",") if x))
@@ -36,15 +40,20 @@ def main():
         env.step(pool[t % bench.N_POOL])
     buf = torch.zeros(a.envs * (a.capacity // 64), 16, dtype=torch.int64, device=dev)
     env.lib.pve_debug_phase_cycles(env._h, C.c_void_p(buf.data_ptr()))
-    for t in range(a.warmup, a.warmup + a.ticks):
-        env.step(pool[t % bench.N_POOL])
+    if a.many:
+        env.set_action_pool(pool)
+        env.step_many(a.ticks)
+    else:
+        for t in range(a.warmup, a.warmup + a.ticks):
+            env.step(pool[t % bench.N_POOL])
     torch.cuda.synchronize()
     env.lib.pve_debug_phase_cycles(env._h, None)
     cyc = buf.sum(0).cpu().numpy().astype(float)
     waves = a.envs * (a.capacity // 64) * a.ticks
     tot = cyc.sum()
     print("phase                cycles/wave   share")
-    for k, name in enumerate(PHASES):
+    names = PHASES_MANY if a.many else PHASES
+    for k, name in enumerate(names):
         if cyc[k] > 0:
             print("%-18s %12.0f  %6.1f%%" % (name, cyc[k] / waves, 100 * cyc[k] / tot))
     print("%-18s %12.0f  (wall_clock64 ticks, 100 MHz constant clock => x10 ns)" % ("total", tot / waves))
@@ -58,7 +67,7 @@ def main():
     slow = per_env >= np.percentile(per_env, 99)
     mid = (per_env >= np.percentile(per_env, 40)) & (per_env <= np.percentile(per_env, 60))
     print("phase means  (slowest 1%% | middle 20%%):")
-    for k, name in enumerate(PHASES):
+    for k, name in enumerate(names):
         if ph[:, k].sum() > 0:
             print("   %-16s %7.0f | %7.0f" % (name, ph[slow, k].mean(), ph[mid, k].mean()))
     print("corr(time, n_alive) = %.3f ; n_alive min/mean/max = %d / %.1f / %d" % (
