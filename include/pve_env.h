@@ -51,6 +51,9 @@ enum {
                                       (the type the actor consumes, model_agent_maddpg.py:15; SURVEY.md 8d "FP32 observation
                                       output": 268 instead of 380 algorithmic bytes per slot-step).  Fused ticks only:
                                       obs_pre / state_pre / pve_compact(obs) stay float64 and are refused with this flag. */
+#define PVE_CFG_GEO_SCAN     0x4   /* flags (diagnostics): the general-geometry kernel finds list members by scanning every controlled
+                                      vehicle (its fallback when an intersection's lists overflow the LDS entry pool) instead of reading
+                                      the per-route lists; results are identical (tested) */
 typedef struct pve_config {
     double deltaT;          /* 0.1 */
     double vm, vM;          /* 5, 13   (train(): vm = 6, main.py:230) */

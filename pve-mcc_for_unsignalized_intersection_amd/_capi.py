@@ -15,6 +15,7 @@ PVE_MAX_DIRS = 16
 DIR_NUM = {4: 12, 8: 16, 12: 12}     # virtual-lane lists per layout (ref :86, :132, :167)
 CFG_GENERAL_PATH = 0x1
 CFG_OBS_F32 = 0x2
+CFG_GEO_SCAN = 0x4
 PVE_OBS_WIDTH = 28
 PVE_NBR = 6
 PVE_N_METRICS = 12

@@ -56,6 +56,8 @@ class BatchedIntersections:
         self.n_envs, self.capacity = int(n_envs), int(capacity)
         if config.pop("general_path", False):
             config["flags"] = int(config.get("flags", 0)) | _capi.CFG_GENERAL_PATH
+        if config.pop("geo_scan", False):
+            config["flags"] = int(config.get("flags", 0)) | _capi.CFG_GEO_SCAN
         if obs_dtype not in (torch.float64, torch.float32):
             raise TypeError("obs_dtype must be torch.float64 or torch.float32")
         self.obs_dtype = obs_dtype

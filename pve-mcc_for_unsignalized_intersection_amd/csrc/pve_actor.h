@@ -3,12 +3,8 @@
 //
 //   x(28) -> LayerNorm -> Dense 28x64 -> LayerNorm -> ReLU -> Dense 64x64 -> LayerNorm -> ReLU -> Dense 64x1 -> 3*tanh
 //
-// float32 like the TF graph (placeholder dtype, :15).  One wave64 per intersection; lane r owns the
-// r-th controlled vehicle (ballot + popcount compaction, so no lane is wasted on empty / exit-leg slots).
-// The weights are wave-uniform: they are fetched with scalar loads and fed to v_fmac_f32 as the SGPR operand,
-// the activations of the previous layer are staged in LDS ([k][lane], conflict-free) so the k-loop stays rolled
-// and the 64 accumulators of a layer live in registers.  No MFMA: f32-input MFMA runs at the f32 vector rate on
-// gfx950, and M = controlled vehicles of one env (<= 64) is too ragged to tile across envs without a gather.
+// float32 like the TF graph (placeholder dtype, :15), on the matrix cores (k_actor_t below): this IS a dense
+// contraction (2 x 5 952 flop per controlled vehicle), unlike the tick.
 #pragma once
 #include "pve_types.h"
 
@@ -22,243 +18,217 @@ constexpr int AW_LN0_G = 0, AW_LN0_B = AW_LN0_G + ACT_IN, AW_W1 = AW_LN0_B + ACT
               AW_LN2_B = AW_LN2_G + ACT_H, AW_W3 = AW_LN2_B + ACT_H, AW_B3 = AW_W3 + ACT_H, AW_TOTAL = AW_B3 + 1;
 static_assert(AW_TOTAL == 6393, "actor weight count (SURVEY 8f-1)");
 
+// ------------------------------------------------------------------------------------------------------
+// Canonical float32 evaluation order of the network (plain code, host or device).  The matrix-core kernel below computes
+// exactly this: every dot product and every LayerNorm sum in this order, one rounding per fused multiply-add.  The CPU
+// test emulator calls it directly.  The order follows the data layout of v_mfma_f32_16x16x4_f32 in the transposed form
+// H^T = W^T X^T (hidden units x vehicles): lane group q = 0..3 of a wave holds the hidden units 16 m + 4 q + r
+// (m, r = 0..3) of its vehicle, and one instruction contracts the four values k(q), q = 0..3, in that order.
+inline float actor_ln_combine(const float p[4]) { return (p[0] + p[1]) + (p[2] + p[3]); }   // xor-16 then xor-32 exchange
+
+inline float actor_canonical(const float *W, const float *x)
+{
+    // LayerNorm over the 28 inputs: lane group q holds features 4 s + q
+    float p[4], a0[ACT_IN];
+    for (int q = 0; q < 4; q++) { p[q] = 0.f; for (int s = 0; s < ACT_IN / 4; s++) p[q] += x[4 * s + q]; }
+    float mean = actor_ln_combine(p) / (float)ACT_IN;
+    for (int q = 0; q < 4; q++) {
+        p[q] = 0.f;
+        for (int s = 0; s < ACT_IN / 4; s++) { const float d = x[4 * s + q] - mean; p[q] = fmaf(d, d, p[q]); }
+    }
+    float rstd = 1.0f / sqrtf(actor_ln_combine(p) / (float)ACT_IN + 1e-12f);
+    for (int k = 0; k < ACT_IN; k++) {
+        const float inv = rstd * W[AW_LN0_G + k];
+        a0[k] = fmaf(x[k], inv, W[AW_LN0_B + k] - mean * inv);
+    }
+    // dense 28 -> 64: k = 0 .. 27 in order (step s contracts k = 4 s + q, q = 0..3)
+    float h[ACT_H], g[ACT_H];
+    for (int u = 0; u < ACT_H; u++) {
+        float acc = W[AW_B1 + u];
+        for (int k = 0; k < ACT_IN; k++) acc = fmaf(W[AW_W1 + k * ACT_H + u], a0[k], acc);
+        h[u] = acc;
+    }
+    for (int layer = 1; layer <= 2; layer++) {
+        const int G = layer == 1 ? AW_LN1_G : AW_LN2_G, B = layer == 1 ? AW_LN1_B : AW_LN2_B;
+        float *src = layer == 1 ? h : g;
+        // LayerNorm + ReLU over the 64 hidden units: lane group q sums its units in (m, r) order
+        for (int q = 0; q < 4; q++) {
+            p[q] = 0.f;
+            for (int m = 0; m < 4; m++) for (int r = 0; r < 4; r++) p[q] += src[16 * m + 4 * q + r];
+        }
+        mean = actor_ln_combine(p) / (float)ACT_H;
+        for (int q = 0; q < 4; q++) {
+            p[q] = 0.f;
+            for (int m = 0; m < 4; m++) for (int r = 0; r < 4; r++) { const float d = src[16 * m + 4 * q + r] - mean; p[q] = fmaf(d, d, p[q]); }
+        }
+        rstd = 1.0f / sqrtf(actor_ln_combine(p) / (float)ACT_H + 1e-12f);
+        for (int u = 0; u < ACT_H; u++) {
+            const float inv = rstd * W[G + u];
+            src[u] = fmaxf(fmaf(src[u], inv, W[B + u] - mean * inv), 0.f);
+        }
+        if (layer == 1) {
+            // dense 64 -> 64: contraction order (m, r, q): k = 16 m + 4 q + r
+            for (int u = 0; u < ACT_H; u++) {
+                float acc = W[AW_B2 + u];
+                for (int m = 0; m < 4; m++) for (int r = 0; r < 4; r++) for (int q = 0; q < 4; q++) {
+                    const int k = 16 * m + 4 * q + r;
+                    acc = fmaf(W[AW_W2 + k * ACT_H + u], h[k], acc);
+                }
+                g[u] = acc;
+            }
+        }
+    }
+    // dense 64 -> 1: per lane group in (m, r) order, groups combined like the LayerNorm sums
+    for (int q = 0; q < 4; q++) {
+        p[q] = 0.f;
+        for (int m = 0; m < 4; m++) for (int r = 0; r < 4; r++) { const int k = 16 * m + 4 * q + r; p[q] = fmaf(g[k], W[AW_W3 + k], p[q]); }
+    }
+    return 3.0f * tanhf(actor_ln_combine(p) + W[AW_B3]);
+}
+
 #if defined(__HIPCC__)
 
-template <int N>
-__device__ __forceinline__ void layer_norm_relu(float (&h)[N], const float *gamma, const float *beta, bool relu)
-{   // tc.layers.layer_norm: biased variance over the last axis, eps = 1e-12; y = x*inv + (beta - mean*inv)
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < N; k++) s += h[k];
-    const float mean = s / (float)N;
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < N; k++) { const float d = h[k] - mean; v = fmaf(d, d, v); }
-    const float rstd = 1.0f / sqrtf(v / (float)N + 1e-12f);
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        const float inv = rstd * gamma[k];
-        float y = fmaf(h[k], inv, beta[k] - mean * inv);
-        h[k] = relu ? fmaxf(y, 0.f) : y;
-    }
-}
-
-// acc[0..63] += x_i * row_i[0..63] for NROWS staged inputs; the row is wave-uniform (scalar loads)
-#define PVE_ACTOR_DENSE(ACC, NROWS, WBASE, STAGE_ROW0)                                        \
-    for (int i = 0; i < (NROWS); i++) {                                                       \
-        const float xi = stage[(STAGE_ROW0) + i][lane];                                       \
-        const float *__restrict__ wr = W + (WBASE) + i * ACT_H;                               \
-        _Pragma("unroll") for (int j = 0; j < ACT_H; j++) ACC[j] = fmaf(xi, wr[j], ACC[j]);   \
-    }
-
-template <int CAP, typename OBS_T>
-__global__ __launch_bounds__(64) void k_actor(const float *__restrict__ W, const OBS_T *__restrict__ obs,
-                                              const int32_t *__restrict__ meta, double *__restrict__ actions,
-                                              int n_envs)
-{
-    __shared__ float stage[32][64];           // 32 activations of the previous layer at a time, [k][lane]
-    __shared__ unsigned char slot_of[CAP];
-    const int env = blockIdx.x, lane = threadIdx.x;
-    const size_t base = (size_t)env * CAP;
-    int nctl = 0;
-#pragma unroll
-    for (int sub = 0; sub < CAP / 64; sub++) {
-        const int s = sub * 64 + lane;
-        const int m = meta[base + s];
-        const bool c = (m & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
-        const unsigned long long b = __ballot(c);
-        const int rank = nctl + __builtin_popcountll(b & ((1ull << lane) - 1ull));
-        if (c) slot_of[rank] = (unsigned char)s;
-        else actions[base + s] = 0.0;                     // main.py:401: uncontrolled vehicles get 0
-        nctl += __builtin_popcountll(b);
-    }
-    __syncthreads();
-    for (int r0 = 0; r0 < nctl; r0 += 64) {
-        const bool active = r0 + lane < nctl;
-        const int slot = active ? slot_of[r0 + lane] : slot_of[r0];
-        // ---- input row (veh["state"][0], float64 in HBM -> float32 like the TF placeholder)
-        float x[ACT_IN];
-        {
-            const OBS_T *row = obs + (base + slot) * OBSW;
-#pragma unroll
-            for (int k = 0; k < ACT_IN; k++) x[k] = (float)row[k];
-        }
-        layer_norm_relu<ACT_IN>(x, W + AW_LN0_G, W + AW_LN0_B, false);
-#pragma unroll
-        for (int k = 0; k < ACT_IN; k++) stage[k][lane] = x[k];
-        // ---- dense 28 -> 64
-        float h[ACT_H];
-#pragma unroll
-        for (int j = 0; j < ACT_H; j++) h[j] = W[AW_B1 + j];
-        PVE_ACTOR_DENSE(h, ACT_IN, AW_W1, 0)
-        layer_norm_relu<ACT_H>(h, W + AW_LN1_G, W + AW_LN1_B, true);
-        // ---- dense 64 -> 64, the 64 inputs staged 32 at a time (the lane's LDS column is private: DS
-        //      operations of one wave execute in order, no barrier needed)
-        float g[ACT_H];
-#pragma unroll
-        for (int j = 0; j < ACT_H; j++) g[j] = W[AW_B2 + j];
-#pragma unroll
-        for (int k = 0; k < 32; k++) stage[k][lane] = h[k];
-        PVE_ACTOR_DENSE(g, 32, AW_W2, 0)
-#pragma unroll
-        for (int k = 0; k < 32; k++) stage[k][lane] = h[32 + k];
-        PVE_ACTOR_DENSE(g, 32, AW_W2 + 32 * ACT_H, 0)
-        layer_norm_relu<ACT_H>(g, W + AW_LN2_G, W + AW_LN2_B, true);
-        // ---- dense 64 -> 1, 3*tanh
-        float y = W[AW_B3];
-#pragma unroll
-        for (int j = 0; j < ACT_H; j++) y = fmaf(g[j], W[AW_W3 + j], y);
-        const float a = 3.0f * tanhf(y);
-        if (active) actions[base + slot] = (double)a;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------
-// k_actor_mfma: the same network on the matrix cores.  v_mfma_f32_32x32x2_f32 is an exact float32 FMA chain
-// (k-ordered, one rounding per product: bitwise the order of the VALU kernel above), at the f32 vector rate,
-// but it takes its operands per lane: A[i = lane & 31][k = lane >> 5] and B[k = lane >> 5][j = lane & 31].
-// That removes every wave-uniform operand: the 28x64 + 64x64 weights live in 92 VGPRs per lane for the whole
-// kernel (loaded once, coalesced), activations are exchanged between the C layout (column per lane) and the A
-// layout (row per lane) through a padded 64x65 LDS tile, and the LayerNorm statistics of a vehicle are a sum
-// over the 14 / 32 features its two lanes (lane, lane ^ 32) hold plus one cross-lane exchange.
-// One wave64 per intersection; 64 controlled vehicles (2 row tiles of 32) per pass; 184 MFMAs per pass.
-typedef float pve_v16f __attribute__((ext_vector_type(16)));
+// k_actor_t: the network on the matrix cores in the TRANSPOSED form H^T = W^T X^T.  v_mfma_f32_16x16x4_f32 is an exact
+// float32 FMA chain at the f32 vector rate; operands are per lane:
+//   A[i = lane & 15][k = lane >> 4]  = W[k][16 m' + i]            (a weight, straight from L1 / L2: 64-B segments)
+//   B[k = lane >> 4][j = lane & 15]  = activation k of vehicle j   (already in this lane's registers, see below)
+//   D[i = 4 (lane >> 4) + r][j]      -> lane (j, q = lane >> 4) holds hidden units 16 m' + 4 q + r of vehicle j.
+// The output layout of one layer IS the B-operand layout of the next (the contraction index is merely enumerated in the
+// order (m, r, q)), so activations never move: no LDS tile, no transposes, no weights parked in registers.  LayerNorm =
+// 16 in-lane values + two cross-lane exchanges (lanes j, j + 16, j + 32, j + 48 hold one vehicle).  16 controlled
+// vehicles per wave and pass (ballot compaction), 28 + 64 MFMAs per pass.
+typedef float pve_v4f __attribute__((ext_vector_type(4)));
 
-template <int CAP, typename OBS_T>
-__global__ __launch_bounds__(64) void k_actor_mfma(const float *__restrict__ W, const OBS_T *__restrict__ obs,
-                                                   const int32_t *__restrict__ meta, double *__restrict__ actions,
-                                                   int n_envs)
+__device__ __forceinline__ float actor_xsum(float s)
 {
-    __shared__ float Hs[32][65];               // activations of 32 vehicles x 64 features (+1 pad: conflict-free)
-    __shared__ float lnp[2 * ACT_IN + 4 * ACT_H + ACT_H];   // g0,b0 | g1,b1 | g2,b2 | w3
-    __shared__ unsigned char slot_of[CAP];
-    const int lane = threadIdx.x, lo = lane & 31, hi = lane >> 5;
-    for (int k = lane; k < 2 * ACT_IN; k += 64) lnp[k] = W[AW_LN0_G + k];
-    for (int k = lane; k < 2 * ACT_H; k += 64) {
-        lnp[2 * ACT_IN + k] = W[AW_LN1_G + k];
-        lnp[2 * ACT_IN + 2 * ACT_H + k] = W[AW_LN2_G + k];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    return s;
+}
+
+// LayerNorm + ReLU over the 64 hidden units of a vehicle: 16 of them in this lane (units 16 m + 4 q + r), the rest in the
+// lanes 16 / 32 / 48 further on
+__device__ __forceinline__ void actor_ln_relu16(pve_v4f (&v)[4], const float *__restrict__ gamma, const float *__restrict__ beta, int q)
+{
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) sum += v[m][r];
+    const float mean = actor_xsum(sum) / (float)ACT_H;
+    float var = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float d = v[m][r] - mean; var = fmaf(d, d, var); }
+    const float rstd = 1.0f / sqrtf(actor_xsum(var) / (float)ACT_H + 1e-12f);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const pve_v4f ga = *(const pve_v4f *)(gamma + 16 * m + 4 * q), be = *(const pve_v4f *)(beta + 16 * m + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float inv = rstd * ga[r];
+            v[m][r] = fmaxf(fmaf(v[m][r], inv, be[r] - mean * inv), 0.f);
+        }
     }
-    lnp[2 * ACT_IN + 4 * ACT_H + lane] = W[AW_W3 + lane];
-    // weight fragments, loaded once per (persistent) wave: B[k = 2s + hi][j = 32nt + lo]
-    float B1[ACT_IN / 2][2], B2[ACT_H / 2][2], b1c[2], b2c[2];
-#pragma unroll
-    for (int s = 0; s < ACT_IN / 2; s++)
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) B1[s][nt] = W[AW_W1 + (2 * s + hi) * ACT_H + 32 * nt + lo];
-#pragma unroll
-    for (int s = 0; s < ACT_H / 2; s++)
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) B2[s][nt] = W[AW_W2 + (2 * s + hi) * ACT_H + 32 * nt + lo];
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++) { b1c[nt] = W[AW_B1 + 32 * nt + lo]; b2c[nt] = W[AW_B2 + 32 * nt + lo]; }
-    const float b3 = W[AW_B3];
-    const float *g0 = lnp, *be0 = lnp + ACT_IN, *g1 = lnp + 2 * ACT_IN, *be1 = g1 + ACT_H, *g2 = be1 + ACT_H,
-                *be2 = g2 + ACT_H, *w3 = be2 + ACT_H;
-    __syncthreads();
+}
+
+// Workgroup = 4 waves sharing ONE copy of the two dense kernels in LDS (rows padded to 68 floats: the four lane groups of
+// an A-operand read hit disjoint banks); persistent workgroups loop over the intersections, wave w takes the 16-vehicle
+// tiles w, w + 4, ... of the current one (<= 64 controlled vehicles: one tile per wave, all four SIMDs of the CU busy).
+constexpr int ACT_WPAD = 68;
+template <int CAP, typename OBS_T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_t(const float *__restrict__ W, const OBS_T *__restrict__ obs,
+                                                 const int32_t *__restrict__ meta, double *__restrict__ actions,
+                                                 int n_envs)
+{
+    __shared__ float Ws1[ACT_IN][ACT_WPAD], Ws2[ACT_H][ACT_WPAD];
+    __shared__ unsigned char slot_of[CAP];
+    __shared__ int nctl_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jl = lane & 15, q = lane >> 4;
+    for (int i = tid; i < ACT_IN * ACT_H; i += 256) Ws1[i >> 6][i & 63] = W[AW_W1 + i];
+    for (int i = tid; i < ACT_H * ACT_H; i += 256) Ws2[i >> 6][i & 63] = W[AW_W2 + i];
     for (int env = blockIdx.x; env < n_envs; env += gridDim.x) {
         const size_t base = (size_t)env * CAP;
-        // controlled-vehicle compaction
-        int nctl = 0;
+        __syncthreads();                                      // weights staged / slot_of of the previous intersection consumed
+        // controlled-vehicle compaction (first CAP / 64 waves)
+        if (wave == 0) {
+            int nctl = 0;
 #pragma unroll
-        for (int sub = 0; sub < CAP / 64; sub++) {
-            const int s = sub * 64 + lane;
-            const int m = meta[base + s];
-            const bool c = (m & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
-            const unsigned long long b = __ballot(c);
-            const int rank = nctl + __builtin_popcountll(b & ((1ull << lane) - 1ull));
-            if (c) slot_of[rank] = (unsigned char)s;
-            else actions[base + s] = 0.0;                 // main.py:401: uncontrolled vehicles get 0
-            nctl += __builtin_popcountll(b);
+            for (int sub = 0; sub < CAP / 64; sub++) {
+                const int s = sub * 64 + lane;
+                const int m = meta[base + s];
+                const bool c = (m & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
+                const unsigned long long b = __ballot(c);
+                const int rank = nctl + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+                if (c) slot_of[rank] = (unsigned char)s;
+                else actions[base + s] = 0.0;                 // main.py:401: uncontrolled vehicles get 0
+                nctl += __builtin_popcountll(b);
+            }
+            if (lane == 0) nctl_s = nctl;
         }
         __syncthreads();
-        for (int v0 = 0; v0 < nctl; v0 += 32) {           // one row tile = 32 vehicles per pass
-            const int v = v0 + lo;
+        const int nctl = nctl_s;
+        for (int v0 = 16 * wave; v0 < nctl; v0 += 64) {       // 16 vehicles per pass and wave
+            // the A operands are read from LDS right before the MFMA that consumes them; an offset the compiler cannot
+            // see through keeps it from hoisting all 92 reads out of the loops into 250 registers (1 wave per SIMD)
+            int wo = 0;
+            asm volatile("" : "+v"(wo));
+            const int v = v0 + jl;
             const bool valid = v < nctl;
             const int slot = slot_of[valid ? v : v0];
-            pve_v16f acc[2];
-            // ---- layer 1: LayerNorm(28) -> dense 28x64.  Lane holds features k = 2s + hi of vehicle v0 + lo.
+            // ---- inputs: lane (j, q) takes features 4 s + q of vehicle j; LayerNorm over the 28
+            float x[ACT_IN / 4];
             {
                 const OBS_T *row = obs + (base + slot) * OBSW;
-                float x[ACT_IN / 2], sum = 0.f;
+                float sum = 0.f;
 #pragma unroll
-                for (int s = 0; s < ACT_IN / 2; s++) { x[s] = (float)row[2 * s + hi]; sum += x[s]; }
-                const float mean = (sum + __shfl_xor(sum, 32)) / (float)ACT_IN;
+                for (int s = 0; s < ACT_IN / 4; s++) { x[s] = (float)row[4 * s + q]; sum += x[s]; }
+                const float mean = actor_xsum(sum) / (float)ACT_IN;
                 float var = 0.f;
 #pragma unroll
-                for (int s = 0; s < ACT_IN / 2; s++) { const float d = x[s] - mean; var = fmaf(d, d, var); }
-                const float rstd = 1.0f / sqrtf((var + __shfl_xor(var, 32)) / (float)ACT_IN + 1e-12f);
+                for (int s = 0; s < ACT_IN / 4; s++) { const float d = x[s] - mean; var = fmaf(d, d, var); }
+                const float rstd = 1.0f / sqrtf(actor_xsum(var) / (float)ACT_IN + 1e-12f);
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-                    for (int q = 0; q < 16; q++) acc[nt][q] = b1c[nt];
-#pragma unroll
-                for (int s = 0; s < ACT_IN / 2; s++) {
-                    const float inv = rstd * g0[2 * s + hi];
-                    const float a = fmaf(x[s], inv, be0[2 * s + hi] - mean * inv);
-#pragma unroll
-                    for (int nt = 0; nt < 2; nt++)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B1[s][nt], acc[nt], 0, 0, 0);
+                for (int s = 0; s < ACT_IN / 4; s++) {
+                    const float inv = rstd * W[AW_LN0_G + 4 * s + q];
+                    x[s] = fmaf(x[s], inv, W[AW_LN0_B + 4 * s + q] - mean * inv);
                 }
             }
-            // ---- C layout -> LDS [vehicle][feature]: lane holds column 32nt + lo, rows (q&3) + 8(q>>2) + 4hi
+            // ---- dense 28 -> 64 (+ bias): 7 steps x 4 unit tiles
+            pve_v4f h[4];
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++)
+            for (int m = 0; m < 4; m++) h[m] = *(const pve_v4f *)(W + AW_B1 + 16 * m + 4 * q);
 #pragma unroll
-                for (int q = 0; q < 16; q++) Hs[(q & 3) + 8 * (q >> 2) + 4 * hi][32 * nt + lo] = acc[nt][q];
-            __syncthreads();
-            // ---- layer 2: LayerNorm_1 -> ReLU -> dense 64x64
-            {
-                float raw[ACT_H / 2], sum = 0.f;
+            for (int s = 0; s < ACT_IN / 4; s++)
 #pragma unroll
-                for (int s = 0; s < ACT_H / 2; s++) { raw[s] = Hs[lo][2 * s + hi]; sum += raw[s]; }
-                const float mean = (sum + __shfl_xor(sum, 32)) / (float)ACT_H;
-                float var = 0.f;
+                for (int m = 0; m < 4; m++)
+                    h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws1[4 * s + q][16 * m + jl + wo], x[s], h[m], 0, 0, 0);
+            // ---- LayerNorm_1 + ReLU, dense 64 -> 64, LayerNorm_2 + ReLU
+            actor_ln_relu16(h, W + AW_LN1_G, W + AW_LN1_B, q);
+            pve_v4f g[4];
 #pragma unroll
-                for (int s = 0; s < ACT_H / 2; s++) { const float d = raw[s] - mean; var = fmaf(d, d, var); }
-                const float rstd = 1.0f / sqrtf((var + __shfl_xor(var, 32)) / (float)ACT_H + 1e-12f);
+            for (int m2 = 0; m2 < 4; m2++) g[m2] = *(const pve_v4f *)(W + AW_B2 + 16 * m2 + 4 * q);
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++)
+            for (int m = 0; m < 4; m++)                       // step (m, r) contracts k = 16 m + 4 q + r
 #pragma unroll
-                    for (int q = 0; q < 16; q++) acc[nt][q] = b2c[nt];
+                for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int s = 0; s < ACT_H / 2; s++) {
-                    const float inv = rstd * g1[2 * s + hi];
-                    const float a = fmaxf(fmaf(raw[s], inv, be1[2 * s + hi] - mean * inv), 0.f);
+                    for (int m2 = 0; m2 < 4; m2++)
+                        g[m2] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws2[16 * m + 4 * q + r][16 * m2 + jl + wo], h[m][r], g[m2], 0, 0, 0);
+            actor_ln_relu16(g, W + AW_LN2_G, W + AW_LN2_B, q);
+            // ---- dense 64 -> 1, 3 tanh
+            float part = 0.f;
 #pragma unroll
-                    for (int nt = 0; nt < 2; nt++)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B2[s][nt], acc[nt], 0, 0, 0);
-                }
+            for (int m = 0; m < 4; m++) {
+                const pve_v4f w3 = *(const pve_v4f *)(W + AW_W3 + 16 * m + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; r++) part = fmaf(g[m][r], w3[r], part);
             }
-            __syncthreads();
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-                for (int q = 0; q < 16; q++) Hs[(q & 3) + 8 * (q >> 2) + 4 * hi][32 * nt + lo] = acc[nt][q];
-            __syncthreads();
-            // ---- layer 3: LayerNorm_2 -> ReLU -> dense 64x1 -> 3*tanh
-            {
-                float raw[ACT_H / 2], sum = 0.f;
-#pragma unroll
-                for (int s = 0; s < ACT_H / 2; s++) { raw[s] = Hs[lo][2 * s + hi]; sum += raw[s]; }
-                const float mean = (sum + __shfl_xor(sum, 32)) / (float)ACT_H;
-                float var = 0.f;
-#pragma unroll
-                for (int s = 0; s < ACT_H / 2; s++) { const float d = raw[s] - mean; var = fmaf(d, d, var); }
-                const float rstd = 1.0f / sqrtf((var + __shfl_xor(var, 32)) / (float)ACT_H + 1e-12f);
-                float part = 0.f;
-#pragma unroll
-                for (int s = 0; s < ACT_H / 2; s++) {
-                    const float inv = rstd * g2[2 * s + hi];
-                    const float y = fmaxf(fmaf(raw[s], inv, be2[2 * s + hi] - mean * inv), 0.f);
-                    part = fmaf(y, w3[2 * s + hi], part);
-                }
-                const float y = part + __shfl_xor(part, 32) + b3;
-                const float a = 3.0f * tanhf(y);
-                if (hi == 0 && valid) actions[base + slot] = (double)a;
-            }
-            __syncthreads();                    // Hs is rewritten by the next pass
+            const float a = 3.0f * tanhf(actor_xsum(part) + W[AW_B3]);
+            if (q == 0 && valid) actions[base + slot] = (double)a;
         }
-        __syncthreads();                        // slot_of is rewritten for the next environment
     }
 }
 

@@ -236,7 +236,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     __syncthreads();
     B::ph_step3(g.base, t, sh, r);
     B::ph_step3_publish(t, sh, r);
-    T::ph_order2(t, sh);
+    T::ph_order2(t, sh, P.geo_scan != 0);
+    __syncthreads();
+    T::ph_fill(g, t, sh, r);
     __syncthreads();
     T::ph_scan(g, t, sh, r);
     T::ph_reward(g, t, sh, r);
@@ -309,8 +311,6 @@ static std::string hip_err(const char *what, hipError_t e)
     return std::string(what) + ": " + hipGetErrorString(e);
 }
 
-static int actor_grid = 2048;   // PVE_ACTOR_GRID env var (tuning knob): persistent workgroups of k_actor_mfma
-
 struct Backend {
     static int set_device(int dev, std::string &err)
     {
@@ -318,7 +318,6 @@ struct Backend {
         hipError_t e = hipGetDeviceCount(&n);
         if (e != hipSuccess || n <= 0) { err = "no HIP device visible (libpveenv.so needs an AMD GPU; there is no CPU fallback)"; return -1; }
         if (dev < 0 || dev >= n) { err = "device_id out of range"; return -1; }
-        if (const char *g = getenv("PVE_ACTOR_GRID")) { int v = atoi(g); if (v > 0) actor_grid = v; }
         return 0;
     }
     static int enter_device(int dev)
@@ -412,16 +411,11 @@ struct Backend {
     static void launch_actor_t(const float *W, const OBS_T *obs, const int32_t *meta, double *actions, int n_envs, int cap,
                                hipStream_t s)
     {
-        static const bool valu = getenv("PVE_ACTOR_VALU") != nullptr;    // A/B knob: the scalar-broadcast VALU kernel
-        if (valu) {
-            if (cap == 64) hipLaunchKernelGGL((k_actor<64, OBS_T>), dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
-            else hipLaunchKernelGGL((k_actor<128, OBS_T>), dim3(n_envs), dim3(64), 0, s, W, obs, meta, actions, n_envs);
-        } else {
-            // persistent waves (the 92 weight VGPRs are loaded once per wave): 256 CUs x 8 waves
-            const int grid = n_envs < actor_grid ? n_envs : actor_grid;
-            if (cap == 64) hipLaunchKernelGGL((k_actor_mfma<64, OBS_T>), dim3(grid), dim3(64), 0, s, W, obs, meta, actions, n_envs);
-            else hipLaunchKernelGGL((k_actor_mfma<128, OBS_T>), dim3(grid), dim3(64), 0, s, W, obs, meta, actions, n_envs);
-        }
+        // persistent workgroups (the 23 KB of dense kernels are staged in LDS once per workgroup): 4 per CU
+        static const int wgs = getenv("PVE_ACTOR_GRID") ? atoi(getenv("PVE_ACTOR_GRID")) : 1024;
+        const int grid = n_envs < wgs ? n_envs : wgs;
+        if (cap == 64) hipLaunchKernelGGL((k_actor_t<64, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
+        else hipLaunchKernelGGL((k_actor_t<128, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
     }
     static int launch_actor(const float *W, const void *obs, int obs_f32, const int32_t *meta, double *actions, int n_envs,
                             int cap, void *stream, std::string &err)

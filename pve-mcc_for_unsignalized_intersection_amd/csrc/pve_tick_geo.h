@@ -30,7 +30,17 @@ template <int CAP> struct SharedGeo {
     double p1[CAP], v1[CAP];
     double virdis[CAP];
     double red_reward[NW], red_jerk[NW];
-    double u_vd[CAP];                // dead-lock scratch: records by rank (ph_lock2)
+    // Virtual-lane lists (ref :240-270), unsorted: list d (one per route) = [lbase[d], lbase[d] + fill[d]) of the entry
+    // pool; an entry = (build-time virtual distance, slot).  Every controlled vehicle files itself into the lists it is a
+    // member of (FILL), every ego then reads only its own list (SCAN) instead of testing membership of every controlled
+    // vehicle of the intersection.  Segment sizes are upper bounds from the per-route counts (rc); if they do not fit
+    // the pool (pool_ok = 0, dense 8-lane traffic) SCAN falls back to the membership scan, with identical results.
+    static constexpr int PE = 4 * CAP;
+    double u_vd[PE];                 // entry pool; LOCK2 re-uses [0, CAP) as the dead-lock scratch (records by rank)
+    uint8_t u_slot[PE];
+    int rc[ND], fill[ND], pool_ok;   // controlled vehicles per route, entries filed per list
+    int16_t lbase[ND + 1];
+    uint16_t lroutes[ND];            // bit d: route r can be a member of list d (transpose of mroutes)
     double vdt[4][MAXK][4];          // get_virtual_distance table (GeoConst::vd)
     double inbox[4];
     int cnt[CAP];
@@ -114,6 +124,17 @@ template <int CAP> struct TickGeo {
             for (int q = 0; q < 3; q++) if (g.direction[li][q] >= 0) mr |= 1u << g.direction[li][q];
             for (int q = 0; q < MAXK; q++) if (g.l2l[t][q] >= 0) mr |= 1u << g.l2l[t][q];
             sh.mroutes[t] = (uint16_t)mr;
+            // transpose: the lists route t can be filed into
+            unsigned lr = 0;
+            for (int d = 0; d < g.dir_num; d++) {
+                bool in = false;
+                const int ld = g.dir_lane[d];
+                for (int q = 0; q < 3; q++) in = in || (g.direction[ld][q] == t);
+                for (int q = 0; q < MAXK; q++) in = in || (g.l2l[d][q] == t);
+                if (in) lr |= 1u << d;
+            }
+            sh.lroutes[t] = (uint16_t)lr;
+            sh.rc[t] = 0; sh.fill[t] = 0;
         }
     }
 
@@ -137,6 +158,7 @@ template <int CAP> struct TickGeo {
     static PVE_HD void ph_order(int t, Sh &sh, Regs &r)
     {
         r.ord = t;
+        if (r.alive && r.ctl) lds_add(&sh.rc[r.route], 1);
         if (r.alive) {
             const int ls = sh.hd.lane_start[r.lane], le = sh.hd.lane_start[r.lane + 1];
             int o = ls;
@@ -149,10 +171,39 @@ template <int CAP> struct TickGeo {
             sh.slot_at[o] = (int16_t)t;
         }
     }
-    static PVE_HD void ph_order2(int t, Sh &sh)
+    static PVE_HD void ph_order2(int t, Sh &sh, bool force_scan)
     {
         const int N = sh.hd.n_alive;
         vote<NW>(sh.m_ctl_ord, t, t < N && mask_test(sh.m_ctl, sh.slot_at[t < N ? t : 0]));
+        // list d can hold at most the controlled vehicles of the routes in mroutes[d]: segment offsets by a wave scan
+        int cap = 0;
+        if (t < ND) {
+            const unsigned mr = sh.mroutes[t];
+#pragma unroll
+            for (int rt = 0; rt < ND; rt++) cap += ((mr >> rt) & 1u) ? sh.rc[rt] : 0;
+        }
+#if PVE_DEVICE_CODE
+        const int incl = wave_incl_scan(t, cap, nullptr);            // lists 0 .. 15 live in the first 16 lanes of wave 0
+#else
+        const int incl = wave_incl_scan(t, cap, &sh.emu_scan);
+#endif
+        if (t < ND) {
+            sh.lbase[t + 1] = (int16_t)(incl > 32767 ? 32767 : incl);
+            if (t == 0) sh.lbase[0] = 0;
+            if (t == ND - 1) sh.pool_ok = (!force_scan && incl <= Sh::PE) ? 1 : 0;
+        }
+    }
+    // FILL: every controlled vehicle files (virtual distance at list build, slot) into each list it is a member of
+    static PVE_HD void ph_fill(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
+    {
+        if (!sh.pool_ok || !(r.alive && r.ctl)) return;
+        for (unsigned ls = sh.lroutes[r.route]; ls; ls &= ls - 1) {
+            const int d = __builtin_ctz(ls);
+            double vo;
+            if (!member(g, sh, d, g.dir_lane[d], g.dir_index[d], t, vo)) continue;
+            const int e = sh.lbase[d] + lds_claim(&sh.fill[d], 1);
+            sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)t;
+        }
     }
 
     // ============================================================== membership of vehicle x in the list of route d
@@ -208,16 +259,25 @@ template <int CAP> struct TickGeo {
         for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
         // (a) one thread per list d: head of list d, persisted for next tick's step (ref :1517); lists are rebuilt only
         //     when their physical lane holds a vehicle (ref :234), otherwise the old head stays (stale by design)
+        const bool lists = sh.pool_ok != 0;
         if (t >= CAP - ND && t - (CAP - ND) < g.dir_num) {     // the last 16 threads: the (mostly empty) tail of the last wave
             const int d = t - (CAP - ND), li = g.dir_lane[d], m = g.dir_index[d];
             if (sh.hd.lane_start[li + 1] > sh.hd.lane_start[li]) {
                 double best = INFINITY; int bs = -1;
-                for (int w = 0; w < NW; w++)
-                    for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
-                        const int x = w * 64 + __builtin_ctzll(bits);
-                        double vo;
-                        if (member(g, sh, d, li, m, x, vo) && vo < best) { best = vo; bs = x; }   // ties: lower slot stays
+                if (lists) {
+                    const int e1 = sh.lbase[d] + sh.fill[d];
+                    for (int e = sh.lbase[d]; e < e1; e++) {
+                        const double vo = sh.u_vd[e]; const int x = sh.u_slot[e];
+                        if (vo < best || (vo == best && x < bs)) { best = vo; bs = x; }           // ties: lower slot
                     }
+                } else {
+                    for (int w = 0; w < NW; w++)
+                        for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
+                            const int x = w * 64 + __builtin_ctzll(bits);
+                            double vo;
+                            if (member(g, sh, d, li, m, x, vo) && vo < best) { best = vo; bs = x; }   // ties: lower slot stays
+                        }
+                }
                 if (bs >= 0) {
                     lds_or(&sh.hd.head_valid, 1 << d);
                     const int hl = sh.lane_of[bs];
@@ -229,7 +289,7 @@ template <int CAP> struct TickGeo {
             }
         }
         if (!(r.alive && r.ctl)) return;
-        // (b) every controlled vehicle scans the members of its route's list
+        // (b) every controlled vehicle goes through the members of its route's list
         const int d = r.route, li = r.lane, m = r.intent;
         const double me = r.p;                                   // own entry: vd = p, never adjusted
         const bool fix = (g.lane_num == 4) && (d % 3 == 0);      // ref :1301
@@ -239,47 +299,59 @@ template <int CAP> struct TickGeo {
         double bvo = -INFINITY, bvc = 0; int bslot = -1;
         // the 6 nearest so far, sorted by |vd - vd_self|: only (distance, slot) travel through the insertion chain;
         // the build-time / current distances of the 6 winners are re-derived at the end, and the rare exact
-        // distance ties (which the reference's stable sort breaks by list position) take the full-key path
+        // distance ties (which the reference's stable sort breaks by list position) take the full-key path.
+        // Every comparison carries its tie-break explicitly, so the order in which the members arrive does not matter.
         double kd[NNB]; int ks[NNB];
 #pragma unroll
         for (int k = 0; k < NNB; k++) { kd[k] = INFINITY; ks[k] = -1; }
-        for (int w = 0; w < NW; w++)
-            for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
-                const int x = w * 64 + __builtin_ctzll(bits);
-                double vo;
-                if (x == t || !((mroutes >> sh.route_of[x]) & 1u) || !member(g, sh, d, li, m, x, vo)) continue;
-                const double vc = (fix && sh.route_of[x] == opp) ? adjusted(g, sh, m, ls, le, t, vo) : vo;
-                // predecessor in list order = stable sort by the build-time distance (ref :271, :1353)
-                const bool before = vo < me || (vo == me && x < t);
-                if (before && (vo > bvo || (vo == bvo && x > bslot))) { bvo = vo; bslot = x; bvc = vc; }
-                // 6 nearest: stable sort of the list by |vd - vd_self| on the current values (ref :1383-1397)
-                double cd = fabs(vc - me); int cs = x;
-                bool tie = false;
+        auto consider = [&](int x, double vo) {
+            const double vc = (fix && sh.route_of[x] == opp) ? adjusted(g, sh, m, ls, le, t, vo) : vo;
+            // predecessor in list order = stable sort by the build-time distance (ref :271, :1353)
+            const bool before = vo < me || (vo == me && x < t);
+            if (before && (vo > bvo || (vo == bvo && x > bslot))) { bvo = vo; bslot = x; bvc = vc; }
+            // 6 nearest: stable sort of the list by |vd - vd_self| on the current values (ref :1383-1397)
+            double cd = fabs(vc - me); int cs = x;
+            bool tie = false;
 #pragma unroll
-                for (int k = 0; k < NNB; k++) tie = tie || (cd == kd[k]);
-                if (!tie) {
-                    bool ins = false;                             // once placed, the tail shifts down by one
+            for (int k = 0; k < NNB; k++) tie = tie || (cd == kd[k]);
+            if (!tie) {
+                bool ins = false;                             // once placed, the tail shifts down by one
 #pragma unroll
-                    for (int k = 0; k < NNB; k++) {
-                        const bool sw = ins || cd < kd[k];
-                        ins = sw;
-                        const double td = sw ? kd[k] : cd; const int ts = sw ? ks[k] : cs;
-                        kd[k] = sw ? cd : kd[k]; ks[k] = sw ? cs : ks[k];
-                        cd = td; cs = ts;
-                    }
-                } else {
-                    double co = vo;
+                for (int k = 0; k < NNB; k++) {
+                    const bool sw = ins || cd < kd[k];
+                    ins = sw;
+                    const double td = sw ? kd[k] : cd; const int ts = sw ? ks[k] : cs;
+                    kd[k] = sw ? cd : kd[k]; ks[k] = sw ? cs : ks[k];
+                    cd = td; cs = ts;
+                }
+            } else {
+                double co = vo;
 #pragma unroll
-                    for (int k = 0; k < NNB; k++) {
-                        double eo = INFINITY;                     // build-time distance of the entry (list position)
-                        if (ks[k] >= 0) member(g, sh, d, li, m, ks[k], eo);
-                        const bool sw = key_less(cd, co, cs, kd[k], eo, ks[k] < 0 ? 0x7fffffff : ks[k]);
-                        const double td = sw ? kd[k] : cd, to = sw ? eo : co; const int ts = sw ? ks[k] : cs;
-                        kd[k] = sw ? cd : kd[k]; ks[k] = sw ? cs : ks[k];
-                        cd = td; co = to; cs = ts;
-                    }
+                for (int k = 0; k < NNB; k++) {
+                    double eo = INFINITY;                     // build-time distance of the entry (list position)
+                    if (ks[k] >= 0) member(g, sh, d, li, m, ks[k], eo);
+                    const bool sw = key_less(cd, co, cs, kd[k], eo, ks[k] < 0 ? 0x7fffffff : ks[k]);
+                    const double td = sw ? kd[k] : cd, to = sw ? eo : co; const int ts = sw ? ks[k] : cs;
+                    kd[k] = sw ? cd : kd[k]; ks[k] = sw ? cs : ks[k];
+                    cd = td; co = to; cs = ts;
                 }
             }
+        };
+        if (lists) {
+            const int e1 = sh.lbase[d] + sh.fill[d];
+            for (int e = sh.lbase[d]; e < e1; e++) {
+                const int x = sh.u_slot[e];
+                if (x != t) consider(x, sh.u_vd[e]);
+            }
+        } else {
+            for (int w = 0; w < NW; w++)
+                for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
+                    const int x = w * 64 + __builtin_ctzll(bits);
+                    double vo;
+                    if (x == t || !((mroutes >> sh.route_of[x]) & 1u) || !member(g, sh, d, li, m, x, vo)) continue;
+                    consider(x, vo);
+                }
+        }
 #pragma unroll
         for (int k = 0; k < NNB; k++) {
             double vo = 0;

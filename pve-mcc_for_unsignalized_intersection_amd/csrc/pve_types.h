@@ -109,6 +109,7 @@ struct Params {
     int32_t mode;
     int32_t mask_uncontrolled;   // 1: actions of uncontrolled slots are forced to 0 (main.py:401)
     int32_t obs_f32;             // PVE_CFG_OBS_F32: out.obs_post holds float32 rows (the type the actor consumes)
+    int32_t geo_scan;            // PVE_CFG_GEO_SCAN: general-geometry kernel uses the membership scan even when the lists fit
     const int32_t *choice;       // 8-lane: the randint(0,1) draws of ref :390, [rows][lane_num] per env, or null (all 0)
     long long choice_env_stride; // int32 elements between envs (0 = shared)
     unsigned long long *phase_cycles;   // diagnostics: 16 counters of wave-cycles per phase, or null

@@ -107,7 +107,9 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_order(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_step3(g.base, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_step3_publish(t, sh, regs[t]);
-        for (int t = 0; t < CAP; t++) T::ph_order2(t, sh);
+        sh.emu_scan = 0;
+        for (int t = 0; t < CAP; t++) T::ph_order2(t, sh, P.geo_scan != 0);
+        for (int t = 0; t < CAP; t++) T::ph_fill(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_scan(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_reward(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_effects(g, t, sh, regs[t]);
@@ -176,21 +178,7 @@ struct Backend {
         }
         return 0;
     }
-    // plain float32 loop with the same layer order / epsilon as csrc/pve_actor.h (host-logic tests only)
-    static void ln(float *h, int n, const float *g, const float *b, bool relu)
-    {
-        float s = 0.f;
-        for (int k = 0; k < n; k++) s += h[k];
-        const float mean = s / (float)n;
-        float v = 0.f;
-        for (int k = 0; k < n; k++) { const float d = h[k] - mean; v = fmaf(d, d, v); }
-        const float rstd = 1.0f / sqrtf(v / (float)n + 1e-12f);
-        for (int k = 0; k < n; k++) {
-            const float inv = rstd * g[k];
-            float y = fmaf(h[k], inv, b[k] - mean * inv);
-            h[k] = relu ? fmaxf(y, 0.f) : y;
-        }
-    }
+    // the canonical float32 evaluation order of csrc/pve_actor.h (what the matrix-core kernel computes)
     static int launch_actor(const float *W, const void *obs_v, int obs_f32, const int32_t *meta, double *actions, int n_envs,
                             int cap, void *, std::string &)
     {
@@ -198,18 +186,9 @@ struct Backend {
         const float *obsf = (const float *)obs_v;
         for (size_t s = 0; s < (size_t)n_envs * cap; s++) {
             if ((meta[s] & (M_ALIVE | M_CONTROL)) != (M_ALIVE | M_CONTROL)) { actions[s] = 0.0; continue; }
-            float x[ACT_IN], h[ACT_H], g[ACT_H];
+            float x[ACT_IN];
             for (int k = 0; k < ACT_IN; k++) x[k] = obs_f32 ? obsf[s * OBSW + k] : (float)obs[s * OBSW + k];
-            ln(x, ACT_IN, W + AW_LN0_G, W + AW_LN0_B, false);
-            for (int j = 0; j < ACT_H; j++) h[j] = W[AW_B1 + j];
-            for (int i = 0; i < ACT_IN; i++) for (int j = 0; j < ACT_H; j++) h[j] = fmaf(x[i], W[AW_W1 + i * ACT_H + j], h[j]);
-            ln(h, ACT_H, W + AW_LN1_G, W + AW_LN1_B, true);
-            for (int j = 0; j < ACT_H; j++) g[j] = W[AW_B2 + j];
-            for (int i = 0; i < ACT_H; i++) for (int j = 0; j < ACT_H; j++) g[j] = fmaf(h[i], W[AW_W2 + i * ACT_H + j], g[j]);
-            ln(g, ACT_H, W + AW_LN2_G, W + AW_LN2_B, true);
-            float y = W[AW_B3];
-            for (int j = 0; j < ACT_H; j++) y = fmaf(g[j], W[AW_W3 + j], y);
-            actions[s] = (double)(3.0f * tanhf(y));
+            actions[s] = (double)actor_canonical(W, x);
         }
         return 0;
     }

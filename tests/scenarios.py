@@ -622,3 +622,38 @@ def check_full_size_vs_oracle(backend, n_envs, capacity, rate, ticks=420, n_samp
     assert m["ticks"] == ticks * n_envs
     assert m["overflow"] == 0, "deferred spawns at %g veh/h/lane x %d slots (peak of the sampled envs: %d)" % (rate, capacity, peak)
     return m, peak
+
+
+def check_geo_lists_equal_scan(backend, lane_num, n_envs=6, capacity=128, ticks=250, rate=None, seed=91, quantize=None):
+    """General-geometry kernel: the per-route list path == its membership-scan fallback (PVE_CFG_GEO_SCAN), bit for bit,
+    on random (optionally quantised: exact ties) action tapes; dense traffic makes some intersections overflow the list
+    pool, so one batch mixes both paths."""
+    from pve_mcc_amd.arrivals import synthetic_intentions
+    rng = np.random.default_rng(seed)
+    rate = rate or {12: 1100.0, 8: 1500.0, 4: 1800.0}[lane_num]
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed, lane_num=lane_num)
+    ch = synthetic_intentions(n_envs, arr.shape[1], seed=seed, lane_num=lane_num) if lane_num == 8 else None
+    outs = ("obs_post", "obs_pre", "reward", "flags", "nbr", "env_out", "new_slot", "lanej")
+    kw = dict(lane_num=lane_num, intentions=ch, outputs=outs)
+    if lane_num == 12:
+        kw["general_path"] = True
+    bl = make_batch(arr, n_envs, capacity, backend, **kw)
+    bs = make_batch(arr, n_envs, capacity, backend, geo_scan=True, **kw)
+    bl.reset(); bs.reset()
+    for t in range(ticks):
+        acts = rng.uniform(-3, 3, size=(n_envs, capacity)).astype(np.float32).astype(np.float64)
+        if quantize:
+            acts = np.round(acts / quantize) * quantize
+        a = torch.as_tensor(acts).to(bl.device)
+        o1, o2 = bl.step(a), bs.step(a)
+        f = _np(o1["flags"])
+        assert np.array_equal(f, _np(o2["flags"])), "tick %d: flags" % t
+        alive, c = (f & 1) != 0, (f & 2) != 0
+        for k in ("reward", "lanej", "new_slot"):
+            assert np.array_equal(_np(o1[k])[alive], _np(o2[k])[alive]), "tick %d: %s" % (t, k)
+        assert np.array_equal(_np(o1["nbr"])[c], _np(o2["nbr"])[c]), "tick %d: nbr" % t
+        assert np.array_equal(_np(o1["obs_pre"])[c], _np(o2["obs_pre"])[c]), "tick %d: obs_pre" % t
+        assert np.array_equal(_np(o1["env_out"]), _np(o2["env_out"])), "tick %d: env_out" % t
+        if t % 50 == 0 or t == ticks - 1:
+            batches_equal(bl, bs, "tick %d" % t)
+    return bl.metrics()

@@ -49,3 +49,9 @@ def test_geo_fuzz_random_tapes(lane_num, rate, cap, quant, seed):
 @pytest.mark.parametrize("lane_num", [4, 8])
 def test_geo_overflow_empty_exhausted(lane_num):
     scenarios.check_geo_overflow_and_empty(BACKEND, lane_num)
+
+
+@pytest.mark.parametrize("lane_num,rate,quant", [(8, 1500.0, None), (8, 2400.0, 1.0), (4, 1800.0, 1.0), (12, 1100.0, None)])
+def test_geo_list_path_equals_scan_fallback(lane_num, rate, quant):
+    m = scenarios.check_geo_lists_equal_scan("emu", lane_num, n_envs=3, ticks=200, rate=rate, quantize=quant)
+    assert m["ctl_steps"] > 2000

@@ -315,3 +315,32 @@ def test_gpu_full_size_actor_closed_loop_matches_small_batch():
     assert torch.equal(big.obs.index_select(0, idx), small.obs)
     m = big.metrics()
     assert m["overflow"] == 0 and m["alive_steps"] / m["ticks"] > 40
+
+
+def test_gpu_actor_kernel_follows_the_canonical_order():
+    """k_actor_t (v_mfma_f32_16x16x4_f32, transposed form) computes every dot product and LayerNorm sum in the order of
+    csrc/pve_actor.h `actor_canonical` (which the CPU emulator calls): same float32 results up to the final tanh's ulps."""
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    from oracle.actor_np import flat_weights, load_weights
+    n, ticks = 24, 120
+    arr = synthetic_arrivals(n, rate=1100.0, horizon_s=ticks * 0.1 + 30, seed=77)
+    w = flat_weights(load_weights())
+    outs = ("obs_post", "reward", "flags", "env_out")
+    dev, emu = make_batch(arr, n, 128, BACKEND, outputs=outs), make_batch(arr, n, 128, "emu", outputs=outs)
+    for b in (dev, emu):
+        b.reset()
+        b.set_actor(w)
+        for t in range(ticks):
+            b.step(None)
+    assert np.array_equal(dev.state_field("meta").cpu().numpy(), emu.state_field("meta").numpy())
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for scale in (1.0, 30.0, 150.0):
+        obs = rng.normal(0, scale, size=(n, 128, 28))
+        dev.obs.copy_(torch.as_tensor(obs).cuda())
+        emu.obs.copy_(torch.as_tensor(obs))
+        a_dev, a_emu = dev.act().cpu().numpy(), emu.act().numpy()
+        ctl = (emu.state_field("meta").numpy() & 1) != 0
+        assert ctl.sum() > 200 and np.all(a_dev[~ctl] == 0)
+        worst = max(worst, np.abs(a_dev - a_emu).max())
+    assert worst <= 2e-6, worst
