@@ -135,8 +135,10 @@ __device__ __forceinline__ void actor_ln_relu16(pve_v4f (&v)[4], const float *__
 }
 
 // Workgroup = 4 waves sharing ONE copy of the two dense kernels in LDS (rows padded to 68 floats: the four lane groups of
-// an A-operand read hit disjoint banks); persistent workgroups loop over the intersections, wave w takes the 16-vehicle
-// tiles w, w + 4, ... of the current one (<= 64 controlled vehicles: one tile per wave, all four SIMDs of the CU busy).
+// an A-operand read hit disjoint banks).  Every wave is on its own: it loops over intersections (persistent), compacts
+// the controlled vehicles of its intersection with ballots and runs their 16-vehicle tiles one after the other -- no
+// workgroup barrier after the weights are staged, so the waves of a SIMD drift apart and one wave's loads / LayerNorms
+// hide under another's MFMAs.  The next intersection's flags and the next tile's rows are loaded one step ahead.
 constexpr int ACT_WPAD = 68;
 template <int CAP, typename OBS_T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_t(const float *__restrict__ W, const OBS_T *__restrict__ obs,
@@ -144,47 +146,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                  int n_envs)
 {
     __shared__ float Ws1[ACT_IN][ACT_WPAD], Ws2[ACT_H][ACT_WPAD];
-    __shared__ unsigned char slot_of[CAP];
-    __shared__ int nctl_s;
+    __shared__ unsigned char slot_of_s[4][CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jl = lane & 15, q = lane >> 4;
+    unsigned char *slot_of = slot_of_s[wave];
     for (int i = tid; i < ACT_IN * ACT_H; i += 256) Ws1[i >> 6][i & 63] = W[AW_W1 + i];
     for (int i = tid; i < ACT_H * ACT_H; i += 256) Ws2[i >> 6][i & 63] = W[AW_W2 + i];
-    for (int env = blockIdx.x; env < n_envs; env += gridDim.x) {
-        const size_t base = (size_t)env * CAP;
-        __syncthreads();                                      // weights staged / slot_of of the previous intersection consumed
-        // controlled-vehicle compaction (first CAP / 64 waves)
-        if (wave == 0) {
-            int nctl = 0;
+    const int stride = gridDim.x * 4;
+    int env = blockIdx.x * 4 + wave;
+    int mt[CAP / 64];                                         // flags of the wave's next intersection (loaded one ahead)
 #pragma unroll
-            for (int sub = 0; sub < CAP / 64; sub++) {
-                const int s = sub * 64 + lane;
-                const int m = meta[base + s];
-                const bool c = (m & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
-                const unsigned long long b = __ballot(c);
-                const int rank = nctl + __builtin_popcountll(b & ((1ull << lane) - 1ull));
-                if (c) slot_of[rank] = (unsigned char)s;
-                else actions[base + s] = 0.0;                 // main.py:401: uncontrolled vehicles get 0
-                nctl += __builtin_popcountll(b);
-            }
-            if (lane == 0) nctl_s = nctl;
+    for (int sub = 0; sub < CAP / 64; sub++) mt[sub] = env < n_envs ? meta[(size_t)env * CAP + sub * 64 + lane] : 0;
+    __syncthreads();                                          // weights staged
+    for (; env < n_envs; env += stride) {
+        const size_t base = (size_t)env * CAP;
+        // controlled-vehicle compaction (wave-local: DS operations of one wave execute in order)
+        int nctl = 0;
+#pragma unroll
+        for (int sub = 0; sub < CAP / 64; sub++) {
+            const int s = sub * 64 + lane;
+            const bool c = (mt[sub] & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
+            const unsigned long long b = __ballot(c);
+            const int rank = nctl + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+            if (c) slot_of[rank] = (unsigned char)s;
+            else actions[base + s] = 0.0;                     // main.py:401: uncontrolled vehicles get 0
+            nctl += __builtin_popcountll(b);
         }
-        __syncthreads();
-        const int nctl = nctl_s;
-        for (int v0 = 16 * wave; v0 < nctl; v0 += 64) {       // 16 vehicles per pass and wave
+        {
+            const int en = env + stride;
+#pragma unroll
+            for (int sub = 0; sub < CAP / 64; sub++) mt[sub] = en < n_envs ? meta[(size_t)en * CAP + sub * 64 + lane] : 0;
+        }
+        // rows of the first tile
+        float xr[ACT_IN / 4];
+        int slot = slot_of[jl < nctl ? jl : 0];
+        if (nctl > 0) {
+            const OBS_T *row = obs + (base + slot) * OBSW;
+#pragma unroll
+            for (int s = 0; s < ACT_IN / 4; s++) xr[s] = (float)row[4 * s + q];
+        }
+        for (int v0 = 0; v0 < nctl; v0 += 16) {              // 16 vehicles per pass
             // the A operands are read from LDS right before the MFMA that consumes them; an offset the compiler cannot
             // see through keeps it from hoisting all 92 reads out of the loops into 250 registers (1 wave per SIMD)
             int wo = 0;
             asm volatile("" : "+v"(wo));
-            const int v = v0 + jl;
-            const bool valid = v < nctl;
-            const int slot = slot_of[valid ? v : v0];
-            // ---- inputs: lane (j, q) takes features 4 s + q of vehicle j; LayerNorm over the 28
+            const bool valid = v0 + jl < nctl;
+            const int cur_slot = slot;
+            // ---- inputs: lane (j, q) holds features 4 s + q of vehicle j; the next tile's rows are requested now
             float x[ACT_IN / 4];
-            {
+#pragma unroll
+            for (int s = 0; s < ACT_IN / 4; s++) x[s] = xr[s];
+            if (v0 + 16 < nctl) {
+                slot = slot_of[v0 + 16 + jl < nctl ? v0 + 16 + jl : v0 + 16];
                 const OBS_T *row = obs + (base + slot) * OBSW;
+#pragma unroll
+                for (int s = 0; s < ACT_IN / 4; s++) xr[s] = (float)row[4 * s + q];
+            }
+            {   // LayerNorm over the 28 inputs
                 float sum = 0.f;
 #pragma unroll
-                for (int s = 0; s < ACT_IN / 4; s++) { x[s] = (float)row[4 * s + q]; sum += x[s]; }
+                for (int s = 0; s < ACT_IN / 4; s++) sum += x[s];
                 const float mean = actor_xsum(sum) / (float)ACT_IN;
                 float var = 0.f;
 #pragma unroll
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int r = 0; r < 4; r++) part = fmaf(g[m][r], w3[r], part);
             }
             const float a = 3.0f * tanhf(actor_xsum(part) + W[AW_B3]);
-            if (q == 0 && valid) actions[base + slot] = (double)a;
+            if (q == 0 && valid) actions[base + cur_slot] = (double)a;
         }
     }
 }

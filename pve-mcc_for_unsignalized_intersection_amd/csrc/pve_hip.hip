@@ -227,34 +227,58 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     Regs r;
     typedef TickGeo<CAP> T;
     typedef Tick<CAP, SharedGeo<CAP>> B;
+    unsigned long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = P.phase_cycles ? wall_clock64() : 0ull;
+#undef PVE_PHASE_MARK
+#define PVE_PHASE_MARK(idx)                                                              \
+    if (P.phase_cycles) {                                                                \
+        unsigned long long now_ = wall_clock64();                                        \
+        pc_[idx] = now_ - tprev_;                                                        \
+        tprev_ = now_;                                                                   \
+    }
     T::ph_load(g, P, env, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(0)
     T::ph_step1(g, P, env, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(1)
     B::ph_step2(g.base, t, sh, r);
     T::ph_order(t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(2)
     B::ph_step3(g.base, t, sh, r);
     B::ph_step3_publish(t, sh, r);
     T::ph_order2(t, sh, P.geo_scan != 0);
     __syncthreads();
+    PVE_PHASE_MARK(3)
     T::ph_fill(g, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(4)
     T::ph_scan(g, t, sh, r);
+    PVE_PHASE_MARK(11)
     T::ph_reward(g, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(6)
     T::ph_effects(g, t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(7)
     B::ph_prefetch_arrival(P, env, t, sh, r, g.lane_num);
     B::ph_lock(g.base, t, sh, r);
     __syncthreads();
     B::ph_lock2(t, sh, r);
     __syncthreads();
+    PVE_PHASE_MARK(8)
     T::ph_final(g, P, env, t, sh, r);
+    PVE_PHASE_MARK(9)
     if (P.out.state_pre) {
         __threadfence_block();
         __syncthreads();
         T::ph_state(P, env, t, sh, r);
+    }
+    if (P.phase_cycles && (t & 63) == 0) {
+        unsigned long long *row = P.phase_cycles + ((size_t)env * (CAP / 64) + (t >> 6)) * 16;
+#pragma unroll
+        for (int k = 0; k < 12; k++) row[k] += pc_[k];
     }
 }
 
@@ -413,7 +437,7 @@ struct Backend {
     {
         // persistent workgroups (the 23 KB of dense kernels are staged in LDS once per workgroup): 4 per CU
         static const int wgs = getenv("PVE_ACTOR_GRID") ? atoi(getenv("PVE_ACTOR_GRID")) : 1024;
-        const int grid = n_envs < wgs ? n_envs : wgs;
+        const int grid = (n_envs + 3) / 4 < wgs ? (n_envs + 3) / 4 : wgs;     // one wave per intersection
         if (cap == 64) hipLaunchKernelGGL((k_actor_t<64, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
         else hipLaunchKernelGGL((k_actor_t<128, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
     }

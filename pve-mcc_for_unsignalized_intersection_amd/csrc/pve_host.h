@@ -164,6 +164,22 @@ inline GeoConst make_geo_const(const pve_config &cfg)
     for (int i = 0; i < LN; i++)
         for (int m = 0; m < 3; m++)
             if (g.direction[i][m] >= 0) { g.dir_lane[g.direction[i][m]] = (int8_t)i; g.dir_index[g.direction[i][m]] = (int8_t)m; }
+    // membership tables of the virtual-lane lists (ref :240-270): which routes can appear in list d, and where
+    memset(g.pos, -1, sizeof(g.pos));
+    memset(g.mroutes, 0, sizeof(g.mroutes));
+    memset(g.lroutes, 0, sizeof(g.lroutes));
+    for (int d = 0; d < ND; d++) {
+        g.opp[d] = g.l2l[d][1];
+        if (d >= g.dir_num) continue;
+        for (int q = 0; q < MAXK; q++) if (g.l2l[d][q] >= 0) g.pos[d][g.l2l[d][q]] = (int8_t)q;
+        unsigned mr = 0;
+        const int li = g.dir_lane[d];
+        for (int q = 0; q < 3; q++) if (g.direction[li][q] >= 0) mr |= 1u << g.direction[li][q];
+        for (int q = 0; q < MAXK; q++) if (g.l2l[d][q] >= 0) mr |= 1u << g.l2l[d][q];
+        g.mroutes[d] = (uint16_t)mr;
+    }
+    for (int d = 0; d < g.dir_num; d++)
+        for (int rt = 0; rt < ND; rt++) if ((g.mroutes[d] >> rt) & 1u) g.lroutes[rt] |= (uint16_t)(1u << d);
     return g;
 }
 

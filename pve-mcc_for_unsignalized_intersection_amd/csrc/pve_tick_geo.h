@@ -40,7 +40,7 @@ template <int CAP> struct SharedGeo {
     uint8_t u_slot[PE];
     int rc[ND], fill[ND], pool_ok;   // controlled vehicles per route, entries filed per list
     int16_t lbase[ND + 1];
-    uint16_t lroutes[ND];            // bit d: route r can be a member of list d (transpose of mroutes)
+    alignas(4) uint16_t lroutes[ND]; // bit d: route r can be a member of list d (transpose of mroutes)
     double vdt[4][MAXK][4];          // get_virtual_distance table (GeoConst::vd)
     double inbox[4];
     int cnt[CAP];
@@ -50,9 +50,9 @@ template <int CAP> struct SharedGeo {
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW], m_spawn[NW];
     u64 m_int[3][NW];                // alive slots by intention
     u64 m_ctl_ord[NW];               // "controlled" flags in processing order
-    int8_t pos[ND][ND];              // pos[d][route] = index of route in lane2lane[d], or -1
-    int8_t opp[ND];                  // lane2lane[d][1] (4-lane fix-up, ref :1303)
-    uint16_t mroutes[ND];            // bit r: route r can be a member of list d (same lane, or in lane2lane[d])
+    alignas(4) int8_t pos[ND][ND];   // pos[d][route] = index of route in lane2lane[d], or -1
+    alignas(4) int8_t opp[ND];       // lane2lane[d][1] (4-lane fix-up, ref :1303)
+    alignas(4) uint16_t mroutes[ND]; // bit r: route r can be a member of list d (same lane, or in lane2lane[d])
 };
 
 // XY position (ref :896-1249): every (lane, intention) branch of the reference is one of three canonical paths
@@ -77,6 +77,37 @@ PVE_HD void geo_xy(const PVE_AS4 GeoConst &g, double p, int lane, int m, double 
         const double dy = sn * cw, dx = cs * cw;
         x = before ? -(p - Lb + H) : (inside ? -(H - dx) : -yo);
         y = before ? -yo : (inside ? -(H - dy) : -(-1 * p + H));
+    }
+    const int q = g.turn[lane];
+    X = (q == 0) ? x : (q == 1) ? -y : (q == 2) ? -x : y;
+    Y = (q == 0) ? y : (q == 1) ? x : (q == 2) ? -y : -x;
+}
+
+// single-precision twin of geo_xy for the collision PRE-FILTER only (never for a decision): |error| < 1e-3 m
+PVE_HD void geo_xy_f32(const PVE_AS4 GeoConst &g, double pd, int lane, int m, float &X, float &Y)
+{
+    if (g.lane_num == 12) { get_xy_f32(g.base, pd, lane, X, Y); return; }
+    const float cw = (float)g.base.cw, H = (float)g.H, p = (float)pd;
+    const float yo = (g.lane_num == 8 && (lane & 1)) ? 3.f * cw : cw;
+    const float Lb = (float)((m == 2) ? g.base.inbox[2] : g.base.inbox[0]);
+    const float rl = (float)g.RL;
+    const bool before = p > Lb, inside = !before && p > 0.f;
+    const float ra = (inside && m != 1) ? ((m == 0) ? p / (rl * cw) : p / cw) : 0.f;
+    const bool fold = ra > 0.78539816f;
+    const float y0 = fold ? (1.5707964f - ra) : ra, z = y0 * y0;
+    const float s1 = y0 + y0 * z * (-1.6666667e-1f + z * (8.3333338e-3f + z * (-1.9841270e-4f + z * 2.7557319e-6f)));
+    const float c1 = 1.f + z * (-0.5f + z * (4.1666668e-2f + z * (-1.3888889e-3f + z * 2.4801587e-5f)));
+    const float sn = fold ? c1 : s1, cs = fold ? s1 : c1;
+    float x, y;
+    if (m == 1) { x = -1.f * p + H; y = -yo; }
+    else if (m == 0) {
+        const float dy = sn * rl * cw, dx = cs * rl * cw;
+        x = before ? -(p - Lb + H) : (inside ? (dx - H) : cw);
+        y = before ? -cw : (inside ? (H - dy) : (-1.f * p + H));
+    } else {
+        const float dy = sn * cw, dx = cs * cw;
+        x = before ? -(p - Lb + H) : (inside ? -(H - dx) : -yo);
+        y = before ? -yo : (inside ? -(H - dy) : -(-1.f * p + H));
     }
     const int q = g.turn[lane];
     X = (q == 0) ? x : (q == 1) ? -y : (q == 2) ? -x : y;
@@ -111,31 +142,15 @@ template <int CAP> struct TickGeo {
         if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
         for (int w = t; w < 4 * MAXK * 4; w += CAP) (&sh.vdt[0][0][0])[w] = (&g.vd[0][0][0])[w];
         if (t < 3) sh.inbox[t] = g.base.inbox[t];
-        for (int w = t; w < ND * ND; w += CAP) {
-            const int d = w / ND, rt = w - d * ND;
-            int k = -1;
-            for (int q = 0; q < MAXK; q++) if (g.l2l[d][q] == rt) k = q;
-            sh.pos[d][rt] = (int8_t)k;
+        // membership tables: host-computed (GeoConst), copied word by word
+        {
+            const int *src = (const int *)&g.pos[0][0];
+            int *dst = (int *)&sh.pos[0][0];
+            for (int w = t; w < ND * ND / 4; w += CAP) dst[w] = src[w];
         }
-        if (t < ND) {
-            sh.opp[t] = g.l2l[t][1];
-            unsigned mr = 0;
-            const int li = g.dir_lane[t];
-            for (int q = 0; q < 3; q++) if (g.direction[li][q] >= 0) mr |= 1u << g.direction[li][q];
-            for (int q = 0; q < MAXK; q++) if (g.l2l[t][q] >= 0) mr |= 1u << g.l2l[t][q];
-            sh.mroutes[t] = (uint16_t)mr;
-            // transpose: the lists route t can be filed into
-            unsigned lr = 0;
-            for (int d = 0; d < g.dir_num; d++) {
-                bool in = false;
-                const int ld = g.dir_lane[d];
-                for (int q = 0; q < 3; q++) in = in || (g.direction[ld][q] == t);
-                for (int q = 0; q < MAXK; q++) in = in || (g.l2l[d][q] == t);
-                if (in) lr |= 1u << d;
-            }
-            sh.lroutes[t] = (uint16_t)lr;
-            sh.rc[t] = 0; sh.fill[t] = 0;
-        }
+        if (t < ND / 4) ((int *)sh.opp)[t] = ((const int *)g.opp)[t];
+        if (t < ND / 2) { ((int *)sh.mroutes)[t] = ((const int *)g.mroutes)[t]; ((int *)sh.lroutes)[t] = ((const int *)g.lroutes)[t]; }
+        if (t < ND) { sh.rc[t] = 0; sh.fill[t] = 0; }
     }
 
     // ============================================================== S1..S3: step() -- the 12-lane phases; the head
@@ -398,7 +413,17 @@ template <int CAP> struct TickGeo {
         r_ = (r_ > -20) ? r_ : -20;
         r.reward = (r_ < 20) ? r_ : 20;
         r.jerk_sum += fabs(jd);
+        // pre-filter in single precision: the exact FP64 positions (divisions + polynomials) are only evaluated when the
+        // pair is within 5 cm of the threshold band -- the decision itself is always FP64
+        bool near = false;
         if (n0 >= 0) {
+            float ax, ay, bx, by;
+            geo_xy_f32(g, ps, r.lane, r.intent, ax, ay);
+            geo_xy_f32(g, sh.p[n0], sh.lane_of[n0], sh.intent_of[n0], bx, by);
+            const float fx = bx - ax, fy = by - ay, lim = (float)c.collision_thr + 0.05f;
+            near = fx * fx + fy * fy < lim * lim;
+        }
+        if (near) {
             double ax, ay, bx, by;
             geo_xy(g, ps, r.lane, r.intent, ax, ay);
             geo_xy(g, sh.p[n0], sh.lane_of[n0], sh.intent_of[n0], bx, by);

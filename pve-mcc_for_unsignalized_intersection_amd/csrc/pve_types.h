@@ -88,6 +88,11 @@ struct GeoConst {
     int8_t dir_lane[ND], dir_index[ND];    // inverse of direction
     int8_t turn[NL];               // get_p: quarter turns of the canonical path (ref :896-1249)
     int8_t pad_[4];
+    // derived membership tables (host-computed once; the kernel copies them into LDS with plain dword loads)
+    int8_t pos[ND][ND];            // pos[d][route] = index of route in lane2lane[d], or -1
+    int8_t opp[ND];                // lane2lane[d][1] (4-lane fix-up, ref :1303)
+    uint16_t mroutes[ND];          // bit r: route r can be a member of list d (same physical lane, or in lane2lane[d])
+    uint16_t lroutes[ND];          // bit d: route r can be filed into list d (transpose of mroutes)
 };
 
 struct Outputs {        // mirrors pve_outputs (include/pve_env.h)
