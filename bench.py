@@ -113,7 +113,7 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(envs_per_launch, cap, outputs, mode, other):
+def pmc_traffic(envs_per_launch, cap, outputs, mode, ticks_per_launch, other):
     """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x gfx950 correction + WRITE_SIZE).
     Counters cannot be read from inside the process, so they come from the committed rocprofv3 passes of this very
     command (tools/collect_profiles.sh -> profiles/r*_traffic.json); null unless kernel sources, config and launch
@@ -127,9 +127,9 @@ def pmc_traffic(envs_per_launch, cap, outputs, mode, other):
     if not files:
         return None, None
     files.sort(key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)))
-    t = json.load(open(files[-1]))
-    if int(t.get("envs_per_launch", 4096)) != envs_per_launch or t.get("csrc_sha") != csrc_sha() \
-            or t.get("mode", "step") != mode:
+    t = json.load(open(files[-1])).get(mode)
+    if not t or int(t.get("envs_per_launch", 4096)) != envs_per_launch or t.get("csrc_sha") != csrc_sha() \
+            or int(t.get("ticks_per_launch", 1)) != ticks_per_launch:
         return None, None
     return t, os.path.relpath(files[-1], ROOT)
 
@@ -367,10 +367,11 @@ def main(argv=None, env_factory=None):
         kern_s = gpu_ms * 1e-3 / K                      # one tick of one sub-batch (n_envs / n_sub envs) on its stream
         per_launch = b_alg * cap * envs_per_launch / kern_s / 1e9
         kname = (("k_rollout<%d>" if mode == "rollout" else "k_tick<%d>") if lane_num == 12 else "k_tick_geo<%d>") % cap
+        tpl = (args.chunk if args.chunk > 0 else K) if mode == "rollout" else 1      # ticks per kernel launch
         tr, traffic_src = (None, None) if (emu or not steady) else pmc_traffic(
-            int(envs_per_launch), cap, outputs, mode, args.actor or lane_num != 12 or args.obs_f32)
+            int(envs_per_launch), cap, outputs, mode, tpl, args.actor or lane_num != 12 or args.obs_f32)
         traffic = tr["hbm_bytes_per_launch"] if tr else None
-        counter_rate = (traffic * n_sub / (wall / K) / 1e9) if traffic else None
+        counter_rate = (traffic / tpl * n_sub / (wall / K) / 1e9) if traffic else None
         peak_meas = None if (emu or args.no_copy_peak) else measured_copy_peak(torch, dev)
         mean_alive = tot["alive_steps"] / (K * n_envs * world)
         line = {
@@ -382,7 +383,7 @@ def main(argv=None, env_factory=None):
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
                                       if args.actor else "sin action pool"),
-                       "envs_per_gpu": n_envs, "capacity": cap, "mode": mode,
+                       "envs_per_gpu": n_envs, "capacity": cap, "mode": mode, "ticks_per_launch": tpl,
                        "parallelism": "env-parallel x%d" % world + (", %d stream-pipelined sub-batches of %d envs per GPU"
                                                                    % (n_sub, int(envs_per_launch)) if n_sub > 1 else ""),
                        "outputs": list(outputs), "obs_dtype": "f32" if args.obs_f32 else "f64"},

@@ -29,6 +29,17 @@ typedef __attribute__((address_space(4))) const char *KernargPtr;
         tprev_ = now_;                                                                   \
     }
 
+// LDS-only workgroup barrier: orders LDS accesses (lgkmcnt) but does not wait for this wave's outstanding global
+// loads / stores (no vmcnt(0)), so that prefetches and the output stores of one tick stay in flight across the phases
+// of the next.  __syncthreads() remains where global memory must be ordered.
+__device__ __forceinline__ void lds_barrier_x()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 // CAP = 128: 5 waves per SIMD (<= 96 VGPR) + the 15.1 KB LDS block = 10 workgroups of 128 threads per CU instead of 8: with
 // the sub-batches pipelined on several streams the tick scales almost linearly with the resident workgroups.
 // CAP = 64: one wave per workgroup, LDS (10 KB) admits 16 workgroups per CU = 4 waves per SIMD (<= 128 VGPR).
@@ -46,39 +57,39 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(CAP == 64 ?
     unsigned long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev_ = P.phase_cycles ? wall_clock64() : 0ull;
     T::ph_load(c, P, env, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(0)
     T::ph_step1(c, P, env, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(1)
     T::ph_step2(c, t, sh, r);
     T::ph_lists_a(c, t, sh);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(2)
     T::ph_step3(c, t, sh, r);
     T::ph_step3_publish(t, sh, r);
     T::ph_lists_b(t, sh);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(3)
     T::ph_build(c, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(4)
     T::ph_rank(t, sh);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(5)
     T::ph_scan(c, t, sh, r);
     PVE_PHASE_MARK(11)
     T::ph_reward(c, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(6)
     T::ph_effects(c, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(7)
     T::ph_prefetch_arrival(P, env, t, sh, r, NL);
     T::ph_lock(c, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     T::ph_lock2(t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(8)
     T::ph_final(c, P, env, t, sh, r);
     PVE_PHASE_MARK(9)
@@ -95,17 +106,6 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(CAP == 64 ?
     }
 }
 
-// LDS-only workgroup barrier: orders LDS accesses (lgkmcnt) but does not wait for this wave's outstanding global
-// loads / stores (no vmcnt(0)), so that prefetches and the output stores of one tick stay in flight across the phases
-// of the next.  __syncthreads() remains where global memory must be ordered.
-__device__ __forceinline__ void lds_barrier_x()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 // pve_step_many: R.n_ticks ticks of one intersection per workgroup, the state resident in registers / LDS between the
 // ticks (pve_tick_core.h, "k_rollout").  Per tick only the outputs go to HBM; the action of the next tick (pool) and
 // the next arrival times are prefetched under the tail of the current one.

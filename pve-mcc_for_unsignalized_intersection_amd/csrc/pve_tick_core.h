@@ -428,15 +428,16 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         // off the critical path and mostly empty: they wait for n_alive and read the live slots only.
         r.act = 0;
         if (t < 64 || t < N) {
+            // what S1 - S3 need comes first; the fields that are merely carried to FIN (or first read in WALK) are requested
+            // behind them and arrive under the step phases (the kernel's barriers do not wait for global loads)
             if (P.actions) r.act = P.actions[g];          // with the state loads: one latency, not a second one in S1
             r.p = P.f64[F_P][g]; r.v = P.f64[F_V][g]; r.a = P.f64[F_A][g];
+            r.meta = P.i32[I_META][g]; r.step = P.i32[I_STEP][g];
             r.jerk_sum = P.f64[F_JERK_SUM][g]; r.vir_dis = P.f64[F_VIR_DIS][g];
             r.closer_p = P.f64[F_CLOSER_P][g];
             r.id = P.i32[I_ID][g]; r.seq = P.i32[I_SEQ][g]; r.vnum = P.i32[I_VNUM][g];
-            r.step = P.i32[I_STEP][g]; r.count = P.i32[I_COUNT][g]; r.meta = P.i32[I_META][g];
+            r.count = P.i32[I_COUNT][g];
         }
-        sh.virdis[t] = r.vir_dis;                         // carried in LDS, not in a register (WALK overwrites it for the
-                                                          // controlled vehicles, FIN reads it back): 2 VGPRs less across the phases
         sh.cnt[t] = 0;                                    // (rew_ovr / hdr share storage with S2-S3 arrays: BUILD)
         if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
         if (t < 8) {
@@ -558,6 +559,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_build(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         sh.rew_ovr[t] = 0; sh.hdr[t] = -1;                // their storage was bb / pref until the barrier before BUILD
+        sh.virdis[t] = r.vir_dis;                         // carried in LDS, not in a register (WALK overwrites it for the
+                                                          // controlled vehicles, FIN reads it back): 2 VGPRs less across the phases
         if (!(r.alive && r.ctl)) return;
         const int lane = r.lane;
         get_xy_f32(c, r.p, lane, sh.xy32[t][0], sh.xy32[t][1]);
@@ -1213,7 +1216,6 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // work-array initialisation of a resident tick (what LOAD does besides loading), after the barrier behind RELOAD
     static PVE_HD void ph_tick_init(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
-        sh.virdis[t] = r.vir_dis;
         sh.cnt[t] = 0;
         if (t == 0) {
             sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0;

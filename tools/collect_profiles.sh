@@ -1,25 +1,40 @@
 #!/bin/bash
 # Run ON the MI355X box (through gpurun) to collect every measurement that profiles/ summarises.
-# Usage: gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r1'
+# Usage: gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r2'
 set -u
-R=${1:-r1}
+R=${1:-r2}
 export TMPDIR=/tmp
 O=gpurun_out/$R
 mkdir -p $O
-timeout 400 python bench.py 2>&1 | tail -1 > $O/bench_default.json
-timeout 400 python bench.py --pipeline 1 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_single_launch.json
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_single -o r -- python bench.py --pipeline 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o r -- python bench.py --no-cpu-baseline > $O/stats.log 2>&1
-# PMC counters in their own passes (kernel-trace only), FETCH_SIZE and WRITE_SIZE cannot share a pass
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o r -- python bench.py --steps 40 --warmup 300 --no-cpu-baseline > /dev/null 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o r -- python bench.py --steps 40 --warmup 300 --no-cpu-baseline > /dev/null 2>&1
+B="python bench.py"
+NB="python bench.py --no-cpu-baseline --no-copy-peak"
+# ---- bench lines
+timeout 400 $B 2>/dev/null | tail -1 > $O/bench_default.json
+timeout 400 $B --mode step 2>/dev/null | tail -1 > $O/bench_step.json
+timeout 400 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_driver_like.json
+timeout 400 $NB --mode step --pipeline 1 2>/dev/null | tail -1 > $O/bench_single_launch.json
+timeout 400 $NB --mode rollout --pipeline 1 --chunk 0 2>/dev/null | tail -1 > $O/bench_rollout_one_launch.json
+timeout 300 $B --capacity 64 2>/dev/null | tail -1 > $O/bench_cap64.json
+timeout 300 $NB --capacity 64 --mode step 2>/dev/null | tail -1 > $O/bench_cap64_step.json
+timeout 300 $NB --actor --obs-f32 --pipeline 3 2>/dev/null | tail -1 > $O/bench_actor.json
+timeout 300 $NB --actor 2>/dev/null | tail -1 > $O/bench_actor_f64.json
+timeout 300 $B --lane-num 8 --steps 300 --pipeline 3 2>/dev/null | tail -1 > $O/bench_lanes8.json
+timeout 300 $NB --lane-num 4 --capacity 64 --rate 1200 --steps 300 2>/dev/null | tail -1 > $O/bench_lanes4.json
+# ---- per-kernel durations (rocprofv3 --kernel-trace --stats), same commands
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o r -- $NB > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_step -o r -- $NB --mode step > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_cap64 -o r -- $NB --capacity 64 > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_actor -o r -- $NB --actor --obs-f32 --pipeline 3 --steps 300 > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_lanes8 -o r -- $NB --lane-num 8 --steps 300 --pipeline 3 > /dev/null 2>&1
+# ---- HBM counters in their own passes (kernel-trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass)
+for m in rollout step; do
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch_$m -o r -- $NB --mode $m --steps 100 > /dev/null 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write_$m -o r -- $NB --mode $m --steps 100 > /dev/null 2>&1
+done
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/probe -o r -- python tools/traffic_probe.py > $O/probe.log 2>&1
-timeout 300 python bench.py --capacity 64 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cap64.json
-timeout 300 python bench.py --actor --no-cpu-baseline 2>&1 | tail -1 > $O/bench_actor.json
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_actor -o r -- python bench.py --actor --no-cpu-baseline --steps 300 > /dev/null 2>&1
-python tools/phase_profile.py --ticks 50 > $O/phase_profile.txt 2>&1
-# general-geometry kernel (4 / 8 lanes)
-timeout 300 python bench.py --lane-num 8 --steps 300 2>&1 | tail -1 > $O/bench_lanes8.json
-timeout 300 python bench.py --lane-num 4 --capacity 64 --steps 300 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_lanes4.json
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_lanes8 -o r -- python bench.py --lane-num 8 --steps 300 --no-cpu-baseline > /dev/null 2>&1
+# ---- phase profiles
+python tools/phase_profile.py --ticks 100 > $O/phase_profile_step.txt 2>&1
+python tools/phase_profile.py --ticks 100 --many > $O/phase_profile_rollout.txt 2>&1
+python tools/phase_profile.py --ticks 100 --many --capacity 64 > $O/phase_profile_rollout_cap64.txt 2>&1
+python tools/phase_profile.py --ticks 100 --lane-num 8 > $O/phase_profile_lanes8.txt 2>&1
 ls $O

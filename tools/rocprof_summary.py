@@ -20,14 +20,17 @@ def main():
     for r in rows:
         print("%-70s %8d %12.1f %10d %10d %14d %6.2f" % (r[0][:70], r[1], r[2], r[3], r[4], r[5], 100.0 * r[5] / tot))
     if tail:
-        print("## steady state: last %d dispatches of each k_tick kernel" % tail)
-        for (name,) in list(cur.execute("select distinct name from kernels where name like '%k_tick%'")):
+        print("## steady state: last %d dispatches of each k_tick / k_rollout / k_actor kernel" % tail)
+        for (name,) in list(cur.execute("select distinct name from kernels where name like '%k_tick%' or name like '%k_rollout%' "
+                                        "or name like '%k_actor%'")):
             d = [x[0] for x in cur.execute("select end-start from kernels where name=? order by start", (name,))][-tail:]
             print("%-70s n=%d avg_ns=%.1f min=%d max=%d" % (name[:70], len(d), sum(d) / len(d), min(d), max(d)))
-    r = list(cur.execute("select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x "
-                         "from kernels where name like '%k_tick%' limit 1"))
-    if r:
-        print("## k_tick resources: vgpr=%s agpr=%s sgpr=%s lds=%s scratch=%s grid=%s wg=%s" % r[0])
+    for r in cur.execute("select distinct name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x "
+                         "from kernels where name like '%k_tick%' or name like '%k_rollout%' or name like '%k_actor%'"):
+        # rocprofv3's vgpr_count field is NOT the per-lane allocation the occupancy follows (it reports 48 for a kernel the
+        # compiler allocates 96 registers to); the compiler's numbers are in profiles/rNN_resource_usage.txt
+        print("## dispatch record %s: rocprofv3 vgpr_count field=%s accum=%s sgpr=%s lds=%s scratch=%s grid=%s wg=%s "
+              "(compiler allocation: see the resource_usage file)" % ((r[0][:40],) + tuple(r[1:])))
     try:
         rows = list(cur.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
                                 "from counters_collection group by kernel_name, counter_name order by 1, 2"))
@@ -39,12 +42,13 @@ def main():
         for r in rows:
             print("%-60s %-24s %7d %16.3f %16.3f %16.3f" % (r[0][:60], r[1], r[2], r[3], r[4], r[5]))
         if tail:
-            print("## counters, last %d k_tick dispatches" % tail)
+            print("## counters, last %d dispatches per kernel family" % tail)
             for (cn,) in list(cur.execute("select distinct counter_name from counters_collection")):
-                d = [x[0] for x in cur.execute("select value from counters_collection where kernel_name like '%k_tick%' "
-                                               "and counter_name=? order by start", (cn,))][-tail:]
-                if d:
-                    print("%-24s n=%d avg=%.3f" % (cn, len(d), sum(d) / len(d)))
+                for kn in ("k_tick", "k_rollout", "k_actor"):
+                    d = [x[0] for x in cur.execute("select value from counters_collection where kernel_name like ? "
+                                                   "and counter_name=? order by start", ("%" + kn + "%", cn))][-tail:]
+                    if d:
+                        print("%-12s %-24s n=%d avg=%.3f" % (kn, cn, len(d), sum(d) / len(d)))
 
 
 if __name__ == "__main__":
