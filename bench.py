@@ -92,7 +92,7 @@ def cpu_baseline(arr, pool, cap, lane_num=12, choice=None):
 
     n = min(arr.shape[0], max(cores * 4, 16))
     dt, alive = timed([(e, make(e)) for e in range(n)], min(cores, n))
-    n1 = min(arr.shape[0], 8)
+    n1 = min(arr.shape[0], 32)
     dt1, alive1 = timed([(e, make(e)) for e in range(n1)], 1)
     return dict(value=n * cap * CPU_TICKS / dt, unit="env-steps/s", cores=min(cores, n), kind="port",
                 cpu_model=cpu_model(), alive_steps_per_s=alive / dt,
@@ -201,12 +201,17 @@ def main(argv=None, env_factory=None):
                          "one call per sub-batch with the action source (pool / actor) on the device")
     ap.add_argument("--chunk", type=int, default=0,
                     help="rollout mode: ticks per kernel launch (0 = the whole call in one launch)")
+    ap.add_argument("--obs-f64", action="store_true",
+                    help="with --actor: keep float64 observation rows (default there: float32, the type the actor consumes, "
+                         "model_agent_maddpg.py:15; identical trajectories, tests/actor_scenarios.py)")
     ap.add_argument("--obs-f32", action="store_true",
                     help="float32 observation rows (PVE_CFG_OBS_F32; SURVEY 8d's FP32-output variant, 268 B algorithmic); "
                          "the headline / BASELINE metric is the float64 parity layout (380 B)")
     ap.add_argument("--actor", action="store_true",
                     help="BASELINE config 5: close the loop on the device (actor -> tick per step) instead of the action pool")
     args = ap.parse_args(argv)
+    if args.actor and not args.obs_f64:
+        args.obs_f32 = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -242,7 +247,10 @@ def main(argv=None, env_factory=None):
     cap, n_envs, lane_num = args.capacity, args.envs, args.lane_num
     # capacity 64: 350 veh/h/lane keeps the peak population of 4096 envs x 2300 ticks at 57 of 64 slots (oracle run): no deferred
     # spawn ever enters a timed run (400 peaks at 62, 450 at 64+, 500 overflowed 4539 times in round 1)
-    rate = args.rate or {12: (1100.0 if cap == 128 else 350.0), 8: 1500.0, 4: 1800.0}[lane_num]
+    # closed loop: the pretrained actor keeps ~7 % more vehicles in the box than the sin tape; 1000 veh/h/lane keeps every
+    # one of 4096 envs under 128 slots (1100 deferred 59 spawns in 300 ticks)
+    rate = args.rate or {12: ((1000.0 if args.actor else 1100.0) if cap == 128 else 350.0), 8: 1500.0,
+                         4: (1800.0 if cap == 128 else 1200.0)}[lane_num]
     K, W = args.steps, args.warmup
     prefill_min = max(0, args.prefill)
     prefill_cap = max(prefill_min, PREFILL_MAX) if prefill_min >= PREFILL_MIN else prefill_min

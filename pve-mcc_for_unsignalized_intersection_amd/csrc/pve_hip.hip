@@ -248,12 +248,17 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     PVE_PHASE_MARK(2)
     B::ph_step3(g.base, t, sh, r);
     B::ph_step3_publish(t, sh, r);
-    T::ph_order2(t, sh, P.geo_scan != 0);
+    T::ph_order2(t, sh);
     __syncthreads();
     PVE_PHASE_MARK(3)
-    T::ph_fill(g, t, sh, r);
+    T::ph_count(g, t, sh, r);
+    __syncthreads();
+    T::ph_fill(g, t, sh, r, P.geo_scan != 0);
     __syncthreads();
     PVE_PHASE_MARK(4)
+    T::ph_rank(t, sh);
+    __syncthreads();
+    PVE_PHASE_MARK(5)
     T::ph_scan(g, t, sh, r);
     PVE_PHASE_MARK(11)
     T::ph_reward(g, t, sh, r);

@@ -180,6 +180,11 @@ inline GeoConst make_geo_const(const pve_config &cfg)
     }
     for (int d = 0; d < g.dir_num; d++)
         for (int rt = 0; rt < ND; rt++) if ((g.mroutes[d] >> rt) & 1u) g.lroutes[rt] |= (uint16_t)(1u << d);
+    g.turn_pk = 0; g.dir_pk[0] = g.dir_pk[1] = g.dir_pk[2] = 0;
+    for (int i = 0; i < NL; i++) {
+        g.turn_pk |= (unsigned long long)(g.turn[i] & 15) << (4 * i);
+        for (int m = 0; m < 3; m++) g.dir_pk[m] |= (unsigned long long)((g.direction[i][m] + 1) & 31) << (5 * i);
+    }
     return g;
 }
 

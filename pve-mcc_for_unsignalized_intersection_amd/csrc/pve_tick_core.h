@@ -218,17 +218,16 @@ template <int CAP> struct Shared {
     int emu_scan;                    // emulator-only accumulator of wave_incl_scan
 #endif
     int16_t loff[NL + 1];            // list d occupies [loff[d], loff[d+1])
-    int16_t segoff[NL][5];           // start of segment (own, conflict 0..3) inside list d
+    union {
+        alignas(8) int16_t segoff[NL][5];                  // start of segment (own, conflict 0..3) inside list d (LISTS .. BUILD)
+        struct { double red_reward[NW], red_jerk[NW]; };   // per-wave partial sums (LOCK .. FIN)
+    };
     uint8_t lane_of[CAP];            // lane of every alive slot
     union {
         float xy32[CAP][2];          // single-precision position of every controlled vehicle (collision pre-filter; BUILD .. REWARD)
         double act_next[CAP];        // k_rollout: the NEXT tick's action of every slot, prefetched under the tail of this tick
     };
-    union {
-        double tabA[2][4];           // get_virtual_distance table (copy of Const, lane-indexed reads; BUILD only)
-        struct { double red_reward[NW], red_jerk[NW]; };   // per-wave partial sums (LOCK .. FIN)
-    };
-    double tabB[2][4], tabC[2][4];
+    double tabA[2][4], tabB[2][4], tabC[2][4];   // get_virtual_distance table (copy of Const, lane-indexed reads; BUILD only)
     int8_t l2l[NL][4], l2l_inv[NL][4];
     int lead_n;                      // scratch units claimed by the dead-lock cycles
 };
@@ -246,6 +245,7 @@ struct Regs {
     int alive, ctl, del, fin;
     int cyc;                         // dead-lock cycle membership: bit0 | len << 1 | rank << 5 | leader slot << 9
     int intent, route, ord;          // general-geometry path only (intention, direction[lane][intention], processing order)
+    int mmask;                       // general-geometry path only: bit d = member of list d (COUNT .. FILL)
     double act;                      // this tick's action of the slot (loaded with the state, used by S1)
     double next_arr;                 // lane t < 12 that spawns: its next arrival time (loaded in LOCK, stored in FIN)
     double act_nx;                   // k_rollout: next tick's action of this slot (global load in flight under FX .. LOCK2)
@@ -295,11 +295,39 @@ PVE_HD void sincos_q1(double x, double &sn, double &cs)
     cs = fold ? s1 : c1;
 }
 
+// Small constant tables of the kernel arguments are never indexed with a per-lane value (that would be a vector load
+// from the argument buffer, ~1 us on the critical path): the entries are scalar-loaded and selected.
+// (the empty asm makes the loaded values opaque: otherwise the compiler turns the select of loads back into one load
+// from a selected address)
+PVE_HD double sel2(double a0, double a1, bool second)
+{
+#if PVE_DEVICE_CODE
+    asm volatile("" : "+s"(a0), "+s"(a1));
+#endif
+    return second ? a1 : a0;
+}
+PVE_HD double sel3(const PVE_AS4 double (&a)[3], int i)
+{
+    double a0 = a[0], a1 = a[1], a2 = a[2];
+#if PVE_DEVICE_CODE
+    asm volatile("" : "+s"(a0), "+s"(a1), "+s"(a2));
+#endif
+    return i == 0 ? a0 : (i == 1 ? a1 : a2);
+}
+PVE_HD double sel4(const PVE_AS4 double (&a)[4], int i)
+{
+    double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+#if PVE_DEVICE_CODE
+    asm volatile("" : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3));
+#endif
+    return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
+}
+
 PVE_HD void get_xy(const PVE_AS4 Const &c, double p, int lane, double &X, double &Y)
 {   // straight-line (select-based) so that the two evaluations per vehicle pair overlap in the pipeline
     const double cw = c.cw;
     const int m = lane % 3;
-    const double Lb = c.inbox[m == 2 ? 2 : 0];
+    const double Lb = sel2(c.inbox[0], c.inbox[2], m == 2);
     const bool before = p > Lb, inside = !before && p > 0;
     const bool arc = (m != 1) && inside;
     double sn, cs;
@@ -316,7 +344,7 @@ PVE_HD void get_xy(const PVE_AS4 Const &c, double p, int lane, double &X, double
     double x = before ? bx : (inside ? ax : ex);
     double y = before ? by : (inside ? ay : ey);
     if (m == 1) { x = p - 6 * cw; y = 3 * cw; }                         // straight (ref :1268-1270)
-    const double rc = c.rot_cos[lane / 3], rs = c.rot_sin[lane / 3];
+    const double rc = sel4(c.rot_cos, lane / 3), rs = sel4(c.rot_sin, lane / 3);
     X = x * rc - y * rs;
     Y = y * rc + x * rs;
 }
@@ -326,7 +354,7 @@ PVE_HD void get_xy_f32(const PVE_AS4 Const &c, double pd, int lane, float &X, fl
 {
     const float cw = (float)c.cw, p = (float)pd;
     const int m = lane % 3;
-    const float Lb = (float)c.inbox[m == 2 ? 2 : 0];
+    const float Lb = (float)sel2(c.inbox[0], c.inbox[2], m == 2);
     const bool before = p > Lb, inside = !before && p > 0.f;
     float ra = (m != 1 && inside) ? ((Lb - p) / Lb * 1.5707965f) : 0.f;     // 3.141593 / 2
     const bool fold = ra > 0.78539816f;
@@ -340,7 +368,7 @@ PVE_HD void get_xy_f32(const PVE_AS4 Const &c, double pd, int lane, float &X, fl
     float x = before ? (p - Lb + 6.f * cw) : (inside ? ax : ((m == 0) ? -cw : 5.f * cw));
     float y = before ? p0y : (inside ? ay : ((m == 0) ? (-6.f * cw + p) : (6.f * cw - p)));
     if (m == 1) { x = p - 6.f * cw; y = 3.f * cw; }
-    const float rc = (float)c.rot_cos[lane / 3], rs = (float)c.rot_sin[lane / 3];
+    const float rc = (float)sel4(c.rot_cos, lane / 3), rs = (float)sel4(c.rot_sin, lane / 3);
     X = x * rc - y * rs;
     Y = y * rc + x * rs;
 }
@@ -620,37 +648,14 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
     }
 
-    // ============================================================== WALK: predecessor, 6 nearest, reward, hit
-    static PVE_HD void ph_scan(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
+    // Predecessor and the 6 nearest of the vehicle at sorted position s of the list [base, base + n): r.kr / r.kv, pr, pvd.
+    // Shared by the 12-lane WALK and the general-geometry kernel (per-route lists, pve_tick_geo.h).
+    static PVE_HD void walk_window(Sh &sh, int base, int n, int s, double ps, Regs &r, int &pr, double &pvd)
     {
-        r.reward = 0; r.hit = 0; r.hdr = -1;
-#pragma unroll
-        for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
-        const bool ctl = r.alive && r.ctl;
-        const bool head_thread = r.alive && r.j == 0;     // lane non-empty -> its list is rebuilt (ref :234)
-        if (!(ctl || head_thread)) return;
-        const int lane = r.lane;
-        const double ps = r.p;
-        const int base = sh.loff[lane], n = sh.loff[lane + 1] - base;
-        if (head_thread) {                                // persisted for next tick's step (ref :1517)
-            const int e0 = Sh::DIRECT ? 0 : sh.s_idx[base];
-            const double hvd = Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base : 0] : sh.u_vd[n > 0 ? e0 : 0];
-            if (n > 0 && hvd < INFINITY) {
-                const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[e0];
-                lds_or(&sh.hd.head_valid, 1 << lane);
-                int hl = sh.lane_of[hr];
-                sh.hd.head_lane[lane] = hl;
-                sh.hd.head_j[lane] = hr - sh.hd.lane_start[hl];
-            } else {
-                lds_and(&sh.hd.head_valid, ~(1 << lane));
-            }
-        }
-        if (!ctl) return;
-        const int s = sh.mypos[t];
         const uint16_t *sidx = sh.s_idx + base;      // sorted position -> entry
 #define sv(pos_) (Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base + (pos_) : 0] : sh.u_vd[sidx[pos_]])
 #define ss(pos_) (Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base + (pos_) : 0] : sh.u_slot[sidx[pos_]])
-        int pr = -1; double pvd = 0;
+        pr = -1; pvd = 0;
         if (s > 0) { pr = ss(s - 1); pvd = sv(s - 1); }                             // ref :1353-1354
         // The 6 nearest in the reference's stable |vd - vd_self| sort = the 6 smallest keys (|d|, vd, slot) (ref
         // :1383-1397).  Both sides of our own position are already sorted by |d|: left = keys below ours (walking
@@ -748,14 +753,44 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 for (int q = 0; q < NNB; q++) if (q == k) { r.kr[q] = slot; r.kv[q] = vv; }
             }
         }
+#undef sv
+#undef ss
+    }
+
+    // ============================================================== WALK: predecessor, 6 nearest, reward, hit
+    static PVE_HD void ph_scan(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
+    {
+        r.reward = 0; r.hit = 0; r.hdr = -1;
+#pragma unroll
+        for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
+        const bool ctl = r.alive && r.ctl;
+        const bool head_thread = r.alive && r.j == 0;     // lane non-empty -> its list is rebuilt (ref :234)
+        if (!(ctl || head_thread)) return;
+        const int lane = r.lane;
+        const double ps = r.p;
+        const int base = sh.loff[lane], n = sh.loff[lane + 1] - base;
+        if (head_thread) {                                // persisted for next tick's step (ref :1517)
+            const int e0 = Sh::DIRECT ? 0 : sh.s_idx[base];
+            const double hvd = Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base : 0] : sh.u_vd[n > 0 ? e0 : 0];
+            if (n > 0 && hvd < INFINITY) {
+                const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[e0];
+                lds_or(&sh.hd.head_valid, 1 << lane);
+                int hl = sh.lane_of[hr];
+                sh.hd.head_lane[lane] = hl;
+                sh.hd.head_j[lane] = hr - sh.hd.lane_start[hl];
+            } else {
+                lds_and(&sh.hd.head_valid, ~(1 << lane));
+            }
+        }
+        if (!ctl) return;
+        int pr; double pvd;
+        walk_window(sh, base, n, sh.mypos[t], ps, r, pr, pvd);
         // ref :1348-1354
         r.hdr = pr;
         r.vir_dis = (pr >= 0) ? (ps - pvd) : 100.0;
         sh.hdr[t] = (int16_t)pr;
         sh.virdis[t] = r.vir_dis;
         r.count += 1;                                                             // ref :292
-#undef sv
-#undef ss
     }
 
     // ============================================================== REWARD: reward terms + XY collision test
@@ -815,7 +850,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_effects(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
 #if !PVE_DEVICE_CODE
-        if (t == 0) { sh.red_reward[0] = 0; sh.red_jerk[0] = 0; }   // emulator: block_sum accumulates; storage was tabA
+        if (t == 0) { sh.red_reward[0] = 0; sh.red_jerk[0] = 0; }   // emulator: block_sum accumulates; storage was segoff
 #endif
         r.del = 0; r.fin = 0; r.coll_seen = 0; r.coll_fin = 0;
         if (r.alive) {
@@ -1010,7 +1045,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             if (RES) { fc.sp_slot = slot; fc.sp_id = nid; fc.sp_vnum = nvnum; }
             else {
                 Regs nv;
-                nv.p = c.spawn_p[t % 3]; nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
+                nv.p = sel3(c.spawn_p, t % 3); nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
                 nv.vir_dis = 100; nv.closer_p = 150;
                 nv.id = nid;
                 nv.seq = sh.hd.veh_rec[t];
@@ -1171,7 +1206,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
         if (fc.sp_slot >= 0) {                           // t < NL: the vehicle lane t spawns (ref :395-433)
             const int s = fc.sp_slot;
-            sh.template stf<Sh::SF_P>()[s] = c.spawn_p[t % 3]; sh.template stf<Sh::SF_V>()[s] = c.v0;
+            sh.template stf<Sh::SF_P>()[s] = sel3(c.spawn_p, t % 3); sh.template stf<Sh::SF_V>()[s] = c.v0;
             sh.template stf<Sh::SF_A>()[s] = 0; sh.template stf<Sh::SF_JERK>()[s] = 0; sh.template stf<Sh::SF_JERK_SUM>()[s] = 0;
             sh.template stf<Sh::SF_VIR_DIS>()[s] = 100; sh.template stf<Sh::SF_CLOSER_P>()[s] = 150;
             sh.template sti<I_ID>()[s] = fc.sp_id; sh.template sti<I_SEQ>()[s] = sh.hd.veh_rec[t];
@@ -1221,7 +1256,6 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0;
             sh.hd.current_time = sh.hd.current_time + c.deltaT;                   // ref :223 (repeated +=, not tick*dt)
         }
-        if (t < 8) sh.tabA[t >> 2][t & 3] = c.vdA[t >> 2][t & 3];                // its storage held the reward / jerk sums
     }
     // FLUSH (after the last tick's barrier B): staging area + header -> HBM
     static PVE_HD void ph_flush(const PVE_AS4 Params &P, int env, int t, Sh &sh)

@@ -27,20 +27,30 @@ template <int CAP> struct SharedGeo {
     static constexpr int NW = CAP / 64;
     EnvHeader hd;
     double p[CAP], v[CAP], a[CAP];
-    double p1[CAP], v1[CAP];
     double virdis[CAP];
     double red_reward[NW], red_jerk[NW];
-    // Virtual-lane lists (ref :240-270), unsorted: list d (one per route) = [lbase[d], lbase[d] + fill[d]) of the entry
-    // pool; an entry = (build-time virtual distance, slot).  Every controlled vehicle files itself into the lists it is a
-    // member of (FILL), every ego then reads only its own list (SCAN) instead of testing membership of every controlled
-    // vehicle of the intersection.  Segment sizes are upper bounds from the per-route counts (rc); if they do not fit
-    // the pool (pool_ok = 0, dense 8-lane traffic) SCAN falls back to the membership scan, with identical results.
+    // Virtual-lane lists (ref :240-270), one per route: list d = [loff[d], loff[d + 1]) of the entry pool; an entry =
+    // (build-time virtual distance, slot).  COUNT: every controlled vehicle tests its membership in the lists its route
+    // can appear in and counts; FILL: it files itself into them; RANK: counting sort of every list by (distance, slot) =
+    // the reference's stable sort (ref :271); WALK: predecessor and 6 nearest from the window around the own position
+    // (the 12-lane kernel's walk_window).  Every ego reads only its own list instead of testing every controlled
+    // vehicle of the intersection.  If the lists do not fit the pool (pool_ok = 0: very dense traffic) WALK falls back
+    // to the membership scan, with identical results.
     static constexpr int PE = 4 * CAP;
-    double u_vd[PE];                 // entry pool; LOCK2 re-uses [0, CAP) as the dead-lock scratch (records by rank)
-    uint8_t u_slot[PE];
-    int rc[ND], fill[ND], pool_ok;   // controlled vehicles per route, entries filed per list
-    int16_t lbase[ND + 1];
-    alignas(4) uint16_t lroutes[ND]; // bit d: route r can be a member of list d (transpose of mroutes)
+    static constexpr bool DIRECT = false;   // (walk_window: sorted lists are index arrays into the entries)
+    union {                                 // p1 / v1 die at the barrier after S3, the lists are born after it
+        struct { double p1[CAP], v1[CAP]; };
+        double u_vd[PE];                    // entry pool; LOCK2 re-uses [0, CAP) as the dead-lock scratch (records by rank)
+    };
+    double s_vd[1];
+    uint16_t s_idx[PE];
+    uint8_t u_slot[PE], u_list[PE], s_slot[1];
+    int16_t mypos[CAP];                     // sorted position of every controlled vehicle's own entry in its route's list
+    int cntd[ND], fill[ND], pool_ok;        // members per list (COUNT), entries filed so far (FILL)
+    int16_t loff[ND + 1];
+    alignas(4) uint16_t lroutes[ND];        // bit d: route r can be a member of list d (transpose of mroutes)
+    alignas(4) int8_t dir_lane[ND], dir_index[ND];   // copies of GeoConst's (dynamic indexing of kernel arguments = global loads)
+    alignas(4) int8_t dty[ND];              // d % tmod: row of the get_virtual_distance table of list d
     double vdt[4][MAXK][4];          // get_virtual_distance table (GeoConst::vd)
     double inbox[4];
     int cnt[CAP];
@@ -62,7 +72,7 @@ PVE_HD void geo_xy(const PVE_AS4 GeoConst &g, double p, int lane, int m, double 
     if (g.lane_num == 12) { get_xy(g.base, p, lane, X, Y); return; }
     const double cw = g.base.cw, H = g.H;
     const double yo = (g.lane_num == 8 && (lane & 1)) ? 3 * cw : cw;
-    const double Lb = (m == 2) ? g.base.inbox[2] : g.base.inbox[0];
+    const double Lb = sel2(g.base.inbox[0], g.base.inbox[2], m == 2);
     const double rl = (double)g.RL;
     const bool before = p > Lb, inside = !before && p > 0;
     double sn, cs;
@@ -78,7 +88,7 @@ PVE_HD void geo_xy(const PVE_AS4 GeoConst &g, double p, int lane, int m, double 
         x = before ? -(p - Lb + H) : (inside ? -(H - dx) : -yo);
         y = before ? -yo : (inside ? -(H - dy) : -(-1 * p + H));
     }
-    const int q = g.turn[lane];
+    const int q = (int)((g.turn_pk >> (4 * lane)) & 15ull);
     X = (q == 0) ? x : (q == 1) ? -y : (q == 2) ? -x : y;
     Y = (q == 0) ? y : (q == 1) ? x : (q == 2) ? -y : -x;
 }
@@ -89,7 +99,7 @@ PVE_HD void geo_xy_f32(const PVE_AS4 GeoConst &g, double pd, int lane, int m, fl
     if (g.lane_num == 12) { get_xy_f32(g.base, pd, lane, X, Y); return; }
     const float cw = (float)g.base.cw, H = (float)g.H, p = (float)pd;
     const float yo = (g.lane_num == 8 && (lane & 1)) ? 3.f * cw : cw;
-    const float Lb = (float)((m == 2) ? g.base.inbox[2] : g.base.inbox[0]);
+    const float Lb = (float)sel2(g.base.inbox[0], g.base.inbox[2], m == 2);
     const float rl = (float)g.RL;
     const bool before = p > Lb, inside = !before && p > 0.f;
     const float ra = (inside && m != 1) ? ((m == 0) ? p / (rl * cw) : p / cw) : 0.f;
@@ -109,7 +119,7 @@ PVE_HD void geo_xy_f32(const PVE_AS4 GeoConst &g, double pd, int lane, int m, fl
         x = before ? -(p - Lb + H) : (inside ? -(H - dx) : -yo);
         y = before ? -yo : (inside ? -(H - dy) : -(-1.f * p + H));
     }
-    const int q = g.turn[lane];
+    const int q = (int)((g.turn_pk >> (4 * lane)) & 15ull);
     X = (q == 0) ? x : (q == 1) ? -y : (q == 2) ? -x : y;
     Y = (q == 0) ? y : (q == 1) ? x : (q == 2) ? -y : -x;
 }
@@ -148,9 +158,12 @@ template <int CAP> struct TickGeo {
             int *dst = (int *)&sh.pos[0][0];
             for (int w = t; w < ND * ND / 4; w += CAP) dst[w] = src[w];
         }
-        if (t < ND / 4) ((int *)sh.opp)[t] = ((const int *)g.opp)[t];
+        if (t < ND / 4) {
+            ((int *)sh.opp)[t] = ((const int *)g.opp)[t];
+            ((int *)sh.dir_lane)[t] = ((const int *)g.dir_lane)[t]; ((int *)sh.dir_index)[t] = ((const int *)g.dir_index)[t];
+        }
         if (t < ND / 2) { ((int *)sh.mroutes)[t] = ((const int *)g.mroutes)[t]; ((int *)sh.lroutes)[t] = ((const int *)g.lroutes)[t]; }
-        if (t < ND) { sh.rc[t] = 0; sh.fill[t] = 0; }
+        if (t < ND) { sh.cntd[t] = 0; sh.fill[t] = 0; sh.dty[t] = (int8_t)(t % g.tmod); }
     }
 
     // ============================================================== S1..S3: step() -- the 12-lane phases; the head
@@ -161,7 +174,12 @@ template <int CAP> struct TickGeo {
         r.intent = 0; r.route = 0;
         if (r.alive) {
             r.intent = (g.lane_num == 12) ? (r.lane % 3) : ((r.meta >> M_INT_SHIFT) & M_INT_MASK);
-            r.route = g.direction[r.lane][r.intent];
+            unsigned long long d0 = g.dir_pk[0], d1 = g.dir_pk[1], d2 = g.dir_pk[2];
+#if PVE_DEVICE_CODE
+            asm volatile("" : "+s"(d0), "+s"(d1), "+s"(d2));      // scalar loads + select (not one load from a selected address)
+#endif
+            const unsigned long long dpk = (r.intent == 0) ? d0 : ((r.intent == 1) ? d1 : d2);
+            r.route = (int)((dpk >> (5 * r.lane)) & 31ull) - 1;                     // direction[lane][intention]
             sh.route_of[t] = (uint8_t)r.route;
             sh.intent_of[t] = (uint8_t)r.intent;
         }
@@ -173,7 +191,6 @@ template <int CAP> struct TickGeo {
     static PVE_HD void ph_order(int t, Sh &sh, Regs &r)
     {
         r.ord = t;
-        if (r.alive && r.ctl) lds_add(&sh.rc[r.route], 1);
         if (r.alive) {
             const int ls = sh.hd.lane_start[r.lane], le = sh.hd.lane_start[r.lane + 1];
             int o = ls;
@@ -186,38 +203,83 @@ template <int CAP> struct TickGeo {
             sh.slot_at[o] = (int16_t)t;
         }
     }
-    static PVE_HD void ph_order2(int t, Sh &sh, bool force_scan)
+    static PVE_HD void ph_order2(int t, Sh &sh)
     {
         const int N = sh.hd.n_alive;
         vote<NW>(sh.m_ctl_ord, t, t < N && mask_test(sh.m_ctl, sh.slot_at[t < N ? t : 0]));
-        // list d can hold at most the controlled vehicles of the routes in mroutes[d]: segment offsets by a wave scan
-        int cap = 0;
-        if (t < ND) {
-            const unsigned mr = sh.mroutes[t];
-#pragma unroll
-            for (int rt = 0; rt < ND; rt++) cap += ((mr >> rt) & 1u) ? sh.rc[rt] : 0;
-        }
-#if PVE_DEVICE_CODE
-        const int incl = wave_incl_scan(t, cap, nullptr);            // lists 0 .. 15 live in the first 16 lanes of wave 0
-#else
-        const int incl = wave_incl_scan(t, cap, &sh.emu_scan);
-#endif
-        if (t < ND) {
-            sh.lbase[t + 1] = (int16_t)(incl > 32767 ? 32767 : incl);
-            if (t == 0) sh.lbase[0] = 0;
-            if (t == ND - 1) sh.pool_ok = (!force_scan && incl <= Sh::PE) ? 1 : 0;
-        }
     }
-    // FILL: every controlled vehicle files (virtual distance at list build, slot) into each list it is a member of
-    static PVE_HD void ph_fill(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
+    // COUNT (positions are final: after S3): membership of every controlled vehicle in the lists its route can appear in
+    static PVE_HD void ph_count(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
     {
-        if (!sh.pool_ok || !(r.alive && r.ctl)) return;
+        r.mmask = 0;
+        if (!(r.alive && r.ctl)) return;
         for (unsigned ls = sh.lroutes[r.route]; ls; ls &= ls - 1) {
             const int d = __builtin_ctz(ls);
             double vo;
-            if (!member(g, sh, d, g.dir_lane[d], g.dir_index[d], t, vo)) continue;
-            const int e = sh.lbase[d] + lds_claim(&sh.fill[d], 1);
-            sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)t;
+            if (!member_self(sh, d, r, vo)) continue;
+            r.mmask |= 1 << d;
+            lds_add(&sh.cntd[d], 1);
+        }
+    }
+    // FILL: segment offsets (every thread sums the 16 counts itself: no scan phase), then every controlled vehicle files
+    // (virtual distance at list build, slot) into its lists; the order inside a segment is arbitrary (RANK sorts)
+    static PVE_HD void ph_fill(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r, bool force_scan)
+    {
+        int total = 0;
+#pragma unroll
+        for (int d = 0; d < ND; d++) total += sh.cntd[d];
+        const bool ok = !force_scan && total <= Sh::PE;
+        if (t == 0) {
+            sh.pool_ok = ok ? 1 : 0;
+            int run = 0;
+            for (int d = 0; d < ND; d++) { sh.loff[d] = (int16_t)run; run += ok ? sh.cntd[d] : 0; }
+            sh.loff[ND] = (int16_t)run;
+        }
+        if (!ok || !r.mmask) return;
+        int run = 0;
+        for (int d = 0; d < g.dir_num; d++) {
+            const int c = sh.cntd[d];
+            if ((r.mmask >> d) & 1) {
+                double vo = 0;
+                member_self(sh, d, r, vo);
+                const int e = run + lds_claim(&sh.fill[d], 1);
+                sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)d;
+            }
+            run += c;
+        }
+    }
+    // RANK: counting sort of every list by (vd, slot) = the reference's stable sort by vd of the list it builds in
+    // (lane, intention, j) order (ref :271); entry-parallel, 8 independent LDS reads per round (cf. Tick::ph_rank)
+    static PVE_HD void ph_rank(int t, Sh &sh)
+    {
+        if (!sh.pool_ok) return;
+        const int M = sh.loff[ND];
+        for (int e = t; e < M; e += CAP) {
+            const int d = sh.u_list[e];
+            const double vd = sh.u_vd[e];
+            const int slot = sh.u_slot[e];
+            const int lo = sh.loff[d], hi = sh.loff[d + 1];
+            int pos = 0, eq = 0;
+            int f = lo;
+            for (; f + 8 <= hi; f += 8) {
+                double w[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) w[k] = sh.u_vd[f + k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { pos += (w[k] < vd) ? 1 : 0; eq += (w[k] == vd) ? 1 : 0; }
+            }
+            if (f < hi) {                                 // tail (< 8 entries): one more round of independent reads
+                const int n = hi - f;
+                double w[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) w[k] = sh.u_vd[f + (k < n ? k : 0)];
+#pragma unroll
+                for (int k = 0; k < 7; k++) { pos += (k < n) & (w[k] < vd); eq += (k < n) & (w[k] == vd); }
+            }
+            if (eq > 1)                                   // exact vd ties (rare): lower slot first
+                for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
+            sh.s_idx[lo + pos] = (uint16_t)e;
+            if (d == sh.route_of[slot]) sh.mypos[slot] = (int16_t)pos;          // the vehicle's own entry (vd = p)
         }
     }
 
@@ -235,8 +297,27 @@ template <int CAP> struct TickGeo {
         }
         const int k = sh.pos[d][rx];                                                   // ref :258
         if (k < 0) return false;
-        const double *e = sh.vdt[d % g.tmod][k];
+        const double *e = sh.vdt[sh.dty[d]][k];
         const double delta = (px - e[0]) + e[1];                                       // ref :453-660 / :733-803
+        if (!(delta > 0)) return false;
+        vo = (delta + e[2]) - e[3];
+        return true;
+    }
+
+    // the same test for the thread's OWN vehicle (COUNT / FILL): its lane, route, intention and position are in registers,
+    // so one evaluation is two levels of LDS reads instead of five
+    static PVE_HD bool member_self(const Sh &sh, int d, const Regs &r, double &vo)
+    {
+        const int li = sh.dir_lane[d], m = sh.dir_index[d], k = sh.pos[d][r.route], ty = sh.dty[d];
+        if (r.lane == li) {
+            if (r.route == d) { vo = r.p; return true; }                                // ref :246-249
+            const double q = r.p - sh.inbox[r.intent];                                  // ref :251-252
+            if (q > 0) { vo = q + sh.inbox[m]; return true; }                           // ref :253-257
+            return false;
+        }
+        if (k < 0) return false;                                                        // ref :258
+        const double *e = sh.vdt[ty][k];
+        const double delta = (r.p - e[0]) + e[1];                                       // ref :453-660 / :733-803
         if (!(delta > 0)) return false;
         vo = (delta + e[2]) - e[3];
         return true;
@@ -276,15 +357,11 @@ template <int CAP> struct TickGeo {
         //     when their physical lane holds a vehicle (ref :234), otherwise the old head stays (stale by design)
         const bool lists = sh.pool_ok != 0;
         if (t >= CAP - ND && t - (CAP - ND) < g.dir_num) {     // the last 16 threads: the (mostly empty) tail of the last wave
-            const int d = t - (CAP - ND), li = g.dir_lane[d], m = g.dir_index[d];
+            const int d = t - (CAP - ND), li = sh.dir_lane[d], m = sh.dir_index[d];
             if (sh.hd.lane_start[li + 1] > sh.hd.lane_start[li]) {
                 double best = INFINITY; int bs = -1;
                 if (lists) {
-                    const int e1 = sh.lbase[d] + sh.fill[d];
-                    for (int e = sh.lbase[d]; e < e1; e++) {
-                        const double vo = sh.u_vd[e]; const int x = sh.u_slot[e];
-                        if (vo < best || (vo == best && x < bs)) { best = vo; bs = x; }           // ties: lower slot
-                    }
+                    if (sh.loff[d + 1] > sh.loff[d]) bs = sh.u_slot[sh.s_idx[sh.loff[d]]];       // sorted: the first entry
                 } else {
                     for (int w = 0; w < NW; w++)
                         for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
@@ -352,9 +429,22 @@ template <int CAP> struct TickGeo {
                 }
             }
         };
+        if (lists && !fix) {
+            // sorted list, no entry is ever re-written: the 12-lane kernel's window walk (ref :1340-1405)
+            int pr; double pvd;
+            Base::walk_window(sh, sh.loff[d], sh.loff[d + 1] - sh.loff[d], sh.mypos[t], me, r, pr, pvd);
+            r.hdr = pr;                                                                 // ref :1348-1354
+            r.vir_dis = (pr >= 0) ? (me - pvd) : 100.0;
+            sh.hdr[t] = (int16_t)pr;
+            sh.virdis[t] = r.vir_dis;
+            r.count += 1;                                                               // ref :292
+            return;
+        }
         if (lists) {
-            const int e1 = sh.lbase[d] + sh.fill[d];
-            for (int e = sh.lbase[d]; e < e1; e++) {
+            // 4-lane left-turn routes: the entries of the opposing left-turn route are re-written ego by ego (ref
+            // :1301-1319), so these egos still look at every member of their list
+            const int e1 = sh.loff[d + 1];
+            for (int e = sh.loff[d]; e < e1; e++) {
                 const int x = sh.u_slot[e];
                 if (x != t) consider(x, sh.u_vd[e]);
             }
@@ -530,7 +620,7 @@ template <int CAP> struct TickGeo {
                 intention = (t & 1) ? (ch ? 2 : 1) : (ch ? 1 : 0);                     // ref :125-134
             } else intention = t % 3;                                                  // ref :393-394
             Regs nv;
-            nv.p = c.spawn_p[intention]; nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
+            nv.p = sel3(c.spawn_p, intention); nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
             nv.vir_dis = 100; nv.closer_p = 150;
             nv.id = sh.hd.id_seq + nth;
             nv.seq = sh.hd.veh_rec[t];

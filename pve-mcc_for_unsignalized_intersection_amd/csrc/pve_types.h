@@ -93,6 +93,9 @@ struct GeoConst {
     int8_t opp[ND];                // lane2lane[d][1] (4-lane fix-up, ref :1303)
     uint16_t mroutes[ND];          // bit r: route r can be a member of list d (same physical lane, or in lane2lane[d])
     uint16_t lroutes[ND];          // bit d: route r can be filed into list d (transpose of mroutes)
+    // the two tables the kernel indexes per vehicle, packed into scalars (a dynamic index into the kernel arguments
+    // is a global load): turn[lane] in 4-bit fields, direction[lane][m] + 1 in 5-bit fields of dir_pk[m]
+    unsigned long long turn_pk, dir_pk[3];
 };
 
 struct Outputs {        // mirrors pve_outputs (include/pve_env.h)
