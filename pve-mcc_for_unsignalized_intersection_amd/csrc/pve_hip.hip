@@ -215,7 +215,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
 // General-geometry tick (lane_num 4 / 8): same workgroup-per-intersection structure, phases of
 // pve_tick_geo.h.  Correctness-first (per-vehicle scans instead of sorted lists).
-template <int CAP>
+template <int CAP, bool PROF = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tick_geo(const GeoConst g_arg, const Params P_arg)
 {
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -228,50 +228,54 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     typedef TickGeo<CAP> T;
     typedef Tick<CAP, SharedGeo<CAP>> B;
     unsigned long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev_ = P.phase_cycles ? wall_clock64() : 0ull;
+    unsigned long long tprev_ = PROF ? wall_clock64() : 0ull;
 #undef PVE_PHASE_MARK
 #define PVE_PHASE_MARK(idx)                                                              \
-    if (P.phase_cycles) {                                                                \
+    if (PROF) {                                                                          \
         unsigned long long now_ = wall_clock64();                                        \
         pc_[idx] = now_ - tprev_;                                                        \
         tprev_ = now_;                                                                   \
     }
     T::ph_load(g, P, env, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(0)
     T::ph_step1(g, P, env, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(1)
     B::ph_step2(g.base, t, sh, r);
     T::ph_order(t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(2)
     B::ph_step3(g.base, t, sh, r);
     B::ph_step3_publish(t, sh, r);
     T::ph_order2(t, sh);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(3)
-    T::ph_count(g, t, sh, r);
-    __syncthreads();
-    T::ph_fill(g, t, sh, r, P.geo_scan != 0);
-    __syncthreads();
+    T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
+    lds_barrier();
+    T::ph_pairs_exact(t, sh, P.geo_scan != 0);
+    lds_barrier();
+    T::ph_pairs_apply(t, sh);
+    lds_barrier();
+    T::ph_pairs_fill(g, t, sh);
+    lds_barrier();
     PVE_PHASE_MARK(4)
     T::ph_rank(t, sh);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(5)
     T::ph_scan(g, t, sh, r);
     PVE_PHASE_MARK(11)
     T::ph_reward(g, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(6)
     T::ph_effects(g, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(7)
     B::ph_prefetch_arrival(P, env, t, sh, r, g.lane_num);
     B::ph_lock(g.base, t, sh, r);
-    __syncthreads();
+    lds_barrier();
     B::ph_lock2(t, sh, r);
-    __syncthreads();
+    lds_barrier();
     PVE_PHASE_MARK(8)
     T::ph_final(g, P, env, t, sh, r);
     PVE_PHASE_MARK(9)
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         __syncthreads();
         T::ph_state(P, env, t, sh, r);
     }
-    if (P.phase_cycles && (t & 63) == 0) {
+    if (PROF && P.phase_cycles && (t & 63) == 0) {
         unsigned long long *row = P.phase_cycles + ((size_t)env * (CAP / 64) + (t >> 6)) * 16;
 #pragma unroll
         for (int k = 0; k < 12; k++) row[k] += pc_[k];
@@ -417,8 +421,11 @@ struct Backend {
     static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)
     {
         hipStream_t s = (hipStream_t)stream;
-        if (cap == 64) hipLaunchKernelGGL(k_tick_geo<64>, dim3(P.n_envs), dim3(64), 0, s, g, P);
-        else hipLaunchKernelGGL(k_tick_geo<128>, dim3(P.n_envs), dim3(128), 0, s, g, P);
+        if (P.phase_cycles) {                                        // diagnostics build (pve_debug_phase_cycles)
+            if (cap == 64) hipLaunchKernelGGL((k_tick_geo<64, true>), dim3(P.n_envs), dim3(64), 0, s, g, P);
+            else hipLaunchKernelGGL((k_tick_geo<128, true>), dim3(P.n_envs), dim3(128), 0, s, g, P);
+        } else if (cap == 64) hipLaunchKernelGGL((k_tick_geo<64, false>), dim3(P.n_envs), dim3(64), 0, s, g, P);
+        else hipLaunchKernelGGL((k_tick_geo<128, false>), dim3(P.n_envs), dim3(128), 0, s, g, P);
         return check_launch(err);
     }
     static int launch_reset_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)

@@ -82,9 +82,9 @@ inline GeoConst make_geo_const(const pve_config &cfg)
     g.lane_num = LN;
     memset(g.l2l, -1, sizeof(g.l2l));
     memset(g.direction, -1, sizeof(g.direction));
-    memset(g.dir_lane, 0, sizeof(g.dir_lane));
+    memset(g.tab.dir_lane, 0, sizeof(g.tab.dir_lane));
     auto set = [&](int ty, int k, double A, double B, double C, double C2) {
-        g.vd[ty][k][0] = A; g.vd[ty][k][1] = B; g.vd[ty][k][2] = C; g.vd[ty][k][3] = C2;
+        g.tab.vd[ty][k][0] = A; g.tab.vd[ty][k][1] = B; g.tab.vd[ty][k][2] = C; g.tab.vd[ty][k][3] = C2;
     };
     if (LN == 4) {
         g.dir_num = 12; g.tmod = 3; g.RL = 3; g.H = 2 * cw;
@@ -163,23 +163,32 @@ inline GeoConst make_geo_const(const pve_config &cfg)
     c.exit_p = -dc + (double)((LN + 1) / 2) * cw;                                // ref :341-342
     for (int i = 0; i < LN; i++)
         for (int m = 0; m < 3; m++)
-            if (g.direction[i][m] >= 0) { g.dir_lane[g.direction[i][m]] = (int8_t)i; g.dir_index[g.direction[i][m]] = (int8_t)m; }
+            if (g.direction[i][m] >= 0) { g.tab.dir_lane[g.direction[i][m]] = (int8_t)i; g.tab.dir_index[g.direction[i][m]] = (int8_t)m; }
     // membership tables of the virtual-lane lists (ref :240-270): which routes can appear in list d, and where
-    memset(g.pos, -1, sizeof(g.pos));
-    memset(g.mroutes, 0, sizeof(g.mroutes));
-    memset(g.lroutes, 0, sizeof(g.lroutes));
+    memset(g.tab.pos, -1, sizeof(g.tab.pos));
+    memset(g.tab.mroutes, 0, sizeof(g.tab.mroutes));
+    memset(g.tab.lroutes, 0, sizeof(g.tab.lroutes));
     for (int d = 0; d < ND; d++) {
-        g.opp[d] = g.l2l[d][1];
+        g.tab.opp[d] = g.l2l[d][1];
         if (d >= g.dir_num) continue;
-        for (int q = 0; q < MAXK; q++) if (g.l2l[d][q] >= 0) g.pos[d][g.l2l[d][q]] = (int8_t)q;
+        for (int q = 0; q < MAXK; q++) if (g.l2l[d][q] >= 0) g.tab.pos[d][g.l2l[d][q]] = (int8_t)q;
         unsigned mr = 0;
-        const int li = g.dir_lane[d];
+        const int li = g.tab.dir_lane[d];
         for (int q = 0; q < 3; q++) if (g.direction[li][q] >= 0) mr |= 1u << g.direction[li][q];
         for (int q = 0; q < MAXK; q++) if (g.l2l[d][q] >= 0) mr |= 1u << g.l2l[d][q];
-        g.mroutes[d] = (uint16_t)mr;
+        g.tab.mroutes[d] = (uint16_t)mr;
     }
     for (int d = 0; d < g.dir_num; d++)
-        for (int rt = 0; rt < ND; rt++) if ((g.mroutes[d] >> rt) & 1u) g.lroutes[rt] |= (uint16_t)(1u << d);
+        for (int rt = 0; rt < ND; rt++) if ((g.tab.mroutes[d] >> rt) & 1u) g.tab.lroutes[rt] |= (uint16_t)(1u << d);
+    memset(g.tab.lst, 0, sizeof(g.tab.lst));
+    for (int rt = 0; rt < ND; rt++) {
+        int n = 0;
+        for (int d = 0; d < g.dir_num; d++) if ((g.tab.lroutes[rt] >> d) & 1u) g.tab.lst[rt][n++] = (int8_t)d;
+        g.tab.nl[rt] = (int8_t)n;
+        g.tab.ninv[rt] = (uint16_t)(n ? (32768 + n - 1) / n : 0);
+    }
+    for (int d = 0; d < ND; d++) g.tab.dty[d] = (int8_t)(d % g.tmod);
+    for (int m = 0; m < 3; m++) g.tab.inbox[m] = c.inbox[m];
     g.turn_pk = 0; g.dir_pk[0] = g.dir_pk[1] = g.dir_pk[2] = 0;
     for (int i = 0; i < NL; i++) {
         g.turn_pk |= (unsigned long long)(g.turn[i] & 15) << (4 * i);

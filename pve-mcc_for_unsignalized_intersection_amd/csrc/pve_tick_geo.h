@@ -29,13 +29,14 @@ template <int CAP> struct SharedGeo {
     double p[CAP], v[CAP], a[CAP];
     double virdis[CAP];
     double red_reward[NW], red_jerk[NW];
-    // Virtual-lane lists (ref :240-270), one per route: list d = [loff[d], loff[d + 1]) of the entry pool; an entry =
-    // (build-time virtual distance, slot).  COUNT: every controlled vehicle tests its membership in the lists its route
-    // can appear in and counts; FILL: it files itself into them; RANK: counting sort of every list by (distance, slot) =
-    // the reference's stable sort (ref :271); WALK: predecessor and 6 nearest from the window around the own position
-    // (the 12-lane kernel's walk_window).  Every ego reads only its own list instead of testing every controlled
-    // vehicle of the intersection.  If the lists do not fit the pool (pool_ok = 0: very dense traffic) WALK falls back
-    // to the membership scan, with identical results.
+    // Virtual-lane lists (ref :240-270), one per route: list d = [lbase[d], lbase[d] + fill[d]) of the entry pool; an
+    // entry = (build-time virtual distance, slot).  PAIRS: the (controlled vehicle, list its route can appear in)
+    // pairs of the intersection are dealt evenly to the threads; a pair that is a member claims the next entry of its
+    // list; RANK: counting sort of every list by (distance, slot) = the reference's stable sort (ref :271); WALK:
+    // predecessor and 6 nearest from the window around the own position (the 12-lane kernel's walk_window).  Every ego
+    // reads only its own list instead of testing every controlled vehicle of the intersection.  Segment capacities are
+    // upper bounds from the per-route counts; if they do not fit the pool (pool_ok = 0: very dense traffic) WALK falls
+    // back to the membership scan, with identical results.
     static constexpr int PE = 4 * CAP;
     static constexpr bool DIRECT = false;   // (walk_window: sorted lists are index arrays into the entries)
     union {                                 // p1 / v1 die at the barrier after S3, the lists are born after it
@@ -46,23 +47,20 @@ template <int CAP> struct SharedGeo {
     uint16_t s_idx[PE];
     uint8_t u_slot[PE], u_list[PE], s_slot[1];
     int16_t mypos[CAP];                     // sorted position of every controlled vehicle's own entry in its route's list
-    int cntd[ND], fill[ND], pool_ok;        // members per list (COUNT), entries filed so far (FILL)
-    int16_t loff[ND + 1];
-    alignas(4) uint16_t lroutes[ND];        // bit d: route r can be a member of list d (transpose of mroutes)
-    alignas(4) int8_t dir_lane[ND], dir_index[ND];   // copies of GeoConst's (dynamic indexing of kernel arguments = global loads)
-    alignas(4) int8_t dty[ND];              // d % tmod: row of the get_virtual_distance table of list d
-    double vdt[4][MAXK][4];          // get_virtual_distance table (GeoConst::vd)
-    double inbox[4];
+    int rc[ND], rfill[ND], fill[ND], cnt2[ND], pool_ok;   // controlled vehicles per route, claimed so far; entries filed per list;
+                                            // exact member counts (only when the upper bounds overflow the pool)
+    int16_t lnew[ND];
+    int16_t lbase[ND + 1];                  // list d owns [lbase[d], lbase[d] + fill[d]) (capacity: the next lbase)
+    int16_t rbase[ND + 1], pbase[ND + 1];   // prefix of rc (route-sorted controlled vehicles) and of rc * nl (pairs)
+    uint8_t ctl_by_route[CAP];
+    alignas(8) GeoTab tab;           // copy of GeoConst::tab
     int cnt[CAP];
-    int acc_passed_steps, acc_collisions, lead_n, emu_scan;
+    int acc_passed_steps, acc_collisions, lead_n, emu_scan, emu_scan2, emu_scan3;
     int16_t hdr[CAP], cyc_off[CAP], ord[CAP], slot_at[CAP];
     uint8_t bb[CAP], rew_ovr[CAP], lane_of[CAP], route_of[CAP], intent_of[CAP], lk_slot[CAP];
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW], m_spawn[NW];
     u64 m_int[3][NW];                // alive slots by intention
     u64 m_ctl_ord[NW];               // "controlled" flags in processing order
-    alignas(4) int8_t pos[ND][ND];   // pos[d][route] = index of route in lane2lane[d], or -1
-    alignas(4) int8_t opp[ND];       // lane2lane[d][1] (4-lane fix-up, ref :1303)
-    alignas(4) uint16_t mroutes[ND]; // bit r: route r can be a member of list d (same lane, or in lane2lane[d])
 };
 
 // XY position (ref :896-1249): every (lane, intention) branch of the reference is one of three canonical paths
@@ -132,6 +130,13 @@ template <int CAP> struct TickGeo {
     // ============================================================== L: load
     static PVE_HD void ph_load(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
+        // the lookup tables first (they are written to LDS, so their loads must be waited for before the first barrier;
+        // everything issued behind them may still be in flight then)
+        {
+            const int *src = (const int *)&g.tab;
+            int *dst = (int *)&sh.tab;
+            for (int w = t; w < (int)(sizeof(GeoTab) / 4); w += CAP) dst[w] = src[w];
+        }
         const EnvHeader &gh = P.headers[env];
         {
             const int *src = (const int *)&gh;
@@ -143,27 +148,20 @@ template <int CAP> struct TickGeo {
         const size_t gi = (size_t)env * CAP + t;
         r.alive = t < N;
         r.jerk = 0;
-        r.act = P.actions ? P.actions[gi] : 0.0;
-        r.p = P.f64[F_P][gi]; r.v = P.f64[F_V][gi]; r.a = P.f64[F_A][gi];
-        r.jerk_sum = P.f64[F_JERK_SUM][gi]; r.vir_dis = P.f64[F_VIR_DIS][gi]; r.closer_p = P.f64[F_CLOSER_P][gi];
-        r.id = P.i32[I_ID][gi]; r.seq = P.i32[I_SEQ][gi]; r.vnum = P.i32[I_VNUM][gi];
-        r.step = P.i32[I_STEP][gi]; r.count = P.i32[I_COUNT][gi]; r.meta = P.i32[I_META][gi];
+        r.act = 0;
+        r.p = r.v = r.a = r.jerk_sum = r.vir_dis = r.closer_p = 0;
+        r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
+        if (t < 64 || t < N) {                    // first wave unconditionally (no dependence on n_alive), later waves live slots only
+            if (P.actions) r.act = P.actions[gi];
+            r.p = P.f64[F_P][gi]; r.v = P.f64[F_V][gi]; r.a = P.f64[F_A][gi];
+            r.meta = P.i32[I_META][gi]; r.step = P.i32[I_STEP][gi];
+            r.jerk_sum = P.f64[F_JERK_SUM][gi]; r.vir_dis = P.f64[F_VIR_DIS][gi]; r.closer_p = P.f64[F_CLOSER_P][gi];
+            r.id = P.i32[I_ID][gi]; r.seq = P.i32[I_SEQ][gi]; r.vnum = P.i32[I_VNUM][gi];
+            r.count = P.i32[I_COUNT][gi];
+        }
         sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
         if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
-        for (int w = t; w < 4 * MAXK * 4; w += CAP) (&sh.vdt[0][0][0])[w] = (&g.vd[0][0][0])[w];
-        if (t < 3) sh.inbox[t] = g.base.inbox[t];
-        // membership tables: host-computed (GeoConst), copied word by word
-        {
-            const int *src = (const int *)&g.pos[0][0];
-            int *dst = (int *)&sh.pos[0][0];
-            for (int w = t; w < ND * ND / 4; w += CAP) dst[w] = src[w];
-        }
-        if (t < ND / 4) {
-            ((int *)sh.opp)[t] = ((const int *)g.opp)[t];
-            ((int *)sh.dir_lane)[t] = ((const int *)g.dir_lane)[t]; ((int *)sh.dir_index)[t] = ((const int *)g.dir_index)[t];
-        }
-        if (t < ND / 2) { ((int *)sh.mroutes)[t] = ((const int *)g.mroutes)[t]; ((int *)sh.lroutes)[t] = ((const int *)g.lroutes)[t]; }
-        if (t < ND) { sh.cntd[t] = 0; sh.fill[t] = 0; sh.dty[t] = (int8_t)(t % g.tmod); }
+        if (t < ND) { sh.rc[t] = 0; sh.rfill[t] = 0; sh.fill[t] = 0; sh.cnt2[t] = 0; }
     }
 
     // ============================================================== S1..S3: step() -- the 12-lane phases; the head
@@ -182,6 +180,7 @@ template <int CAP> struct TickGeo {
             r.route = (int)((dpk >> (5 * r.lane)) & 31ull) - 1;                     // direction[lane][intention]
             sh.route_of[t] = (uint8_t)r.route;
             sh.intent_of[t] = (uint8_t)r.intent;
+            if (r.ctl) lds_add(&sh.rc[r.route], 1);
         }
         vote<NW>(sh.m_int[0], t, r.alive && r.intent == 0);
         vote<NW>(sh.m_int[1], t, r.alive && r.intent == 1);
@@ -191,6 +190,36 @@ template <int CAP> struct TickGeo {
     static PVE_HD void ph_order(int t, Sh &sh, Regs &r)
     {
         r.ord = t;
+        // list capacities, route-sorted controlled vehicles and pair counts: three prefix sums over the 16 routes / lists
+        // in the first 16 lanes (rc is complete: barrier behind S1)
+        {
+            int cap = 0, rcv = 0, prs = 0;
+            if (t < ND) {
+                const unsigned mr = sh.tab.mroutes[t];
+#pragma unroll
+                for (int rt = 0; rt < ND; rt++) cap += ((mr >> rt) & 1u) ? sh.rc[rt] : 0;
+                rcv = sh.rc[t];
+                prs = rcv * sh.tab.nl[t];
+            }
+#if PVE_DEVICE_CODE
+            const int i1 = wave_incl_scan(t, cap, nullptr), i2 = wave_incl_scan(t, rcv, nullptr), i3 = wave_incl_scan(t, prs, nullptr);
+#else
+            if (t == 0) sh.emu_scan = sh.emu_scan2 = sh.emu_scan3 = 0;
+            const int i1 = wave_incl_scan(t, cap, &sh.emu_scan), i2 = wave_incl_scan(t, rcv, &sh.emu_scan2),
+                      i3 = wave_incl_scan(t, prs, &sh.emu_scan3);
+#endif
+            if (t < ND) {
+                sh.lbase[t + 1] = (int16_t)(i1 > 32767 ? 32767 : i1); sh.rbase[t + 1] = (int16_t)i2; sh.pbase[t + 1] = (int16_t)i3;
+                if (t == 0) { sh.lbase[0] = 0; sh.rbase[0] = 0; sh.pbase[0] = 0; }
+            }
+        }
+        if (t < Sh::PE / 4) ((int *)sh.u_list)[t] = -1;          // 0xFF = "no entry here" (RANK skips the gaps)
+        if (r.alive && r.ctl) {
+            int rb = 0;
+#pragma unroll
+            for (int rt = 0; rt < ND; rt++) rb += (rt < r.route) ? sh.rc[rt] : 0;
+            sh.ctl_by_route[rb + lds_claim(&sh.rfill[r.route], 1)] = (uint8_t)t;
+        }
         if (r.alive) {
             const int ls = sh.hd.lane_start[r.lane], le = sh.hd.lane_start[r.lane + 1];
             int o = ls;
@@ -208,57 +237,72 @@ template <int CAP> struct TickGeo {
         const int N = sh.hd.n_alive;
         vote<NW>(sh.m_ctl_ord, t, t < N && mask_test(sh.m_ctl, sh.slot_at[t < N ? t : 0]));
     }
-    // COUNT (positions are final: after S3): membership of every controlled vehicle in the lists its route can appear in
-    static PVE_HD void ph_count(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
+    // PAIRS (positions are final: after S3): pair q = (route r, its i-th controlled vehicle, the k-th list the route can
+    // appear in), routes in order: every thread takes pairs q = t, t + CAP, ... -- the same amount of work for everybody,
+    // whatever the mix of routes in the wave.  COUNT = false: a member claims the next entry of its list.  COUNT = true
+    // (only when the capacity upper bounds overflow the pool): members are counted per list, ph_pairs_exact then packs
+    // the segments to their exact sizes before the fill pass.
+    template <bool COUNT>
+    static PVE_HD void pairs_loop(const PVE_AS4 GeoConst &g, int t, Sh &sh)
     {
-        r.mmask = 0;
-        if (!(r.alive && r.ctl)) return;
-        for (unsigned ls = sh.lroutes[r.route]; ls; ls &= ls - 1) {
-            const int d = __builtin_ctz(ls);
+        const int total = sh.pbase[ND];
+        for (int q = t; q < total; q += CAP) {
+            int rt = 0;
+#pragma unroll
+            for (int k = 1; k < ND; k++) rt += (q >= sh.pbase[k]) ? 1 : 0;
+            const int off = q - sh.pbase[rt], n = sh.tab.nl[rt];
+            const int i = (off * (int)sh.tab.ninv[rt]) >> 15, k = off - i * n;          // off / n, off % n (exact: off < 2048, n <= 10)
+            const int x = sh.ctl_by_route[sh.rbase[rt] + i], d = sh.tab.lst[rt][k];
             double vo;
-            if (!member_self(sh, d, r, vo)) continue;
-            r.mmask |= 1 << d;
-            lds_add(&sh.cntd[d], 1);
+            if (!member(g, sh, d, sh.tab.dir_lane[d], sh.tab.dir_index[d], x, vo)) continue;
+            if (COUNT) { lds_add(&sh.cnt2[d], 1); continue; }
+            const int e = sh.lbase[d] + lds_claim(&sh.fill[d], 1);
+            sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)x; sh.u_list[e] = (uint8_t)d;
         }
     }
-    // FILL: segment offsets (every thread sums the 16 counts itself: no scan phase), then every controlled vehicle files
-    // (virtual distance at list build, slot) into its lists; the order inside a segment is arbitrary (RANK sorts)
-    static PVE_HD void ph_fill(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r, bool force_scan)
+    static PVE_HD void ph_pairs_count(const PVE_AS4 GeoConst &g, int t, Sh &sh, bool force_scan)
     {
-        int total = 0;
-#pragma unroll
-        for (int d = 0; d < ND; d++) total += sh.cntd[d];
-        const bool ok = !force_scan && total <= Sh::PE;
-        if (t == 0) {
-            sh.pool_ok = ok ? 1 : 0;
-            int run = 0;
-            for (int d = 0; d < ND; d++) { sh.loff[d] = (int16_t)run; run += ok ? sh.cntd[d] : 0; }
-            sh.loff[ND] = (int16_t)run;
-        }
-        if (!ok || !r.mmask) return;
-        int run = 0;
-        for (int d = 0; d < g.dir_num; d++) {
-            const int c = sh.cntd[d];
-            if ((r.mmask >> d) & 1) {
-                double vo = 0;
-                member_self(sh, d, r, vo);
-                const int e = run + lds_claim(&sh.fill[d], 1);
-                sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)d;
-            }
-            run += c;
-        }
+        if (force_scan || sh.lbase[ND] <= Sh::PE) return;       // the upper bounds fit (or the scan is forced): nothing to count
+        pairs_loop<true>(g, t, sh);
+    }
+    static PVE_HD void ph_pairs_exact(int t, Sh &sh, bool force_scan)
+    {
+        const bool over = sh.lbase[ND] > Sh::PE;                // (uniform; read before anybody rewrites lbase: same phase,
+        int c = 0;                                              //  but only the first 16 lanes write, after their own read)
+        if (over && t < ND) c = sh.cnt2[t];
+#if PVE_DEVICE_CODE
+        const int incl = wave_incl_scan(t, c, nullptr);
+#else
+        if (t == 0) sh.emu_scan = 0;
+        const int incl = wave_incl_scan(t, c, &sh.emu_scan);
+#endif
+        if (over && t < ND) sh.lnew[t] = (int16_t)(incl > 32767 ? 32767 : incl);
+        if (t == 0) sh.pool_ok = force_scan ? 0 : (over ? 2 : 1);  // 2: exact segment offsets are in lnew (applied by FILL)
+    }
+    static PVE_HD void ph_pairs_fill(const PVE_AS4 GeoConst &g, int t, Sh &sh)
+    {
+        if (sh.pool_ok == 0 || (sh.pool_ok == 2 && sh.lnew[ND - 1] > Sh::PE)) return;
+        pairs_loop<false>(g, t, sh);
+    }
+    // (between EXACT and FILL: one thread per list moves the exact offsets into lbase; own phase = own barrier)
+    static PVE_HD void ph_pairs_apply(int t, Sh &sh)
+    {
+        if (sh.pool_ok != 2) return;
+        if (t < ND) sh.lbase[t + 1] = sh.lnew[t];
+        if (t == ND && sh.lnew[ND - 1] > Sh::PE) sh.pool_ok = 0;    // even the exact sizes do not fit: membership scan
     }
     // RANK: counting sort of every list by (vd, slot) = the reference's stable sort by vd of the list it builds in
     // (lane, intention, j) order (ref :271); entry-parallel, 8 independent LDS reads per round (cf. Tick::ph_rank)
     static PVE_HD void ph_rank(int t, Sh &sh)
     {
         if (!sh.pool_ok) return;
-        const int M = sh.loff[ND];
+        const int M = sh.lbase[ND] < Sh::PE ? sh.lbase[ND] : Sh::PE;
         for (int e = t; e < M; e += CAP) {
             const int d = sh.u_list[e];
+            if (d == 0xFF) continue;                      // capacity nobody claimed
             const double vd = sh.u_vd[e];
             const int slot = sh.u_slot[e];
-            const int lo = sh.loff[d], hi = sh.loff[d + 1];
+            const int lo = sh.lbase[d], hi = lo + sh.fill[d];
             int pos = 0, eq = 0;
             int f = lo;
             for (; f + 8 <= hi; f += 8) {
@@ -291,33 +335,14 @@ template <int CAP> struct TickGeo {
         const double px = sh.p[x];
         if (lx == li) {
             if (rx == d) { vo = px; return true; }                                     // ref :246-249
-            const double q = px - sh.inbox[sh.intent_of[x]];                           // ref :251-252
-            if (q > 0) { vo = q + sh.inbox[m]; return true; }                          // ref :253-257
+            const double q = px - sh.tab.inbox[sh.intent_of[x]];                           // ref :251-252
+            if (q > 0) { vo = q + sh.tab.inbox[m]; return true; }                          // ref :253-257
             return false;
         }
-        const int k = sh.pos[d][rx];                                                   // ref :258
+        const int k = sh.tab.pos[d][rx];                                                   // ref :258
         if (k < 0) return false;
-        const double *e = sh.vdt[sh.dty[d]][k];
+        const double *e = sh.tab.vd[sh.tab.dty[d]][k];
         const double delta = (px - e[0]) + e[1];                                       // ref :453-660 / :733-803
-        if (!(delta > 0)) return false;
-        vo = (delta + e[2]) - e[3];
-        return true;
-    }
-
-    // the same test for the thread's OWN vehicle (COUNT / FILL): its lane, route, intention and position are in registers,
-    // so one evaluation is two levels of LDS reads instead of five
-    static PVE_HD bool member_self(const Sh &sh, int d, const Regs &r, double &vo)
-    {
-        const int li = sh.dir_lane[d], m = sh.dir_index[d], k = sh.pos[d][r.route], ty = sh.dty[d];
-        if (r.lane == li) {
-            if (r.route == d) { vo = r.p; return true; }                                // ref :246-249
-            const double q = r.p - sh.inbox[r.intent];                                  // ref :251-252
-            if (q > 0) { vo = q + sh.inbox[m]; return true; }                           // ref :253-257
-            return false;
-        }
-        if (k < 0) return false;                                                        // ref :258
-        const double *e = sh.vdt[ty][k];
-        const double delta = (r.p - e[0]) + e[1];                                       // ref :453-660 / :733-803
         if (!(delta > 0)) return false;
         vo = (delta + e[2]) - e[3];
         return true;
@@ -357,11 +382,11 @@ template <int CAP> struct TickGeo {
         //     when their physical lane holds a vehicle (ref :234), otherwise the old head stays (stale by design)
         const bool lists = sh.pool_ok != 0;
         if (t >= CAP - ND && t - (CAP - ND) < g.dir_num) {     // the last 16 threads: the (mostly empty) tail of the last wave
-            const int d = t - (CAP - ND), li = sh.dir_lane[d], m = sh.dir_index[d];
+            const int d = t - (CAP - ND), li = sh.tab.dir_lane[d], m = sh.tab.dir_index[d];
             if (sh.hd.lane_start[li + 1] > sh.hd.lane_start[li]) {
                 double best = INFINITY; int bs = -1;
                 if (lists) {
-                    if (sh.loff[d + 1] > sh.loff[d]) bs = sh.u_slot[sh.s_idx[sh.loff[d]]];       // sorted: the first entry
+                    if (sh.fill[d] > 0) bs = sh.u_slot[sh.s_idx[sh.lbase[d]]];                  // sorted: the first entry
                 } else {
                     for (int w = 0; w < NW; w++)
                         for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
@@ -385,9 +410,9 @@ template <int CAP> struct TickGeo {
         const int d = r.route, li = r.lane, m = r.intent;
         const double me = r.p;                                   // own entry: vd = p, never adjusted
         const bool fix = (g.lane_num == 4) && (d % 3 == 0);      // ref :1301
-        const int opp = sh.opp[d];
+        const int opp = sh.tab.opp[d];
         const int ls = sh.hd.lane_start[li], le = sh.hd.lane_start[li + 1];
-        const unsigned mroutes = sh.mroutes[d];                  // routes that can appear in list d (cheap early reject)
+        const unsigned mroutes = sh.tab.mroutes[d];                  // routes that can appear in list d (cheap early reject)
         double bvo = -INFINITY, bvc = 0; int bslot = -1;
         // the 6 nearest so far, sorted by |vd - vd_self|: only (distance, slot) travel through the insertion chain;
         // the build-time / current distances of the 6 winners are re-derived at the end, and the rare exact
@@ -432,7 +457,7 @@ template <int CAP> struct TickGeo {
         if (lists && !fix) {
             // sorted list, no entry is ever re-written: the 12-lane kernel's window walk (ref :1340-1405)
             int pr; double pvd;
-            Base::walk_window(sh, sh.loff[d], sh.loff[d + 1] - sh.loff[d], sh.mypos[t], me, r, pr, pvd);
+            Base::walk_window(sh, sh.lbase[d], sh.fill[d], sh.mypos[t], me, r, pr, pvd);
             r.hdr = pr;                                                                 // ref :1348-1354
             r.vir_dis = (pr >= 0) ? (me - pvd) : 100.0;
             sh.hdr[t] = (int16_t)pr;
@@ -443,8 +468,8 @@ template <int CAP> struct TickGeo {
         if (lists) {
             // 4-lane left-turn routes: the entries of the opposing left-turn route are re-written ego by ego (ref
             // :1301-1319), so these egos still look at every member of their list
-            const int e1 = sh.loff[d + 1];
-            for (int e = sh.loff[d]; e < e1; e++) {
+            const int e1 = sh.lbase[d] + sh.fill[d];
+            for (int e = sh.lbase[d]; e < e1; e++) {
                 const int x = sh.u_slot[e];
                 if (x != t) consider(x, sh.u_vd[e]);
             }

@@ -75,6 +75,23 @@ struct EnvHeader {
 enum { F_P = 0, F_V, F_A, F_JERK, F_JERK_SUM, F_VIR_DIS, F_CLOSER_P, NF64 };
 enum { I_ID = 0, I_SEQ, I_VNUM, I_STEP, I_COUNT, I_META, I_HDR, NI32 };
 
+// Lookup tables of the general-geometry kernel that are indexed per vehicle / per list: one block, host-computed
+// (make_geo_const), copied verbatim into LDS at the top of every launch (a per-lane index into the kernel arguments
+// would be a vector load from the argument buffer in the middle of a phase).
+struct GeoTab {
+    double vd[4][MAXK][4];         // [route type][k] = A, B, C, C2:  delta = (p1 - A) + B ; vd = (delta + C) - C2
+    double inbox[4];               // Const::inbox (lane_info[m][1]) of this layout
+    int8_t pos[ND][ND];            // pos[d][route] = index of route in lane2lane[d], or -1
+    int8_t lst[ND][12];            // lst[r][k] = k-th list (ascending) route r can be filed into, k < nl[r] <= 10
+    uint16_t mroutes[ND];          // bit r: route r can be a member of list d (same physical lane, or in lane2lane[d])
+    uint16_t lroutes[ND];          // bit d: route r can be filed into list d (transpose of mroutes)
+    uint16_t ninv[ND];             // ceil(32768 / nl[r]): exact division of a pair offset < 2048 by nl[r]
+    int8_t opp[ND];                // lane2lane[d][1] (4-lane fix-up, ref :1303)
+    int8_t dir_lane[ND], dir_index[ND];    // inverse of direction
+    int8_t nl[ND];
+    int8_t dty[ND];                // d % tmod: row of vd for list d
+};
+
 // General geometry (lane_num 4 / 8, and 12 for cross-checks): everything the 4-/8-lane branches of the reference
 // derive in the constructor (ref :66-145), get_virtual_distance (ref :453-660) and get_p (ref :896-1249).
 struct GeoConst {
@@ -82,20 +99,14 @@ struct GeoConst {
     int32_t lane_num, dir_num, tmod, RL;   // tmod: routes of the same type are d % tmod apart; RL: left radius / cw
     double H;                      // half box width: 2cw (4-lane), 4cw (8-lane)
     double fix_d, fix_hi, fix_lo;  // 4-lane far-conflict fix-up (ref :1304-1318): (_alpha-alpha)*3*cw, _alpha*3*cw, alpha*3*cw
-    double vd[4][MAXK][4];         // [route type][k] = A, B, C, C2:  delta = (p1 - A) + B ; vd = (delta + C) - C2
     int8_t l2l[ND][MAXK];          // lane2lane rows, -1 padded
     int8_t direction[NL][4];       // direction[lane][intention], -1 = none (ref :88-93, :135-144, :168-181)
-    int8_t dir_lane[ND], dir_index[ND];    // inverse of direction
     int8_t turn[NL];               // get_p: quarter turns of the canonical path (ref :896-1249)
     int8_t pad_[4];
-    // derived membership tables (host-computed once; the kernel copies them into LDS with plain dword loads)
-    int8_t pos[ND][ND];            // pos[d][route] = index of route in lane2lane[d], or -1
-    int8_t opp[ND];                // lane2lane[d][1] (4-lane fix-up, ref :1303)
-    uint16_t mroutes[ND];          // bit r: route r can be a member of list d (same physical lane, or in lane2lane[d])
-    uint16_t lroutes[ND];          // bit d: route r can be filed into list d (transpose of mroutes)
     // the two tables the kernel indexes per vehicle, packed into scalars (a dynamic index into the kernel arguments
     // is a global load): turn[lane] in 4-bit fields, direction[lane][m] + 1 in 5-bit fields of dir_pk[m]
     unsigned long long turn_pk, dir_pk[3];
+    GeoTab tab;
 };
 
 struct Outputs {        // mirrors pve_outputs (include/pve_env.h)

@@ -108,8 +108,10 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
         for (int t = 0; t < CAP; t++) B::ph_step3(g.base, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_step3_publish(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_order2(t, sh);
-        for (int t = 0; t < CAP; t++) T::ph_count(g, t, sh, regs[t]);
-        for (int t = 0; t < CAP; t++) T::ph_fill(g, t, sh, regs[t], P.geo_scan != 0);
+        for (int t = 0; t < CAP; t++) T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
+        for (int t = 0; t < CAP; t++) T::ph_pairs_exact(t, sh, P.geo_scan != 0);
+        for (int t = 0; t < CAP; t++) T::ph_pairs_apply(t, sh);
+        for (int t = 0; t < CAP; t++) T::ph_pairs_fill(g, t, sh);
         for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
         for (int t = 0; t < CAP; t++) T::ph_scan(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_reward(g, t, sh, regs[t]);

@@ -24,7 +24,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        if "k_tick" not in k and "k_actor" not in k:
+        if "k_tick" not in k and "k_actor" not in k and "k_rollout" not in k:
             continue
         acc[k.split("(")[0][:40]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
