@@ -51,15 +51,23 @@ inline float actor_canonical(const float *W, const float *x)
     for (int layer = 1; layer <= 2; layer++) {
         const int G = layer == 1 ? AW_LN1_G : AW_LN2_G, B = layer == 1 ? AW_LN1_B : AW_LN2_B;
         float *src = layer == 1 ? h : g;
-        // LayerNorm + ReLU over the 64 hidden units: lane group q sums its units in (m, r) order
+        // LayerNorm + ReLU over the 64 hidden units.  Lane group q holds u[m][r] = unit 16 m + 4 q + r as four float4
+        // (one per m): sums run component-wise over m first, then over the 4 components, then over the lane groups
         for (int q = 0; q < 4; q++) {
-            p[q] = 0.f;
-            for (int m = 0; m < 4; m++) for (int r = 0; r < 4; r++) p[q] += src[16 * m + 4 * q + r];
+            float a4[4];
+            for (int r = 0; r < 4; r++)
+                a4[r] = (src[4 * q + r] + src[16 + 4 * q + r]) + (src[32 + 4 * q + r] + src[48 + 4 * q + r]);
+            p[q] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         }
         mean = actor_ln_combine(p) / (float)ACT_H;
         for (int q = 0; q < 4; q++) {
-            p[q] = 0.f;
-            for (int m = 0; m < 4; m++) for (int r = 0; r < 4; r++) { const float d = src[16 * m + 4 * q + r] - mean; p[q] = fmaf(d, d, p[q]); }
+            float e4[4];
+            for (int r = 0; r < 4; r++) {
+                float e = 0.f;
+                for (int m = 0; m < 4; m++) { const float d = src[16 * m + 4 * q + r] - mean; e = fmaf(d, d, e); }
+                e4[r] = e;
+            }
+            p[q] = (e4[0] + e4[1]) + (e4[2] + e4[3]);
         }
         rstd = 1.0f / sqrtf(actor_ln_combine(p) / (float)ACT_H + 1e-12f);
         for (int u = 0; u < ACT_H; u++) {
@@ -100,37 +108,35 @@ inline float actor_canonical(const float *W, const float *x)
 // vehicles per wave and pass (ballot compaction), 28 + 64 MFMAs per pass.
 typedef float pve_v4f __attribute__((ext_vector_type(4)));
 
+typedef unsigned pve_v2u __attribute__((ext_vector_type(2)));
+// sum over the four lanes (j, j + 16, j + 32, j + 48) that hold one vehicle, every lane gets the total: two gfx950 row
+// swaps (VALU, no LDS crossbar round trip): ((row 0 + row 1) + (row 2 + row 3)) in every lane
 __device__ __forceinline__ float actor_xsum(float s)
 {
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    return s;
+    unsigned u = __float_as_uint(s);
+    pve_v2u r = __builtin_amdgcn_permlane16_swap(u, u, false, false);       // odd rows of one copy <-> even rows of the other
+    s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(s);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // LayerNorm + ReLU over the 64 hidden units of a vehicle: 16 of them in this lane (units 16 m + 4 q + r), the rest in the
 // lanes 16 / 32 / 48 further on
 __device__ __forceinline__ void actor_ln_relu16(pve_v4f (&v)[4], const float *__restrict__ gamma, const float *__restrict__ beta, int q)
-{
-    float sum = 0.f;
+{   // float4 arithmetic = packed f32 instructions (v_pk_add / v_pk_mul / v_pk_fma): half the VALU issue of scalar code
+    const pve_v4f a4 = (v[0] + v[1]) + (v[2] + v[3]);
+    const float mean = actor_xsum((a4[0] + a4[1]) + (a4[2] + a4[3])) / (float)ACT_H;
+    pve_v4f e4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) sum += v[m][r];
-    const float mean = actor_xsum(sum) / (float)ACT_H;
-    float var = 0.f;
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const float d = v[m][r] - mean; var = fmaf(d, d, var); }
-    const float rstd = 1.0f / sqrtf(actor_xsum(var) / (float)ACT_H + 1e-12f);
+    for (int m = 0; m < 4; m++) { const pve_v4f d = v[m] - mean; e4 = __builtin_elementwise_fma(d, d, e4); }
+    const float rstd = 1.0f / sqrtf(actor_xsum((e4[0] + e4[1]) + (e4[2] + e4[3])) / (float)ACT_H + 1e-12f);
+    const pve_v4f zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         const pve_v4f ga = *(const pve_v4f *)(gamma + 16 * m + 4 * q), be = *(const pve_v4f *)(beta + 16 * m + 4 * q);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float inv = rstd * ga[r];
-            v[m][r] = fmaxf(fmaf(v[m][r], inv, be[r] - mean * inv), 0.f);
-        }
+        const pve_v4f inv = ga * rstd;
+        v[m] = __builtin_elementwise_max(__builtin_elementwise_fma(v[m], inv, be - inv * mean), zero);
     }
 }
 
