@@ -344,3 +344,11 @@ def test_gpu_actor_kernel_follows_the_canonical_order():
         assert ctl.sum() > 200 and np.all(a_dev[~ctl] == 0)
         worst = max(worst, np.abs(a_dev - a_emu).max())
     assert worst <= 2e-6, worst
+
+
+@pytest.mark.parametrize("lane_num,rate,quant", [(8, 1500.0, None), (8, 2400.0, 1.0), (4, 1800.0, 1.0), (12, 1100.0, None)])
+def test_gpu_geo_list_path_equals_scan_fallback(lane_num, rate, quant):
+    """General-geometry kernel: sorted per-route lists (incl. the exact-size second chance at 2400 veh/h/lane) == the
+    membership-scan fallback (PVE_CFG_GEO_SCAN), bit for bit."""
+    m = scenarios.check_geo_lists_equal_scan(BACKEND, lane_num, n_envs=12, ticks=300, rate=rate, quantize=quant)
+    assert m["ctl_steps"] > 20000
