@@ -155,6 +155,7 @@ PVE_HD void block_sum(double *red, int t, double x)
 // ------------------------------------------------------------------ shared (LDS) block of one env
 template <int CAP> struct Shared {
     static constexpr int NW = CAP / 64;
+    static constexpr bool PIN_READS = true;   // walk_window: keep the batched window reads from being sunk into guarded blocks
     static constexpr int POOL = 5 * CAP;
     // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
     // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
@@ -294,6 +295,15 @@ PVE_HD void sincos_q1(double x, double &sn, double &cs)
     sn = fold ? c1 : s1;
     cs = fold ? s1 : c1;
 }
+
+// PVE_PIN(x): the value of x is materialised HERE.  Without it the compiler sinks a speculative LDS read into the
+// conditional block that uses its result, which turns a batch of independent reads back into one guarded basic block
+// (read, wait, read, wait) per element.
+#if PVE_DEVICE_CODE
+#define PVE_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define PVE_PIN(x) ((void)0)
+#endif
 
 // Small constant tables of the kernel arguments are never indexed with a per-lane value (that would be a vector load
 // from the argument buffer, ~1 us on the critical path): the entries are scalar-loaded and selected.
@@ -655,34 +665,62 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         const uint16_t *sidx = sh.s_idx + base;      // sorted position -> entry
 #define sv(pos_) (Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base + (pos_) : 0] : sh.u_vd[sidx[pos_]])
 #define ss(pos_) (Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base + (pos_) : 0] : sh.u_slot[sidx[pos_]])
-        pr = -1; pvd = 0;
-        if (s > 0) { pr = ss(s - 1); pvd = sv(s - 1); }                             // ref :1353-1354
+        // All window reads are UNCONDITIONAL on clamped positions and the validity is applied to the values afterwards: a
+        // guarded LDS read is a basic block of its own (index read, wait, value read, wait) and thirteen of them in a row
+        // are twenty-six serial LDS round trips; this way the 13 index reads go out back to back, then the 26 value reads.
+        // Only the distances of the window are read (and the predecessor's slot): validity follows from the positions,
+        // the slots of the 6 winners are read once they are known.
+        double lv[NNB + 1]; bool lok[NNB];
+        double rv[NNB]; bool rok[NNB];
+        {
+            const int last = n - 1;                       // (n >= 1: the ego's own entry)
+            double lraw[NNB + 1];
+            double rraw[NNB];
+            int prs = -1;
+#pragma unroll
+            for (int i = 0; i < NNB + 1; i++) {
+                const int pos = s - 1 - i, pc = pos >= 0 ? pos : 0;
+                lraw[i] = sv(pc);
+                if (i == 0) prs = (int)ss(pc);
+            }
+#pragma unroll
+            for (int i = 0; i < NNB; i++) {
+                const int pos = s + 1 + i, pc = pos <= last ? pos : last;
+                rraw[i] = sv(pc);
+            }
+            if (Sh::PIN_READS) {                          // (not in the general-geometry kernel: more spills there)
+#pragma unroll
+                for (int i = 0; i < NNB + 1; i++) PVE_PIN(lraw[i]);
+#pragma unroll
+                for (int i = 0; i < NNB; i++) PVE_PIN(rraw[i]);
+                PVE_PIN(prs);
+            }
+#pragma unroll
+            for (int i = 0; i < NNB + 1; i++) {
+                const bool okl = s - 1 - i >= 0;
+                lv[i] = okl ? lraw[i] : -INFINITY;
+                if (i < NNB) lok[i] = okl;
+            }
+            bool rvalid = true;                                        // everything after the +inf sentinel is stale
+#pragma unroll
+            for (int i = 0; i < NNB; i++) {
+                const double w = (s + 1 + i <= last) ? rraw[i] : INFINITY;
+                rvalid = rvalid && (w < INFINITY);
+                rv[i] = rvalid ? w : INFINITY;
+                rok[i] = rvalid;
+            }
+            pr = (s > 0) ? prs : -1; pvd = (s > 0) ? lv[0] : 0.0;                    // ref :1353-1354
+        }
         // The 6 nearest in the reference's stable |vd - vd_self| sort = the 6 smallest keys (|d|, vd, slot) (ref
         // :1383-1397).  Both sides of our own position are already sorted by |d|: left = keys below ours (walking
         // left), right = keys above (walking right); on equal |d| the left entry comes first (smaller vd, or equal
-        // vd and smaller slot).  FAST PATH: prefetch the 6+6 window with independent LDS reads and merge in
-        // registers (first half of a bitonic merge + a 6-input sorting network).  It is exact unless two LEFT
-        // neighbours (incl. the first one beyond the window) share the same vd: such a run must be emitted in
-        // ascending slot, i.e. against the walking direction; then the general pointer walk below is used.
-        double lv[NNB + 1]; int lsl[NNB];
-        double rv[NNB]; int rsl[NNB];
+        // vd and smaller slot).  FAST PATH: merge the prefetched 7+6 window in registers (first half of a bitonic merge
+        // + a 6-input sorting network).  It is exact unless two LEFT neighbours (incl. the first one beyond the window)
+        // share the same vd: such a run must be emitted in ascending slot, i.e. against the walking direction; then the
+        // general pointer walk below is used.
         bool tie = false;
 #pragma unroll
-        for (int i = 0; i < NNB + 1; i++) {
-            const int pos = s - 1 - i;
-            lv[i] = (pos >= 0) ? sv(pos) : -INFINITY;
-            if (i < NNB) lsl[i] = (pos >= 0) ? (int)ss(pos) : -1;
-            if (i > 0) tie = tie || (pos >= 0 && lv[i] == lv[i - 1]);
-        }
-        bool rvalid = true;                                            // everything after the +inf sentinel is stale
-#pragma unroll
-        for (int i = 0; i < NNB; i++) {
-            const int pos = s + 1 + i;
-            const double w = (pos < n) ? sv(pos) : INFINITY;
-            rvalid = rvalid && (w < INFINITY);
-            rv[i] = rvalid ? w : INFINITY;
-            rsl[i] = rvalid ? (int)ss(pos < n ? pos : 0) : -1;
-        }
+        for (int i = 1; i < NNB + 1; i++) tie = tie || (s - 1 - i >= 0 && lv[i] == lv[i - 1]);
         // candidate = (d, code): code = walking index on the left (0..5) or 8 + index on the right.  min(L_i, R_5-i)
         // (left wins equal d) are the 6 smallest overall; they are then sorted by d alone with a 12-comparator
         // network.  If two of the 6 winners still share the same d (exact |d| ties, quantised states) the order
@@ -690,9 +728,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         double cd[NNB]; int cc[NNB];
 #pragma unroll
         for (int i = 0; i < NNB; i++) {
-            const double dl = (lsl[i] >= 0) ? fabs(lv[i] - ps) : INFINITY;                      // ref :1388
+            const double dl = lok[i] ? fabs(lv[i] - ps) : INFINITY;                             // ref :1388
             const int j = NNB - 1 - i;
-            const double dr = (rsl[j] >= 0) ? fabs(rv[j] - ps) : INFINITY;
+            const double dr = rok[j] ? fabs(rv[j] - ps) : INFINITY;
             const bool takeL = dl <= dr;
             cd[i] = takeL ? dl : dr; cc[i] = takeL ? i : (8 + j);
         }
@@ -961,9 +999,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     }
     static PVE_HD int pack_lanej(const Sh &sh, int slot)
     {
-        if (slot < 0) return -1;
-        int l = sh.lane_of[slot];
-        return (l << 16) | (slot - sh.hd.lane_start[l]);
+        const int sc = slot < 0 ? 0 : slot;                   // unconditional reads on a clamped slot (no guarded LDS blocks)
+        const int l = sh.lane_of[sc];
+        int w = (l << 16) | (sc - sh.hd.lane_start[l]);
+        PVE_PIN(w);
+        return slot < 0 ? -1 : w;
     }
 
     // RES = false: the tick kernel -- state and header go back to HBM (`O` = P.out).
@@ -1134,14 +1174,13 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             double row[OBSW];
             row[0] = r.p; row[1] = r.v; row[2] = r.a; row[3] = (double)r.lane;
 #pragma unroll
-            for (int k = 0; k < NNB; k++) {
-                const int x = r.kr[k];
-                if (x >= 0) {
-                    row[4 + 4 * k] = r.kv[k]; row[5 + 4 * k] = sh.v[x]; row[6 + 4 * k] = sh.a[x];
-                    row[7 + 4 * k] = (double)sh.lane_of[x];
-                } else {
-                    row[4 + 4 * k] = 0; row[5 + 4 * k] = 0; row[6 + 4 * k] = 0; row[7 + 4 * k] = 0;
-                }
+            for (int k = 0; k < NNB; k++) {                   // unconditional gathers on clamped slots, selected afterwards
+                const int x = r.kr[k], xc = x < 0 ? 0 : x;
+                double nv = sh.v[xc], na = sh.a[xc]; int nli = sh.lane_of[xc];
+                PVE_PIN(nv); PVE_PIN(na); PVE_PIN(nli);
+                const double nl = (double)nli;
+                row[4 + 4 * k] = x >= 0 ? r.kv[k] : 0.0; row[5 + 4 * k] = x >= 0 ? nv : 0.0;
+                row[6 + 4 * k] = x >= 0 ? na : 0.0; row[7 + 4 * k] = x >= 0 ? nl : 0.0;
             }
             if (O.obs_pre) {
                 double *o = O.obs_pre + gpre * OBSW;
