@@ -837,6 +837,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (!(r.alive && r.ctl)) return;
         const int lane = r.lane;
         const double ps = r.p;
+        const double myv = sh.v[t];                       // (published in S3: v and a are not carried in registers through WALK)
         // ref :280-310
         double t_distance = 2, d_distance = 10;
         const int n0 = r.kr[0];
@@ -844,7 +845,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const double vdn = r.kv[0];
             d_distance = fabs(ps - vdn);
             r.closer_p = vdn;
-            if (d_distance != 0) t_distance = (ps - vdn) / (r.v - sh.v[n0] + 0.0001);
+            if (d_distance != 0) t_distance = (ps - vdn) / (myv - sh.v[n0] + 0.0001);
         } else {
             r.closer_p = 150;
         }
@@ -858,7 +859,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             double q1 = d_distance * 0.1, q2 = q1 * q1;
             r_ += reward_log_term(q2 * q2 * q1 + 0.00001);
         }
-        r_ += (r.v - c.vm) * c.inv_span * 2.0;
+        r_ += (myv - c.vm) * c.inv_span * 2.0;
         r_ = (r_ > -20) ? r_ : -20;
         r.reward = (r_ < 20) ? r_ : 20;
         r.jerk_sum += fabs(jd);                                                   // ref :321
@@ -1030,6 +1031,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         // ---- per-slot meta
         int meta = 0, hdr_word = -1, new_slot = -1, lockf = 0;
         if (r.alive) {
+            r.v = sh.v[t]; r.a = sh.a[t];                  // back from LDS (S3 published them; dead in registers since then)
             int coll = r.coll_fin > M_COLL_MASK ? M_COLL_MASK : r.coll_fin;
             meta = (r.meta & (M_CONTROL | M_FINISH | M_DONE)) | M_ALIVE | (coll << M_COLL_SHIFT);
             if (r.cyc & 1) {
