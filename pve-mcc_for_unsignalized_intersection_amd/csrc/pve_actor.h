@@ -146,22 +146,53 @@ __device__ __forceinline__ void actor_ln_relu16(pve_v4f (&v)[4], const float *__
 // workgroup barrier after the weights are staged, so the waves of a SIMD drift apart and one wave's loads / LayerNorms
 // hide under another's MFMAs.  The next intersection's flags and the next tile's rows are loaded one step ahead.
 constexpr int ACT_WPAD = 68;
+// the small parameter vectors, staged next to the dense kernels (reads of the parameters inside a tile are LDS reads, not
+// L1 / L2 round trips in front of the MFMAs that need them)
+constexpr int SM_LN0_G = 0, SM_LN0_B = 28, SM_B1 = 56, SM_LN1_G = 120, SM_LN1_B = 184, SM_B2 = 248, SM_LN2_G = 312,
+              SM_LN2_B = 376, SM_W3 = 440, SM_B3 = 504, SM_TOTAL = 508;
+
+// LayerNorm + ReLU over the 64 hidden units of a vehicle: 16 of them in this lane (units 16 m + 4 q + r), the rest in the
+// lanes 16 / 32 / 48 further on; parameters from LDS
+__device__ __forceinline__ void actor_ln_relu16_lds(pve_v4f (&v)[4], const float *gamma, const float *beta, int q)
+{   // float4 arithmetic = packed f32 instructions (v_pk_add / v_pk_mul / v_pk_fma): half the VALU issue of scalar code
+    const pve_v4f a4 = (v[0] + v[1]) + (v[2] + v[3]);
+    const float mean = actor_xsum((a4[0] + a4[1]) + (a4[2] + a4[3])) / (float)ACT_H;
+    pve_v4f e4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; m++) { const pve_v4f d = v[m] - mean; e4 = __builtin_elementwise_fma(d, d, e4); }
+    const float rstd = 1.0f / sqrtf(actor_xsum((e4[0] + e4[1]) + (e4[2] + e4[3])) / (float)ACT_H + 1e-12f);
+    const pve_v4f zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const pve_v4f ga = *(const pve_v4f *)(gamma + 16 * m + 4 * q), be = *(const pve_v4f *)(beta + 16 * m + 4 * q);
+        const pve_v4f inv = ga * rstd;
+        v[m] = __builtin_elementwise_max(__builtin_elementwise_fma(v[m], inv, be - inv * mean), zero);
+    }
+}
+
 template <int CAP, typename OBS_T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_t(const float *__restrict__ W, const OBS_T *__restrict__ obs,
                                                  const int32_t *__restrict__ meta, double *__restrict__ actions,
                                                  int n_envs)
 {
     __shared__ float Ws1[ACT_IN][ACT_WPAD], Ws2[ACT_H][ACT_WPAD];
+    __shared__ __attribute__((aligned(16))) float Wsm[SM_TOTAL];
     __shared__ unsigned char slot_of_s[4][CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jl = lane & 15, q = lane >> 4;
     unsigned char *slot_of = slot_of_s[wave];
-    for (int i = tid; i < ACT_IN * ACT_H; i += 256) Ws1[i >> 6][i & 63] = W[AW_W1 + i];
-    for (int i = tid; i < ACT_H * ACT_H; i += 256) Ws2[i >> 6][i & 63] = W[AW_W2 + i];
     const int stride = gridDim.x * 4;
     int env = blockIdx.x * 4 + wave;
     int mt[CAP / 64];                                         // flags of the wave's next intersection (loaded one ahead)
 #pragma unroll
     for (int sub = 0; sub < CAP / 64; sub++) mt[sub] = env < n_envs ? meta[(size_t)env * CAP + sub * 64 + lane] : 0;
+    for (int i = tid; i < ACT_IN * ACT_H; i += 256) Ws1[i >> 6][i & 63] = W[AW_W1 + i];
+    for (int i = tid; i < ACT_H * ACT_H; i += 256) Ws2[i >> 6][i & 63] = W[AW_W2 + i];
+    if (tid < 2 * ACT_IN) Wsm[SM_LN0_G + tid] = W[AW_LN0_G + tid];
+    if (tid < ACT_H) {
+        Wsm[SM_B1 + tid] = W[AW_B1 + tid]; Wsm[SM_B2 + tid] = W[AW_B2 + tid]; Wsm[SM_W3 + tid] = W[AW_W3 + tid];
+    }
+    if (tid < 2 * ACT_H) { Wsm[SM_LN1_G + tid] = W[AW_LN1_G + tid]; Wsm[SM_LN2_G + tid] = W[AW_LN2_G + tid]; }
+    if (tid == 0) Wsm[SM_B3] = W[AW_B3];
     __syncthreads();                                          // weights staged
     for (; env < n_envs; env += stride) {
         const size_t base = (size_t)env * CAP;
@@ -191,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int s = 0; s < ACT_IN / 4; s++) xr[s] = (float)row[4 * s + q];
         }
         for (int v0 = 0; v0 < nctl; v0 += 16) {              // 16 vehicles per pass
-            // the A operands are read from LDS right before the MFMA that consumes them; an offset the compiler cannot
+            // the A operands are read from LDS one step ahead of the MFMAs that consume them; an offset the compiler cannot
             // see through keeps it from hoisting all 92 reads out of the loops into 250 registers (1 wave per SIMD)
             int wo = 0;
             asm volatile("" : "+v"(wo));
@@ -218,41 +249,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const float rstd = 1.0f / sqrtf(actor_xsum(var) / (float)ACT_IN + 1e-12f);
 #pragma unroll
                 for (int s = 0; s < ACT_IN / 4; s++) {
-                    const float inv = rstd * W[AW_LN0_G + 4 * s + q];
-                    x[s] = fmaf(x[s], inv, W[AW_LN0_B + 4 * s + q] - mean * inv);
+                    const float inv = rstd * Wsm[SM_LN0_G + 4 * s + q];
+                    x[s] = fmaf(x[s], inv, Wsm[SM_LN0_B + 4 * s + q] - mean * inv);
                 }
             }
-            // ---- dense 28 -> 64 (+ bias): 7 steps x 4 unit tiles
+            // ---- dense 28 -> 64 (+ bias): 7 steps x 4 unit tiles, A operands double-buffered
             pve_v4f h[4];
 #pragma unroll
-            for (int m = 0; m < 4; m++) h[m] = *(const pve_v4f *)(W + AW_B1 + 16 * m + 4 * q);
+            for (int m = 0; m < 4; m++) h[m] = *(const pve_v4f *)(Wsm + SM_B1 + 16 * m + 4 * q);
+            {
+                float wa[2][4];
 #pragma unroll
-            for (int s = 0; s < ACT_IN / 4; s++)
+                for (int m = 0; m < 4; m++) wa[0][m] = Ws1[q][16 * m + jl + wo];
 #pragma unroll
-                for (int m = 0; m < 4; m++)
-                    h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws1[4 * s + q][16 * m + jl + wo], x[s], h[m], 0, 0, 0);
+                for (int s = 0; s < ACT_IN / 4; s++) {
+                    if (s + 1 < ACT_IN / 4) {
+#pragma unroll
+                        for (int m = 0; m < 4; m++) wa[(s + 1) & 1][m] = Ws1[4 * (s + 1) + q][16 * m + jl + wo];
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; m++) h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s & 1][m], x[s], h[m], 0, 0, 0);
+                }
+            }
             // ---- LayerNorm_1 + ReLU, dense 64 -> 64, LayerNorm_2 + ReLU
-            actor_ln_relu16(h, W + AW_LN1_G, W + AW_LN1_B, q);
+            actor_ln_relu16_lds(h, Wsm + SM_LN1_G, Wsm + SM_LN1_B, q);
             pve_v4f g[4];
 #pragma unroll
-            for (int m2 = 0; m2 < 4; m2++) g[m2] = *(const pve_v4f *)(W + AW_B2 + 16 * m2 + 4 * q);
+            for (int m2 = 0; m2 < 4; m2++) g[m2] = *(const pve_v4f *)(Wsm + SM_B2 + 16 * m2 + 4 * q);
+            {
+                float wa[2][4];
 #pragma unroll
-            for (int m = 0; m < 4; m++)                       // step (m, r) contracts k = 16 m + 4 q + r
+                for (int m2 = 0; m2 < 4; m2++) wa[0][m2] = Ws2[4 * q][16 * m2 + jl + wo];
 #pragma unroll
-                for (int r = 0; r < 4; r++)
+                for (int st = 0; st < 16; st++) {             // step st = 4 m + r contracts k = 16 m + 4 q + r
+                    const int m = st >> 2, r = st & 3;
+                    if (st + 1 < 16) {
+                        const int mn = (st + 1) >> 2, rn = (st + 1) & 3;
+#pragma unroll
+                        for (int m2 = 0; m2 < 4; m2++) wa[(st + 1) & 1][m2] = Ws2[16 * mn + 4 * q + rn][16 * m2 + jl + wo];
+                    }
 #pragma unroll
                     for (int m2 = 0; m2 < 4; m2++)
-                        g[m2] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws2[16 * m + 4 * q + r][16 * m2 + jl + wo], h[m][r], g[m2], 0, 0, 0);
-            actor_ln_relu16(g, W + AW_LN2_G, W + AW_LN2_B, q);
+                        g[m2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st & 1][m2], h[m][r], g[m2], 0, 0, 0);
+                }
+            }
+            actor_ln_relu16_lds(g, Wsm + SM_LN2_G, Wsm + SM_LN2_B, q);
             // ---- dense 64 -> 1, 3 tanh
             float part = 0.f;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const pve_v4f w3 = *(const pve_v4f *)(W + AW_W3 + 16 * m + 4 * q);
+                const pve_v4f w3 = *(const pve_v4f *)(Wsm + SM_W3 + 16 * m + 4 * q);
 #pragma unroll
                 for (int r = 0; r < 4; r++) part = fmaf(g[m][r], w3[r], part);
             }
-            const float a = 3.0f * tanhf(actor_xsum(part) + W[AW_B3]);
+            const float a = 3.0f * tanhf(actor_xsum(part) + Wsm[SM_B3]);
             if (q == 0 && valid) actions[base + cur_slot] = (double)a;
         }
     }
