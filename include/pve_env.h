@@ -54,6 +54,10 @@ enum {
 #define PVE_CFG_GEO_SCAN     0x4   /* flags (diagnostics): the general-geometry kernel finds list members by scanning every controlled
                                       vehicle (its fallback when an intersection's lists overflow the LDS entry pool) instead of reading
                                       the per-route lists; results are identical (tested) */
+#define PVE_CFG_ACTOR_F32    0x8   /* flags: run the actor as an exact float32 FMA chain (v_mfma_f32_16x16x4_f32, the evaluation order
+                                      of csrc/pve_actor.h `actor_canonical`) instead of the default split-half form (every operand
+                                      x = hi + lo in float16, three v_mfma_f32_16x16x32_f16 per block, float32 accumulation:
+                                      ~1e-6 relative per dot product, 5x less matrix-core time) */
 typedef struct pve_config {
     double deltaT;          /* 0.1 */
     double vm, vM;          /* 5, 13   (train(): vm = 6, main.py:230) */
@@ -177,7 +181,8 @@ int pve_compact(pve_handle h, double *obs_post /* optional: rows are moved with 
 
 /* MADDPG actor inference on the device (reference model_agent_maddpg.py:23-49 `actor_network`, called per
  * vehicle with batch 1 from main.py:36-45, 404): for every controlled vehicle
- *   actions[env][slot] = 3*tanh(Dense1(relu(LN(Dense64(relu(LN(Dense64(LN(obs[env][slot]))))))))   (float32),
+ *   actions[env][slot] = 3*tanh(Dense1(relu(LN(Dense64(relu(LN(Dense64(LN(obs[env][slot]))))))))   (float32; the two dense
+ *   layers on the matrix cores with split-half operands unless PVE_CFG_ACTOR_F32, see pve_config.flags),
  * 0 for every other slot (main.py:401).  weights: DEVICE float32[PVE_ACTOR_N_WEIGHTS] in the order
  * LayerNorm{gamma[28],beta[28]}, dense{kernel[28][64],bias[64]}, LayerNorm_1{gamma,beta}[64],
  * dense_1{kernel[64][64],bias[64]}, LayerNorm_2{gamma,beta}[64], dense_2{kernel[64],bias[1]} (TF variable

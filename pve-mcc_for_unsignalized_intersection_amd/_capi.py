@@ -16,6 +16,7 @@ DIR_NUM = {4: 12, 8: 16, 12: 12}     # virtual-lane lists per layout (ref :86, :
 CFG_GENERAL_PATH = 0x1
 CFG_OBS_F32 = 0x2
 CFG_GEO_SCAN = 0x4
+CFG_ACTOR_F32 = 0x8
 PVE_OBS_WIDTH = 28
 PVE_NBR = 6
 PVE_N_METRICS = 12

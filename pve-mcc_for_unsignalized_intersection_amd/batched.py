@@ -58,6 +58,8 @@ class BatchedIntersections:
             config["flags"] = int(config.get("flags", 0)) | _capi.CFG_GENERAL_PATH
         if config.pop("geo_scan", False):
             config["flags"] = int(config.get("flags", 0)) | _capi.CFG_GEO_SCAN
+        if config.pop("actor_f32", False):
+            config["flags"] = int(config.get("flags", 0)) | _capi.CFG_ACTOR_F32
         if obs_dtype not in (torch.float64, torch.float32):
             raise TypeError("obs_dtype must be torch.float64 or torch.float32")
         self.obs_dtype = obs_dtype

@@ -308,5 +308,164 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_actor_h: the same network with every float32 operand split into two halves, x = hi + lo (hi = half(x), lo =
+// half(x - hi): 22 significant bits; gfx950's matrix cores honour f16 subnormals -- tools/mfma_layout_probe.hip), and
+// three v_mfma_f32_16x16x32_f16 per product block (hi*hi + hi*lo + lo*hi, float32 accumulation; the lo*lo term is
+// 2^-22 relative).  The f16 instruction contracts K = 32 at 16x the rate of the f32 one, so a 16-vehicle tile costs 36
+// MFMAs x 16 cycles instead of 92 x 32.  Same transposed formulation: lane (j, q) supplies B[k = 8 q + e][j] as 8
+// consecutive halves -- for layer 2 exactly the two accumulator registers h[2 b], h[2 b + 1] it already holds for K-block
+// b (k = 32 b + 8 q + e  <->  hidden unit 16 (2 b + e / 4) + 4 q + e % 4) -- and the weights are staged in LDS in the
+// A-operand layout ([block][unit tile][lane][8 halves]: one conflict-free 16-byte read per MFMA).
+// Not bit-identical to the float32 chain of k_actor_t (actor_canonical): ~1e-6 relative per dot product; the action
+// parity bar is 5e-4 (tests/actor_scenarios.py).  PVE_CFG_ACTOR_F32 selects k_actor_t.
+typedef _Float16 pve_v8h __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float (&x)[8], pve_v8h &hi, pve_v8h &lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; e++) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+}
+
+template <int CAP, typename OBS_T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_h(const float *__restrict__ W, const OBS_T *__restrict__ obs,
+                                                 const int32_t *__restrict__ meta, double *__restrict__ actions,
+                                                 int n_envs)
+{
+    // A operands: [hi | lo][unit tile m][lane][8] for layer 1 (K = 28, padded to 32), [hi | lo][K-block b][m][lane][8] for layer 2
+    __shared__ __attribute__((aligned(16))) _Float16 A1[2][4][64][8], A2[2][2][4][64][8];
+    __shared__ __attribute__((aligned(16))) float Wsm[SM_TOTAL];
+    __shared__ unsigned char slot_of_s[4][CAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jl = lane & 15, q = lane >> 4;
+    unsigned char *slot_of = slot_of_s[wave];
+    const int stride = gridDim.x * 4;
+    int env = blockIdx.x * 4 + wave;
+    int mt[CAP / 64];                                         // flags of the wave's next intersection (loaded one ahead)
+#pragma unroll
+    for (int sub = 0; sub < CAP / 64; sub++) mt[sub] = env < n_envs ? meta[(size_t)env * CAP + sub * 64 + lane] : 0;
+    for (int n = tid; n < 4 * 64 * 8; n += 256) {             // layer 1: element e of lane l, tile m = W1[8 q + e][16 m + j]
+        const int e = n & 7, l = (n >> 3) & 63, m = n >> 9, k = 8 * (l >> 4) + e;
+        const float w = k < ACT_IN ? W[AW_W1 + k * ACT_H + 16 * m + (l & 15)] : 0.f;
+        const _Float16 h = (_Float16)w;
+        A1[0][m][l][e] = h; A1[1][m][l][e] = (_Float16)(w - (float)h);
+    }
+    for (int n = tid; n < 2 * 4 * 64 * 8; n += 256) {         // layer 2: W2[16 (2 b + e / 4) + 4 q + e % 4][16 m + j]
+        const int e = n & 7, l = (n >> 3) & 63, m = (n >> 9) & 3, bk = n >> 11;
+        const int k = 16 * (2 * bk + (e >> 2)) + 4 * (l >> 4) + (e & 3);
+        const float w = W[AW_W2 + k * ACT_H + 16 * m + (l & 15)];
+        const _Float16 h = (_Float16)w;
+        A2[0][bk][m][l][e] = h; A2[1][bk][m][l][e] = (_Float16)(w - (float)h);
+    }
+    if (tid < 2 * ACT_IN) Wsm[SM_LN0_G + tid] = W[AW_LN0_G + tid];
+    if (tid < ACT_H) {
+        Wsm[SM_B1 + tid] = W[AW_B1 + tid]; Wsm[SM_B2 + tid] = W[AW_B2 + tid]; Wsm[SM_W3 + tid] = W[AW_W3 + tid];
+    }
+    if (tid < 2 * ACT_H) { Wsm[SM_LN1_G + tid] = W[AW_LN1_G + tid]; Wsm[SM_LN2_G + tid] = W[AW_LN2_G + tid]; }
+    if (tid == 0) Wsm[SM_B3] = W[AW_B3];
+    __syncthreads();                                          // weights staged
+    const int nf = q < 3 ? 8 : ACT_IN - 24;                   // features 8 q .. 8 q + nf - 1 of the 28 live in this lane
+    for (; env < n_envs; env += stride) {
+        const size_t base = (size_t)env * CAP;
+        int nctl = 0;
+#pragma unroll
+        for (int sub = 0; sub < CAP / 64; sub++) {
+            const int s = sub * 64 + lane;
+            const bool c = (mt[sub] & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
+            const unsigned long long b = __ballot(c);
+            const int rank = nctl + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+            if (c) slot_of[rank] = (unsigned char)s;
+            else actions[base + s] = 0.0;                     // main.py:401: uncontrolled vehicles get 0
+            nctl += __builtin_popcountll(b);
+        }
+        {
+            const int en = env + stride;
+#pragma unroll
+            for (int sub = 0; sub < CAP / 64; sub++) mt[sub] = en < n_envs ? meta[(size_t)en * CAP + sub * 64 + lane] : 0;
+        }
+        float xr[8];
+        int slot = slot_of[jl < nctl ? jl : 0];
+        if (nctl > 0) {
+            const OBS_T *row = obs + (base + slot) * OBSW + 8 * q;
+#pragma unroll
+            for (int e = 0; e < 8; e++) xr[e] = e < nf ? (float)row[e] : 0.f;
+        }
+        for (int v0 = 0; v0 < nctl; v0 += 16) {              // 16 vehicles per pass
+            int wo = 0;
+            asm volatile("" : "+v"(wo));                      // (keeps the A-operand reads inside the loop)
+            const bool valid = v0 + jl < nctl;
+            const int cur_slot = slot;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = xr[e];
+            if (v0 + 16 < nctl) {
+                slot = slot_of[v0 + 16 + jl < nctl ? v0 + 16 + jl : v0 + 16];
+                const OBS_T *row = obs + (base + slot) * OBSW + 8 * q;
+#pragma unroll
+                for (int e = 0; e < 8; e++) xr[e] = e < nf ? (float)row[e] : 0.f;
+            }
+            {   // LayerNorm over the 28 inputs (8, 8, 8, 4 per lane group)
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) sum += x[e];
+                const float mean = actor_xsum(sum) / (float)ACT_IN;
+                float var = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) { const float d = e < nf ? x[e] - mean : 0.f; var = fmaf(d, d, var); }
+                const float rstd = 1.0f / sqrtf(actor_xsum(var) / (float)ACT_IN + 1e-12f);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int k = e < nf ? 8 * q + e : 0;
+                    const float inv = rstd * Wsm[SM_LN0_G + k];
+                    x[e] = e < nf ? fmaf(x[e], inv, Wsm[SM_LN0_B + k] - mean * inv) : 0.f;
+                }
+            }
+            // ---- dense 28 -> 64 (+ bias)
+            pve_v4f h[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) h[m] = *(const pve_v4f *)(Wsm + SM_B1 + 16 * m + 4 * q);
+            {
+                pve_v8h xh, xl;
+                split8(x, xh, xl);
+#pragma unroll
+                for (int m = 0; m < 4; m++) h[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A1[0][m][lane + wo][0], xh, h[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; m++) h[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A1[0][m][lane + wo][0], xl, h[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; m++) h[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A1[1][m][lane + wo][0], xh, h[m], 0, 0, 0);
+            }
+            // ---- LayerNorm_1 + ReLU, dense 64 -> 64, LayerNorm_2 + ReLU
+            actor_ln_relu16_lds(h, Wsm + SM_LN1_G, Wsm + SM_LN1_B, q);
+            pve_v4f g[4];
+#pragma unroll
+            for (int m2 = 0; m2 < 4; m2++) g[m2] = *(const pve_v4f *)(Wsm + SM_B2 + 16 * m2 + 4 * q);
+#pragma unroll
+            for (int bk = 0; bk < 2; bk++) {                  // K-block bk: this lane's units of h[2 bk], h[2 bk + 1]
+                float hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) hv[e] = h[2 * bk + (e >> 2)][e & 3];
+                pve_v8h hh, hl;
+                split8(hv, hh, hl);
+#pragma unroll
+                for (int m2 = 0; m2 < 4; m2++) g[m2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A2[0][bk][m2][lane + wo][0], hh, g[m2], 0, 0, 0);
+#pragma unroll
+                for (int m2 = 0; m2 < 4; m2++) g[m2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A2[0][bk][m2][lane + wo][0], hl, g[m2], 0, 0, 0);
+#pragma unroll
+                for (int m2 = 0; m2 < 4; m2++) g[m2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A2[1][bk][m2][lane + wo][0], hh, g[m2], 0, 0, 0);
+            }
+            actor_ln_relu16_lds(g, Wsm + SM_LN2_G, Wsm + SM_LN2_B, q);
+            // ---- dense 64 -> 1, 3 tanh
+            float part = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const pve_v4f w3 = *(const pve_v4f *)(Wsm + SM_W3 + 16 * m + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; r++) part = fmaf(g[m][r], w3[r], part);
+            }
+            const float a = 3.0f * tanhf(actor_xsum(part) + Wsm[SM_B3]);
+            if (q == 0 && valid) actions[base + cur_slot] = (double)a;
+        }
+    }
+}
+
 #endif  // __HIPCC__
 }  // namespace pve

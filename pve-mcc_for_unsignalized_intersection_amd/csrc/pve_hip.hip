@@ -445,20 +445,26 @@ struct Backend {
     }
     template <typename OBS_T>
     static void launch_actor_t(const float *W, const OBS_T *obs, const int32_t *meta, double *actions, int n_envs, int cap,
-                               hipStream_t s)
+                               bool exact_f32, hipStream_t s)
     {
-        // persistent workgroups (the 23 KB of dense kernels are staged in LDS once per workgroup): 4 per CU
+        // persistent workgroups of 4 waves (the dense kernels are staged in LDS once per workgroup): 4 per CU, one wave
+        // per intersection at a time
         static const int wgs = getenv("PVE_ACTOR_GRID") ? atoi(getenv("PVE_ACTOR_GRID")) : 1024;
-        const int grid = (n_envs + 3) / 4 < wgs ? (n_envs + 3) / 4 : wgs;     // one wave per intersection
-        if (cap == 64) hipLaunchKernelGGL((k_actor_t<64, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
-        else hipLaunchKernelGGL((k_actor_t<128, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
+        const int grid = (n_envs + 3) / 4 < wgs ? (n_envs + 3) / 4 : wgs;
+        if (exact_f32) {
+            if (cap == 64) hipLaunchKernelGGL((k_actor_t<64, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
+            else hipLaunchKernelGGL((k_actor_t<128, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
+        } else {
+            if (cap == 64) hipLaunchKernelGGL((k_actor_h<64, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
+            else hipLaunchKernelGGL((k_actor_h<128, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
+        }
     }
-    static int launch_actor(const float *W, const void *obs, int obs_f32, const int32_t *meta, double *actions, int n_envs,
+    static int launch_actor(const float *W, const void *obs, int mode, const int32_t *meta, double *actions, int n_envs,
                             int cap, void *stream, std::string &err)
     {
         hipStream_t s = (hipStream_t)stream;
-        if (obs_f32) launch_actor_t<float>(W, (const float *)obs, meta, actions, n_envs, cap, s);
-        else launch_actor_t<double>(W, (const double *)obs, meta, actions, n_envs, cap, s);
+        if (mode & 1) launch_actor_t<float>(W, (const float *)obs, meta, actions, n_envs, cap, (mode & 2) != 0, s);
+        else launch_actor_t<double>(W, (const double *)obs, meta, actions, n_envs, cap, (mode & 2) != 0, s);
         return check_launch(err);
     }
     static int launch_probe(const Params &P, int cap, int *sink, void *stream, std::string &err)

@@ -190,7 +190,7 @@ struct Backend {
         for (size_t s = 0; s < (size_t)n_envs * cap; s++) {
             if ((meta[s] & (M_ALIVE | M_CONTROL)) != (M_ALIVE | M_CONTROL)) { actions[s] = 0.0; continue; }
             float x[ACT_IN];
-            for (int k = 0; k < ACT_IN; k++) x[k] = obs_f32 ? obsf[s * OBSW + k] : (float)obs[s * OBSW + k];
+            for (int k = 0; k < ACT_IN; k++) x[k] = (obs_f32 & 1) ? obsf[s * OBSW + k] : (float)obs[s * OBSW + k];
             actions[s] = (double)actor_canonical(W, x);
         }
         return 0;

@@ -317,16 +317,20 @@ def test_gpu_full_size_actor_closed_loop_matches_small_batch():
     assert m["overflow"] == 0 and m["alive_steps"] / m["ticks"] > 40
 
 
-def test_gpu_actor_kernel_follows_the_canonical_order():
-    """k_actor_t (v_mfma_f32_16x16x4_f32, transposed form) computes every dot product and LayerNorm sum in the order of
-    csrc/pve_actor.h `actor_canonical` (which the CPU emulator calls): same float32 results up to the final tanh's ulps."""
+@pytest.mark.parametrize("exact,tol", [(True, 2e-6), (False, 1e-4)])
+def test_gpu_actor_kernel_follows_the_canonical_order(exact, tol):
+    """exact: k_actor_t (v_mfma_f32_16x16x4_f32, PVE_CFG_ACTOR_F32) computes every dot product and LayerNorm sum in the
+    order of csrc/pve_actor.h `actor_canonical` (which the CPU emulator calls): same float32 results up to the final
+    tanh's ulps.  Default: k_actor_h (split-half operands on the f16 matrix instruction, float32 accumulation) agrees
+    with the float32 chain to 4e-5 on actions in [-3, 3] for random rows of scale up to 150 (harsher than real states) --
+    an order of magnitude inside the 5e-4 parity bar."""
     from pve_mcc_amd.arrivals import synthetic_arrivals
     from oracle.actor_np import flat_weights, load_weights
     n, ticks = 24, 120
     arr = synthetic_arrivals(n, rate=1100.0, horizon_s=ticks * 0.1 + 30, seed=77)
     w = flat_weights(load_weights())
     outs = ("obs_post", "reward", "flags", "env_out")
-    dev, emu = make_batch(arr, n, 128, BACKEND, outputs=outs), make_batch(arr, n, 128, "emu", outputs=outs)
+    dev, emu = make_batch(arr, n, 128, BACKEND, outputs=outs, actor_f32=exact), make_batch(arr, n, 128, "emu", outputs=outs)
     for b in (dev, emu):
         b.reset()
         b.set_actor(w)
@@ -343,7 +347,8 @@ def test_gpu_actor_kernel_follows_the_canonical_order():
         ctl = (emu.state_field("meta").numpy() & 1) != 0
         assert ctl.sum() > 200 and np.all(a_dev[~ctl] == 0)
         worst = max(worst, np.abs(a_dev - a_emu).max())
-    assert worst <= 2e-6, worst
+    print("actor (exact=%s): max |a_dev - a_canonical| = %.3e" % (exact, worst))
+    assert worst <= tol, worst
 
 
 @pytest.mark.parametrize("lane_num,rate,quant", [(8, 1500.0, None), (8, 2400.0, 1.0), (4, 1800.0, 1.0), (12, 1100.0, None)])
