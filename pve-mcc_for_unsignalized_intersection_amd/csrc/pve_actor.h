@@ -343,18 +343,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int mt[CAP / 64];                                         // flags of the wave's next intersection (loaded one ahead)
 #pragma unroll
     for (int sub = 0; sub < CAP / 64; sub++) mt[sub] = env < n_envs ? meta[(size_t)env * CAP + sub * 64 + lane] : 0;
-    for (int n = tid; n < 4 * 64 * 8; n += 256) {             // layer 1: element e of lane l, tile m = W1[8 q + e][16 m + j]
-        const int e = n & 7, l = (n >> 3) & 63, m = n >> 9, k = 8 * (l >> 4) + e;
-        const float w = k < ACT_IN ? W[AW_W1 + k * ACT_H + 16 * m + (l & 15)] : 0.f;
-        const _Float16 h = (_Float16)w;
-        A1[0][m][l][e] = h; A1[1][m][l][e] = (_Float16)(w - (float)h);
-    }
-    for (int n = tid; n < 2 * 4 * 64 * 8; n += 256) {         // layer 2: W2[16 (2 b + e / 4) + 4 q + e % 4][16 m + j]
-        const int e = n & 7, l = (n >> 3) & 63, m = (n >> 9) & 3, bk = n >> 11;
-        const int k = 16 * (2 * bk + (e >> 2)) + 4 * (l >> 4) + (e & 3);
-        const float w = W[AW_W2 + k * ACT_H + 16 * m + (l & 15)];
-        const _Float16 h = (_Float16)w;
-        A2[0][bk][m][l][e] = h; A2[1][bk][m][l][e] = (_Float16)(w - (float)h);
+    // staging: one thread per operand vector (8 halves of one lane: loads 8 weights, splits them, two 16-byte LDS writes)
+    for (int n = tid; n < (4 + 8) * 64; n += 256) {
+        const int l = n & 63, t8 = n >> 6, qq = l >> 4, col = l & 15;
+        float w[8];
+        if (t8 < 4) {                                         // layer 1, unit tile m = t8: W1[8 q + e][16 m + j]
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const int k = 8 * qq + e; w[e] = k < ACT_IN ? W[AW_W1 + k * ACT_H + 16 * t8 + col] : 0.f; }
+        } else {                                              // layer 2, K-block bk, unit tile m: W2[16 (2 bk + e / 4) + 4 q + e % 4][16 m + j]
+            const int bk = (t8 - 4) >> 2, m = (t8 - 4) & 3;
+#pragma unroll
+            for (int e = 0; e < 8; e++) w[e] = W[AW_W2 + (16 * (2 * bk + (e >> 2)) + 4 * qq + (e & 3)) * ACT_H + 16 * m + col];
+        }
+        pve_v8h hi, lo;
+        split8(w, hi, lo);
+        if (t8 < 4) { *(pve_v8h *)&A1[0][t8][l][0] = hi; *(pve_v8h *)&A1[1][t8][l][0] = lo; }
+        else { *(pve_v8h *)&A2[0][(t8 - 4) >> 2][(t8 - 4) & 3][l][0] = hi; *(pve_v8h *)&A2[1][(t8 - 4) >> 2][(t8 - 4) & 3][l][0] = lo; }
     }
     if (tid < 2 * ACT_IN) Wsm[SM_LN0_G + tid] = W[AW_LN0_G + tid];
     if (tid < ACT_H) {

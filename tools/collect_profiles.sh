@@ -16,15 +16,15 @@ timeout 400 $NB --mode step --pipeline 1 2>/dev/null | tail -1 > $O/bench_single
 timeout 400 $NB --mode rollout --pipeline 1 --chunk 0 2>/dev/null | tail -1 > $O/bench_rollout_one_launch.json
 timeout 300 $B --capacity 64 2>/dev/null | tail -1 > $O/bench_cap64.json
 timeout 300 $NB --capacity 64 --mode step 2>/dev/null | tail -1 > $O/bench_cap64_step.json
-timeout 300 $NB --actor --obs-f32 --pipeline 3 2>/dev/null | tail -1 > $O/bench_actor.json
-timeout 300 $NB --actor 2>/dev/null | tail -1 > $O/bench_actor_f64.json
+timeout 300 $NB --actor 2>/dev/null | tail -1 > $O/bench_actor.json
+timeout 300 $NB --actor --obs-f64 2>/dev/null | tail -1 > $O/bench_actor_f64.json
 timeout 300 $B --lane-num 8 --steps 300 --pipeline 3 2>/dev/null | tail -1 > $O/bench_lanes8.json
 timeout 300 $NB --lane-num 4 --capacity 64 --rate 1200 --steps 300 2>/dev/null | tail -1 > $O/bench_lanes4.json
 # ---- per-kernel durations (rocprofv3 --kernel-trace --stats), same commands
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o r -- $NB > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_step -o r -- $NB --mode step > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_cap64 -o r -- $NB --capacity 64 > /dev/null 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_actor -o r -- $NB --actor --obs-f32 --pipeline 3 --steps 300 > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_actor -o r -- $NB --actor --steps 300 > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_lanes8 -o r -- $NB --lane-num 8 --steps 300 --pipeline 3 > /dev/null 2>&1
 # ---- HBM counters in their own passes (kernel-trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass)
 for m in rollout step; do
