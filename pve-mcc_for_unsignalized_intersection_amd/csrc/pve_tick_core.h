@@ -46,14 +46,17 @@ template <int NW> PVE_HD void vote(u64 *m, int t, bool f)
 #endif
 }
 PVE_HD bool mask_test(const u64 *m, int t) { return (m[t >> 6] >> (t & 63)) & 1ull; }
+// The mask helpers read every word UNCONDITIONALLY (one broadcast LDS read each) and select with arithmetic: a word read
+// under `if (t >= ...)` is a guarded basic block of its own (read, wait), and a tick calls these helpers dozens of times.
+PVE_HD u64 below_sel(int rel)                                  // bits [0, rel) of a 64-bit word, rel may be <= 0 or >= 64
+{
+    return rel >= 64 ? ~0ull : (rel > 0 ? ((1ull << (rel & 63)) - 1ull) : 0ull);
+}
 template <int NW> PVE_HD int mask_below(const u64 *m, int t)   // set bits at positions < t
 {
     int c = 0;
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-        if (t >= (k + 1) * 64) c += __builtin_popcountll(m[k]);
-        else if (t > k * 64) c += __builtin_popcountll(m[k] & ((1ull << (t - k * 64)) - 1ull));
-    }
+    for (int k = 0; k < NW; k++) c += __builtin_popcountll(m[k] & below_sel(t - k * 64));
     return c;
 }
 template <int NW> PVE_HD int mask_count(const u64 *m)
@@ -65,15 +68,13 @@ template <int NW> PVE_HD int mask_count(const u64 *m)
 }
 template <int NW> PVE_HD int mask_prev(const u64 *m, int t)    // highest set bit < t, or -1
 {
+    int best = -1;
 #pragma unroll
-    for (int k = NW - 1; k >= 0; k--) {
-        int lo = k * 64;
-        if (t <= lo) continue;
-        u64 b = m[k];
-        if (t < lo + 64) b &= (1ull << (t - lo)) - 1ull;
-        if (b) return lo + 63 - __builtin_clzll(b);
+    for (int k = 0; k < NW; k++) {                             // ascending: a hit in a higher word overrides
+        const u64 b = m[k] & below_sel(t - k * 64);
+        best = b ? (k * 64 + 63 - __builtin_clzll(b | 1ull)) : best;
     }
-    return -1;
+    return best;
 }
 PVE_HD void lds_add(int *p, int v)
 {
@@ -229,7 +230,7 @@ template <int CAP> struct Shared {
         double act_next[CAP];        // k_rollout: the NEXT tick's action of every slot, prefetched under the tail of this tick
     };
     double tabA[2][4], tabB[2][4], tabC[2][4];   // get_virtual_distance table (copy of Const, lane-indexed reads; BUILD only)
-    int8_t l2l[NL][4], l2l_inv[NL][4];
+    alignas(4) int8_t l2l[NL][4], l2l_inv[NL][4];   // (rows are read as one dword)
     int lead_n;                      // scratch units claimed by the dead-lock cycles
 };
 
@@ -608,15 +609,27 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             sh.u_vd[e] = r.p; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)lane;
         }
         if (lane % 3 == 2) return;                            // right turns conflict with nobody (ref :156)
+        // three batches of independent LDS reads (lane tables, distance tables + list offsets), then the writes: written
+        // as one loop per k the compiler emits four serial chains of three round trips each
+        const int dpk = *(const int *)sh.l2l[lane], kpk = *(const int *)sh.l2l_inv[lane];   // 4 x int8 each
+        int d[4], kk[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { d[k] = (dpk >> (8 * k)) & 0xff; kk[k] = (kpk >> (8 * k)) & 0xff; }   // (>= 0 on these lanes)
+        double tA[4], tB[4], tC[4]; int lo[4], so[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int d = sh.l2l[lane][k];                    // the relation is symmetric
-            const int kk = sh.l2l_inv[lane][k];               // our position inside lane2lane[d]
-            const int m = d % 3;
-            const double delta = r.p - sh.tabA[m][kk] + sh.tabB[m][kk];  // ref :733-803
-            const double vd = (delta > 0) ? (sh.tabC[m][kk] + delta) : INFINITY;   // not chosen -> sorts last
-            const int e = sh.loff[d] + sh.segoff[d][kk + 1] + q;
-            sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)d;
+            const int m = d[k] % 3;
+            tA[k] = sh.tabA[m][kk[k]]; tB[k] = sh.tabB[m][kk[k]]; tC[k] = sh.tabC[m][kk[k]];
+            lo[k] = sh.loff[d[k]]; so[k] = sh.segoff[d[k]][kk[k] + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { PVE_PIN(tA[k]); PVE_PIN(tB[k]); PVE_PIN(tC[k]); PVE_PIN(lo[k]); PVE_PIN(so[k]); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double delta = r.p - tA[k] + tB[k];                          // ref :733-803 (the relation is symmetric: kk =
+            const double vd = (delta > 0) ? (tC[k] + delta) : INFINITY;        // our position inside lane2lane[d]); not chosen -> sorts last
+            const int e = lo[k] + so[k] + q;
+            sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)d[k];
         }
     }
 
@@ -1002,8 +1015,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     {
         const int sc = slot < 0 ? 0 : slot;                   // unconditional reads on a clamped slot (no guarded LDS blocks)
         const int l = sh.lane_of[sc];
-        int w = (l << 16) | (sc - sh.hd.lane_start[l]);
-        PVE_PIN(w);
+        const int w = (l << 16) | (sc - sh.hd.lane_start[l]);
         return slot < 0 ? -1 : w;
     }
 
@@ -1166,23 +1178,35 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (O.reward && r.alive) O.reward[gpre] = r.ctl ? r.reward : 0.0;
         if (O.lanej && r.alive) O.lanej[gpre] = (r.lane << 16) | r.j;
         if (O.new_slot && r.alive) O.new_slot[gpre] = new_slot;
-        if (O.nbr && r.alive && r.ctl) {           // controlled vehicles only (PVE_F_CTL in flags)
-            int *nb = O.nbr + gpre * NNB;
+        if (r.alive && r.ctl) {
+            // the 6 neighbours' speed, acceleration, lane and lane start: two batches of unconditional LDS gathers on clamped
+            // slots (one guarded block per neighbour = six serial round trips), shared by the neighbour ids and the row
+            int xc[NNB], nln[NNB], nls[NNB]; double nv[NNB], na[NNB];
 #pragma unroll
-            for (int k = 0; k < NNB; k++) nb[k] = pack_lanej(sh, r.kr[k]);
-        }
-        if (r.alive && r.ctl && (O.obs_pre || (O.obs_post && new_slot >= 0))) {
+            for (int k = 0; k < NNB; k++) {
+                xc[k] = r.kr[k] < 0 ? 0 : r.kr[k];
+                nln[k] = sh.lane_of[xc[k]]; nv[k] = sh.v[xc[k]]; na[k] = sh.a[xc[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < NNB; k++) { PVE_PIN(nln[k]); PVE_PIN(nv[k]); PVE_PIN(na[k]); }
+#pragma unroll
+            for (int k = 0; k < NNB; k++) nls[k] = sh.hd.lane_start[nln[k]];
+#pragma unroll
+            for (int k = 0; k < NNB; k++) PVE_PIN(nls[k]);
+            if (O.nbr) {                               // controlled vehicles only (PVE_F_CTL in flags)
+                int *nb = O.nbr + gpre * NNB;
+#pragma unroll
+                for (int k = 0; k < NNB; k++) nb[k] = r.kr[k] < 0 ? -1 : ((nln[k] << 16) | (xc[k] - nls[k]));
+            }
+          if (O.obs_pre || (O.obs_post && new_slot >= 0)) {
             // row 0 of the state, ref :1325-1337
             double row[OBSW];
             row[0] = r.p; row[1] = r.v; row[2] = r.a; row[3] = (double)r.lane;
 #pragma unroll
-            for (int k = 0; k < NNB; k++) {                   // unconditional gathers on clamped slots, selected afterwards
-                const int x = r.kr[k], xc = x < 0 ? 0 : x;
-                double nv = sh.v[xc], na = sh.a[xc]; int nli = sh.lane_of[xc];
-                PVE_PIN(nv); PVE_PIN(na); PVE_PIN(nli);
-                const double nl = (double)nli;
-                row[4 + 4 * k] = x >= 0 ? r.kv[k] : 0.0; row[5 + 4 * k] = x >= 0 ? nv : 0.0;
-                row[6 + 4 * k] = x >= 0 ? na : 0.0; row[7 + 4 * k] = x >= 0 ? nl : 0.0;
+            for (int k = 0; k < NNB; k++) {
+                const bool has = r.kr[k] >= 0;
+                row[4 + 4 * k] = has ? r.kv[k] : 0.0; row[5 + 4 * k] = has ? nv[k] : 0.0;
+                row[6 + 4 * k] = has ? na[k] : 0.0; row[7 + 4 * k] = has ? (double)nln[k] : 0.0;
             }
             if (O.obs_pre) {
                 double *o = O.obs_pre + gpre * OBSW;
@@ -1200,6 +1224,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                     for (int k = 0; k < OBSW; k++) o[k] = row[k];
                 }
             }
+          }
         }
     }
     // the tick kernel's FIN
@@ -1216,16 +1241,20 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // this tick's block of the output buffers (trajectory roll-outs: block k; else the same buffers every tick)
     static PVE_HD Outputs tick_outputs(const PVE_AS4 Params &P, const PVE_AS4 RolloutArgs &R, int k)
     {
+        // (all pointers are loaded in one go and shifted with arithmetic: a null test + branch per pointer is a serial chain
+        //  of scalar-load round trips at the top of FIN; a null pointer stays null because s = 0 or the field is unused)
         Outputs o;
         const long long s = R.trajectory ? (long long)k * P.n_envs * CAP : 0;
-        o.obs_post = P.out.obs_post ? (P.obs_f32 ? (double *)((float *)P.out.obs_post + s * OBSW) : P.out.obs_post + s * OBSW) : nullptr;
+        const long long se = R.trajectory ? (long long)k * P.n_envs * 8 : 0;
+        const long long f32 = P.obs_f32 ? 1 : 0;
+        o.obs_post = (double *)((char *)P.out.obs_post + (P.out.obs_post ? s * OBSW * (f32 ? 4 : 8) : 0));
         o.obs_pre = nullptr; o.state_pre = nullptr; o.obs_prev_post = nullptr;
-        o.reward = P.out.reward ? P.out.reward + s : nullptr;
-        o.flags = P.out.flags ? P.out.flags + s : nullptr;
-        o.lanej = P.out.lanej ? P.out.lanej + s : nullptr;
-        o.nbr = P.out.nbr ? P.out.nbr + s * NNB : nullptr;
-        o.new_slot = P.out.new_slot ? P.out.new_slot + s : nullptr;
-        o.env_out = P.out.env_out ? P.out.env_out + (R.trajectory ? (long long)k * P.n_envs * 8 : 0) : nullptr;
+        o.reward = P.out.reward + (P.out.reward ? s : 0);
+        o.flags = P.out.flags + (P.out.flags ? s : 0);
+        o.lanej = P.out.lanej + (P.out.lanej ? s : 0);
+        o.nbr = P.out.nbr + (P.out.nbr ? s * NNB : 0);
+        o.new_slot = P.out.new_slot + (P.out.new_slot ? s : 0);
+        o.env_out = P.out.env_out + (P.out.env_out ? se : 0);
         return o;
     }
     // next tick's action of slot t: the load is issued under FX .. LOCK2 and parked in LDS at the start of FIN
