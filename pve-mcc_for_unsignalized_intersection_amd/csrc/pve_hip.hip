@@ -127,6 +127,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     typedef Tick<CAP> T;
     unsigned long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev_ = PROF ? wall_clock64() : 0ull;
+    const unsigned long long sclk0_ = PROF ? clock64() : 0ull, wclk0_ = tprev_;   // shader clock vs the 100 MHz constant clock
 #undef PVE_PHASE_MARK
 #define PVE_PHASE_MARK(idx)                                                              \
     if (PROF) {                                                                          \
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             unsigned long long *row = P.phase_cycles + ((size_t)env0_ * (CAP / 64) + (t0_ >> 6)) * 16;
 #pragma unroll
             for (int k = 0; k < 12; k++) row[k] += pc_[k];
+            row[12] += clock64() - sclk0_; row[13] += wall_clock64() - wclk0_;
         }
     }
 }

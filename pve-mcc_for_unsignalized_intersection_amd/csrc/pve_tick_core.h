@@ -17,6 +17,7 @@
 #pragma once
 #include "pve_types.h"
 #include <math.h>
+#include <string.h>
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PVE_AS4 __attribute__((address_space(4)))
@@ -203,9 +204,17 @@ template <int CAP> struct Shared {
         uint8_t bb[CAP];             // brake bits: bit0 if front did not brake, bit1 if it did (S2 .. S3 only)
         uint8_t rew_ovr[CAP];        // reward[-1] override (FX .. LOCK; zeroed in BUILD)
     };
-    u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_coll[NW];
-    union { u64 m_lead[NW]; u64 m_keep[NW]; };   // tick kernel | compaction kernel
-    u64 m_spawn[NW];
+    u64 m_alive[NW], m_ctl[NW];
+    union {
+        // entries of list d with a finite distance (own lane + the chosen conflict entries, ref :259-270): RANK sorts only
+        // those, WALK never sees an unchosen entry (LISTS .. WALK; the masks below are born in FX)
+        int nfin[NL];
+        struct {
+            u64 m_del[NW], m_fin[NW], m_ctlnow[NW], m_coll[NW];
+            union { u64 m_lead[NW]; u64 m_keep[NW]; };   // tick kernel | compaction kernel
+            u64 m_spawn[NW];
+        };
+    };
     uint8_t s_slot[DIRECT ? POOL : 1];
     union {
         alignas(8) uint8_t u_list[POOL];   // list of every entry (BUILD .. RANK)
@@ -588,7 +597,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const int base = d ? sh.pref[5 * d - 1] : 0;
             const int mine = t ? sh.pref[t - 1] : 0;
             sh.segoff[d][k] = (int16_t)(mine - base);
-            if (k == 0) { sh.loff[d] = (int16_t)base; sh.lcnt[d] = (int16_t)(sh.pref[t] - base); }
+            if (k == 0) { sh.loff[d] = (int16_t)base; sh.lcnt[d] = (int16_t)(sh.pref[t] - base); sh.nfin[d] = sh.pref[t] - base; }
         }
         if (t == NL * 5) sh.loff[NL] = sh.pref[NL * 5 - 1];
     }
@@ -630,6 +639,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const double vd = (delta > 0) ? (tC[k] + delta) : INFINITY;        // our position inside lane2lane[d]); not chosen -> sorts last
             const int e = lo[k] + so[k] + q;
             sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)d[k];
+            lds_add(&sh.nfin[d[k]], (delta > 0) ? 1 : 0);                       // (unconditional: no guarded block per entry)
         }
     }
 
@@ -641,6 +651,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         for (int e = t; e < M; e += CAP) {
             const int d = sh.u_list[e];
             const double vd = sh.u_vd[e];
+            if (!(vd < INFINITY)) continue;               // not chosen (ref :259-270): not part of the list; the finite entries
+                                                          // occupy the sorted positions [0, nfin[d])
             const int lo = sh.loff[d], hi = sh.loff[d + 1];
             int pos = 0, eq = 0;
             int f = lo;
@@ -658,9 +670,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 #pragma unroll
                 for (int k = 0; k < 7; k++) { pos += (k < n) & (w[k] < vd); eq += (k < n) & (w[k] == vd); }
             }
-            // unchosen entries (vd = +inf) all land on the slot right after the finite ones: one shared
-            // sentinel that ends the walks; their mutual order is irrelevant, so no tie-break for them
-            if (eq > 1 && vd < INFINITY) {                // exact vd ties (rare): lower slot first
+            if (eq > 1) {                                 // exact vd ties (rare): lower slot first
                 const int slot = sh.u_slot[e];
                 for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
             }
@@ -671,66 +681,145 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
     }
 
-    // Predecessor and the 6 nearest of the vehicle at sorted position s of the list [base, base + n): r.kr / r.kv, pr, pvd.
+    // Predecessor and the 6 nearest of the vehicle at sorted position s of the list [base, base + n) (n = its entries, all
+    // with finite distances, n >= 1: the ego's own entry): r.kr / r.kv, pr, pvd.
     // Shared by the 12-lane WALK and the general-geometry kernel (per-route lists, pve_tick_geo.h).
+    //
+    // The 6 nearest in the reference's stable |vd - vd_self| sort = the 6 smallest keys (|d|, vd, slot) (ref :1383-1397).
+    // Both sides of our own position are already sorted by |d|: left = keys below ours (walking left), right = keys above
+    // (walking right); on equal |d| the left entry comes first (smaller vd, or equal vd and smaller slot).
+    // FAST PATH: every candidate of the prefetched 6 + 6 window becomes ONE 32-bit key: the float32 image of |d| (rounding
+    // is monotone, non-negative floats order like unsigned integers) with its low 4 bits replaced by the candidate code
+    // (0..5 = walking index on the left, 8..13 = 8 + index on the right).  min(L_i, R_5-i) are the 6 smallest overall
+    // (first half of a bitonic merge), a 12-comparator network sorts them: one v_min_u32 + one v_max_u32 per comparator
+    // instead of a float64 compare and six selects.  The result is exact when (a) the 6 (winner, loser) pairs of the merge
+    // step differ in the upper 28 bits, (b) the float64 distances of the sorted winners do not decrease (checked on the
+    // values that are read for the output anyway) and (c) no two LEFT neighbours (incl. the first one beyond the window)
+    // share the same vd (such a run is emitted in ascending slot, i.e. against the walking direction).  Anything else
+    // -- near ties, ~1e-6 relative, or equal-vd runs -- takes walk_window_exact below, which decides on float64 keys.
+    static PVE_HD unsigned f32_bits(float x)
+    {
+#if PVE_DEVICE_CODE
+        return __float_as_uint(x);
+#else
+        unsigned u; memcpy(&u, &x, 4); return u;
+#endif
+    }
+    static PVE_HD unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+    static PVE_HD unsigned umax(unsigned a, unsigned b) { return a < b ? b : a; }
     static PVE_HD void walk_window(Sh &sh, int base, int n, int s, double ps, Regs &r, int &pr, double &pvd)
     {
         const uint16_t *sidx = sh.s_idx + base;      // sorted position -> entry
 #define sv(pos_) (Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base + (pos_) : 0] : sh.u_vd[sidx[pos_]])
 #define ss(pos_) (Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base + (pos_) : 0] : sh.u_slot[sidx[pos_]])
-        // All window reads are UNCONDITIONAL on clamped positions and the validity is applied to the values afterwards: a
+        // All window reads are UNCONDITIONAL on clamped positions and the validity is applied to the keys afterwards: a
         // guarded LDS read is a basic block of its own (index read, wait, value read, wait) and thirteen of them in a row
-        // are twenty-six serial LDS round trips; this way the 13 index reads go out back to back, then the 26 value reads.
+        // are twenty-six serial LDS round trips; this way the 13 index reads go out back to back, then the value reads.
         // Only the distances of the window are read (and the predecessor's slot): validity follows from the positions,
         // the slots of the 6 winners are read once they are known.
-        double lv[NNB + 1]; bool lok[NNB];
-        double rv[NNB]; bool rok[NNB];
-        {
-            const int last = n - 1;                       // (n >= 1: the ego's own entry)
-            double lraw[NNB + 1];
-            double rraw[NNB];
-            int prs = -1;
+        const int last = n - 1;
+        double lraw[NNB + 1], rraw[NNB];
+        int prs = -1;
 #pragma unroll
-            for (int i = 0; i < NNB + 1; i++) {
-                const int pos = s - 1 - i, pc = pos >= 0 ? pos : 0;
-                lraw[i] = sv(pc);
-                if (i == 0) prs = (int)ss(pc);
-            }
-#pragma unroll
-            for (int i = 0; i < NNB; i++) {
-                const int pos = s + 1 + i, pc = pos <= last ? pos : last;
-                rraw[i] = sv(pc);
-            }
-            if (Sh::PIN_READS) {                          // (not in the general-geometry kernel: more spills there)
-#pragma unroll
-                for (int i = 0; i < NNB + 1; i++) PVE_PIN(lraw[i]);
-#pragma unroll
-                for (int i = 0; i < NNB; i++) PVE_PIN(rraw[i]);
-                PVE_PIN(prs);
-            }
-#pragma unroll
-            for (int i = 0; i < NNB + 1; i++) {
-                const bool okl = s - 1 - i >= 0;
-                lv[i] = okl ? lraw[i] : -INFINITY;
-                if (i < NNB) lok[i] = okl;
-            }
-            bool rvalid = true;                                        // everything after the +inf sentinel is stale
-#pragma unroll
-            for (int i = 0; i < NNB; i++) {
-                const double w = (s + 1 + i <= last) ? rraw[i] : INFINITY;
-                rvalid = rvalid && (w < INFINITY);
-                rv[i] = rvalid ? w : INFINITY;
-                rok[i] = rvalid;
-            }
-            pr = (s > 0) ? prs : -1; pvd = (s > 0) ? lv[0] : 0.0;                    // ref :1353-1354
+        for (int i = 0; i < NNB + 1; i++) {
+            const int pos = s - 1 - i, pc = pos >= 0 ? pos : 0;
+            lraw[i] = sv(pc);
+            if (i == 0) prs = (int)ss(pc);
         }
-        // The 6 nearest in the reference's stable |vd - vd_self| sort = the 6 smallest keys (|d|, vd, slot) (ref
-        // :1383-1397).  Both sides of our own position are already sorted by |d|: left = keys below ours (walking
-        // left), right = keys above (walking right); on equal |d| the left entry comes first (smaller vd, or equal
-        // vd and smaller slot).  FAST PATH: merge the prefetched 7+6 window in registers (first half of a bitonic merge
-        // + a 6-input sorting network).  It is exact unless two LEFT neighbours (incl. the first one beyond the window)
-        // share the same vd: such a run must be emitted in ascending slot, i.e. against the walking direction; then the
-        // general pointer walk below is used.
+#pragma unroll
+        for (int i = 0; i < NNB; i++) {
+            const int pos = s + 1 + i, pc = pos <= last ? pos : last;
+            rraw[i] = sv(pc);
+        }
+        if (Sh::PIN_READS) {                          // (not in the general-geometry kernel: more spills there)
+#pragma unroll
+            for (int i = 0; i < NNB + 1; i++) PVE_PIN(lraw[i]);
+#pragma unroll
+            for (int i = 0; i < NNB; i++) PVE_PIN(rraw[i]);
+            PVE_PIN(prs);
+        }
+        pr = (s > 0) ? prs : -1; pvd = (s > 0) ? lraw[0] : 0.0;                      // ref :1353-1354
+        bool amb = false;                             // (bitwise, not short-circuit: six compares, no branches)
+#pragma unroll
+        for (int i = 1; i < NNB + 1; i++) amb = amb | ((s - 1 - i >= 0) & (lraw[i] == lraw[i - 1]));
+        unsigned kl[NNB], kq[NNB];
+#pragma unroll
+        for (int i = 0; i < NNB; i++) {
+            const unsigned cl = (unsigned)i, cr = 8u + (unsigned)i;
+            const unsigned bl = f32_bits((float)fabs(lraw[i] - ps)), br = f32_bits((float)fabs(rraw[i] - ps));   // ref :1388
+            kl[i] = (s - 1 - i >= 0) ? ((bl & ~15u) | cl) : (0xFF800000u | (cl << 4) | cl);
+            kq[i] = (s + 1 + i <= last) ? ((br & ~15u) | cr) : (0xFF800000u | (cr << 4) | cr);
+        }
+        unsigned w[NNB], acc = ~0u;                   // acc = the smallest XOR of a (winner, loser) pair of the merge step
+#pragma unroll
+        for (int i = 0; i < NNB; i++) {
+            const unsigned a = kl[i], b = kq[NNB - 1 - i];
+            w[i] = umin(a, b);
+            acc = umin(acc, a ^ b);
+        }
+#define PVE_CE(A, B) { const unsigned lo_ = umin(w[A], w[B]), hi_ = umax(w[A], w[B]); w[A] = lo_; w[B] = hi_; }
+        PVE_CE(0, 5) PVE_CE(1, 3) PVE_CE(2, 4)
+        PVE_CE(1, 2) PVE_CE(3, 4)
+        PVE_CE(0, 3) PVE_CE(2, 5)
+        PVE_CE(0, 1) PVE_CE(2, 3) PVE_CE(4, 5)
+        PVE_CE(1, 2) PVE_CE(3, 4)
+#undef PVE_CE
+        amb = amb | (acc < 16u);
+        // the winners' slots and distances: 6 index reads back to back, then the 12 value reads (not 6 serial chains)
+        int ei[NNB], sl[NNB]; double vv[NNB];
+#pragma unroll
+        for (int k = 0; k < NNB; k++) {
+            const int code = (int)(w[k] & 15u);
+            const int pos = (code & 8) ? (s - 7 + code) : (s - 1 - code);        // = s + 1 + (code - 8) on the right
+            const int pc = ((int)w[k] >= 0) ? pos : 0;                           // (the keys of absent candidates have bit 31 set)
+            ei[k] = Sh::DIRECT ? (base + pc) : (int)sidx[pc];
+        }
+#pragma unroll
+        for (int k = 0; k < NNB; k++) PVE_PIN(ei[k]);
+#pragma unroll
+        for (int k = 0; k < NNB; k++) {
+            sl[k] = Sh::DIRECT ? (int)sh.s_slot[Sh::DIRECT ? ei[k] : 0] : (int)sh.u_slot[ei[k]];
+            vv[k] = Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? ei[k] : 0] : sh.u_vd[ei[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < NNB; k++) { PVE_PIN(sl[k]); PVE_PIN(vv[k]); }
+        // The order of the winners is the reference's iff their float64 distances do not decrease: keys that differ in
+        // the upper 28 bits are ordered exactly; keys that agree there come left before right (by code), which is right
+        // for an exact |d| tie (the frequent case: equally spaced platoons) and wrong only if the right one is nearer.
+        // (two lefts / two rights are in walking order = ascending |d| anyway)
+        double dk[NNB];
+#pragma unroll
+        for (int k = 0; k < NNB; k++) dk[k] = fabs(vv[k] - ps);
+#pragma unroll
+        for (int k = 1; k < NNB; k++) amb = amb | (((int)w[k] >= 0) & (dk[k] < dk[k - 1]));
+        if (!amb) {
+#pragma unroll
+            for (int k = 0; k < NNB; k++) {
+                const bool ok = (int)w[k] >= 0;
+                r.kr[k] = ok ? sl[k] : -1;
+                r.kv[k] = ok ? vv[k] : 0.0;
+            }
+        } else {
+            walk_window_exact(sh, base, n, s, ps, r);
+        }
+#undef sv
+#undef ss
+    }
+
+    // The same selection decided on the float64 keys (exact |d| ties and near ties; rare): float64 merge + 12-comparator
+    // network, and for runs of equal vd on the left or equal |d| among the winners the general pointer walk.
+    static PVE_HD void walk_window_exact(Sh &sh, int base, int n, int s, double ps, Regs &r)
+    {
+        const uint16_t *sidx = sh.s_idx + base;
+#define sv(pos_) (Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base + (pos_) : 0] : sh.u_vd[sidx[pos_]])
+#define ss(pos_) (Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base + (pos_) : 0] : sh.u_slot[sidx[pos_]])
+        const int last = n - 1;
+        double lv[NNB + 1], rv[NNB];
+#pragma unroll
+        for (int i = 0; i < NNB + 1; i++) { const int pos = s - 1 - i; lv[i] = pos >= 0 ? sv(pos >= 0 ? pos : 0) : -INFINITY; }
+#pragma unroll
+        for (int i = 0; i < NNB; i++) { const int pos = s + 1 + i; rv[i] = pos <= last ? sv(pos <= last ? pos : last) : INFINITY; }
+        const double pvd = lv[0];
         bool tie = false;
 #pragma unroll
         for (int i = 1; i < NNB + 1; i++) tie = tie || (s - 1 - i >= 0 && lv[i] == lv[i - 1]);
@@ -741,9 +830,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         double cd[NNB]; int cc[NNB];
 #pragma unroll
         for (int i = 0; i < NNB; i++) {
-            const double dl = lok[i] ? fabs(lv[i] - ps) : INFINITY;                             // ref :1388
+            const double dl = (s - 1 - i >= 0) ? fabs(lv[i] - ps) : INFINITY;                   // ref :1388
             const int j = NNB - 1 - i;
-            const double dr = rok[j] ? fabs(rv[j] - ps) : INFINITY;
+            const double dr = (s + 1 + j <= last) ? fabs(rv[j] - ps) : INFINITY;
             const bool takeL = dl <= dr;
             cd[i] = takeL ? dl : dr; cc[i] = takeL ? i : (8 + j);
         }
@@ -773,15 +862,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             }
         } else {
             // GENERAL PATH: pointer walk; a run of equal vd on the left is emitted in ascending slot
+#pragma unroll
+            for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
             int hi = s - 1, lo = hi, cur, rr = s + 1;
             if (hi >= 0) { const double vh = pvd; while (lo > 0 && sv(lo - 1) == vh) lo--; }
             cur = lo;
             for (int k = 0; k < NNB; k++) {
                 const bool hasL = hi >= 0;
-                double vR = INFINITY;
-                if (rr < n) vR = sv(rr);
-                const bool hasR = vR < INFINITY;
+                const bool hasR = rr < n;
                 if (!(hasL || hasR)) break;
+                double vR = INFINITY;
+                if (hasR) vR = sv(rr);
                 double vL = 0;
                 if (hasL) vL = sv(cur);
                 const double dL = fabs(vL - ps), dR = fabs(vR - ps);              // ref :1388
@@ -819,12 +910,10 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (!(ctl || head_thread)) return;
         const int lane = r.lane;
         const double ps = r.p;
-        const int base = sh.loff[lane], n = sh.loff[lane + 1] - base;
+        const int base = sh.loff[lane], n = sh.nfin[lane];  // (entries with a finite distance: the sorted list)
         if (head_thread) {                                // persisted for next tick's step (ref :1517)
-            const int e0 = Sh::DIRECT ? 0 : sh.s_idx[base];
-            const double hvd = Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base : 0] : sh.u_vd[n > 0 ? e0 : 0];
-            if (n > 0 && hvd < INFINITY) {
-                const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[e0];
+            if (n > 0) {
+                const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[sh.s_idx[base]];
                 lds_or(&sh.hd.head_valid, 1 << lane);
                 int hl = sh.lane_of[hr];
                 sh.hd.head_lane[lane] = hl;
@@ -902,7 +991,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_effects(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
 #if !PVE_DEVICE_CODE
-        if (t == 0) { sh.red_reward[0] = 0; sh.red_jerk[0] = 0; }   // emulator: block_sum accumulates; storage was segoff
+        if (t == 0) {
+            sh.red_reward[0] = 0; sh.red_jerk[0] = 0;               // emulator: block_sum accumulates; storage was segoff
+            for (int k = 0; k < NW; k++)                            // emulator: vote() ORs bits; storage was nfin
+                sh.m_del[k] = sh.m_fin[k] = sh.m_ctlnow[k] = sh.m_coll[k] = sh.m_lead[k] = sh.m_spawn[k] = 0;
+        }
 #endif
         r.del = 0; r.fin = 0; r.coll_seen = 0; r.coll_fin = 0;
         if (r.alive) {

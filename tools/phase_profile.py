@@ -53,6 +53,9 @@ def main():
     torch.cuda.synchronize()
     env.lib.pve_debug_phase_cycles(env._h, None)
     cyc = buf.sum(0).cpu().numpy().astype(float)
+    if cyc[13] > 0:
+        print("shader clock during the launch: %.0f MHz (s_memtime / 100 MHz wall clock)" % (100.0 * cyc[12] / cyc[13]))
+    cyc[12:] = 0
     waves = a.envs * (a.capacity // 64) * a.ticks
     tot = cyc.sum()
     print("phase                cycles/wave   share")
@@ -62,7 +65,7 @@ def main():
             print("%-18s %12.0f  %6.1f%%" % (name, cyc[k] / waves, 100 * cyc[k] / tot))
     print("%-18s %12.0f  (wall_clock64 ticks, 100 MHz constant clock => x10 ns)" % ("total", tot / waves))
     import numpy as np
-    per_wave = buf.sum(1).cpu().numpy().astype(float) / a.ticks
+    per_wave = buf[:, :12].sum(1).cpu().numpy().astype(float) / a.ticks
     per_env = per_wave.reshape(a.envs, -1).max(1)
     n_alive = env.state_field("meta").ne(0).sum(1).cpu().numpy()
     q = np.percentile(per_env, [0, 10, 50, 90, 99, 100])
