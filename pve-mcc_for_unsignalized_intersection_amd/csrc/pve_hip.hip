@@ -274,9 +274,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     lds_barrier();
     PVE_PHASE_MARK(7)
     B::ph_prefetch_arrival(P, env, t, sh, r, g.lane_num);
-    B::ph_lock(g.base, t, sh, r);
+    B::ph_lock_slot(g.base, t, sh, r);
     lds_barrier();
-    B::ph_lock2(t, sh, r);
+    B::ph_lock2_slot(t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(8)
     T::ph_final(g, P, env, t, sh, r);

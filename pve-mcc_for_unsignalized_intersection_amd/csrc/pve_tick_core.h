@@ -2,8 +2,12 @@
 //
 // One workgroup = one intersection; thread t = vehicle slot t (slots are kept sorted by
 // (lane, j), so "order" in the reference's sequential loops == slot index, and every lane is a
-// contiguous slot range).  The reference's order-dependent (Gauss-Seidel) semantics are turned
-// into closed-form parallel rules:
+// contiguous slot range).  The phases that only concern CONTROLLED vehicles (BUILD, WALK, REWARD, the
+// dead-lock walk, the observation rows) run on a second, dense mapping: thread t also works for the
+// t-th controlled vehicle of the intersection (slot_of[t]).  With ~50 controlled among ~85 alive vehicles
+// in 128 slots all of them fall into the first wave, and the second wave skips those phases (its
+// instructions were issued for a dozen active lanes before).  The reference's order-dependent
+// (Gauss-Seidel) semantics are turned into closed-form parallel rules:
 //   S1-S3  step()            ref traffic_interaction_scene.py:1501-1539  (in-lane brake chain)
 //   SCAN   scene_update()    ref :233-334  (virtual lane, predecessor, 6 nearest, reward, XY hit)
 //   FX     ordered effects   ref :333-359  (collision visibility by order, Done / finish)
@@ -59,6 +63,18 @@ template <int NW> PVE_HD int mask_below(const u64 *m, int t)   // set bits at po
 #pragma unroll
     for (int k = 0; k < NW; k++) c += __builtin_popcountll(m[k] & below_sel(t - k * 64));
     return c;
+}
+// set bits below t where t IS the calling thread: one word read and the wave's own lane-prefix count (v_mbcnt)
+template <int NW> PVE_HD int mask_rank(const u64 *m, int t)
+{
+#if PVE_DEVICE_CODE
+    const u64 w = m[t >> 6];
+    int c = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(w >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)w, 0u));
+    if (NW > 1) c += (t >= 64) ? __builtin_popcountll(m[0]) : 0;
+    return c;
+#else
+    return mask_below<NW>(m, t);
+#endif
 }
 template <int NW> PVE_HD int mask_count(const u64 *m)
 {
@@ -165,6 +181,7 @@ template <int CAP> struct Shared {
     // distances: 4.4 KB less LDS = 10 instead of 8 workgroups per CU).  CAP = 64: LDS does not limit residency there
     // (16 one-wave workgroups per CU either way), so the sorted copy is kept and WALK reads it without the index hop.
     static constexpr bool DIRECT = (CAP == 64);
+    static constexpr bool DENSE = true;       // controlled-vehicle phases on the dense mapping (see the top of this file)
     EnvHeader hd;
     double p[CAP], v[CAP], a[CAP];   // post-step kinematics of every slot
     union {                          // p1/v1 die at the barrier after S3, the lists are born after it
@@ -188,6 +205,9 @@ template <int CAP> struct Shared {
     {
         return K < 4 ? u_vd + (K + 1) * CAP : (K == SF_P ? u_vd : (K == SF_V ? v : a));
     }
+    // FX -> LOCK: what FX decided about the reward of the vehicle in slot t (0 = keep, 1 = -10, 2 = +5), for the dense
+    // thread that holds the reward; u_list[CAP ..) is free between RANK and the EARLY staging of FIN
+    PVE_HD uint8_t *fxcode() { return u_list + CAP; }
     template <int K> PVE_HD int *sti()   // K = I_ID .. I_HDR
     {
         if (DIRECT) return (int *)s_vd + K * CAP;
@@ -220,11 +240,13 @@ template <int CAP> struct Shared {
         alignas(8) uint8_t u_list[POOL];   // list of every entry (BUILD .. RANK)
         uint8_t lk_slot[POOL];       // dead-lock scratch: slot of the record filed at each rank (LOCK2 .. FIN)
     };
-    union {
-        int16_t mypos[CAP];          // position of each controlled vehicle inside its own lane's list (RANK .. WALK)
-        int16_t cyc_off[CAP];        // scratch offset of the dead-lock cycle led by slot t (LOCK .. FIN)
+    union {                          // (both < CAP: a list holds a vehicle at most once, the cycles claim <= one unit per member)
+        uint8_t mypos[CAP];          // position of each controlled vehicle inside its own lane's list (RANK .. WALK)
+        uint8_t cyc_off[CAP];        // scratch offset of the dead-lock cycle led by slot t (LOCK .. FIN)
     };
-    int16_t lcnt[NL];                // controlled vehicles per lane
+    uint8_t slot_of[CAP];            // dense mapping: slot of the c-th controlled vehicle (S2 .. FIN)
+    int16_t cstart[NL + 1];          // controlled vehicles in the lanes below d = dense index of lane d's first one
+                                     // (cstart[d + 1] - cstart[d] = controlled vehicles of lane d = the own segment of list d)
 #if !PVE_DEVICE_CODE
     int emu_scan;                    // emulator-only accumulator of wave_incl_scan
 #endif
@@ -239,7 +261,7 @@ template <int CAP> struct Shared {
         double act_next[CAP];        // k_rollout: the NEXT tick's action of every slot, prefetched under the tail of this tick
     };
     double tabA[2][4], tabB[2][4], tabC[2][4];   // get_virtual_distance table (copy of Const, lane-indexed reads; BUILD only)
-    alignas(4) int8_t l2l[NL][4], l2l_inv[NL][4];   // (rows are read as one dword)
+    alignas(4) uint8_t l2lp[NL][4];  // lane2lane[d][k] (15 = none) | our position inside lane2lane[that lane] << 4 (rows are read as one dword)
     int lead_n;                      // scratch units claimed by the dead-lock cycles
 };
 
@@ -257,6 +279,10 @@ struct Regs {
     int cyc;                         // dead-lock cycle membership: bit0 | len << 1 | rank << 5 | leader slot << 9
     int intent, route, ord;          // general-geometry path only (intention, direction[lane][intention], processing order)
     int mmask;                       // general-geometry path only: bit d = member of list d (COUNT .. FILL)
+    // dense mapping (12-lane kernels): thread t = the t-th controlled vehicle of the intersection.  reward / kr / kv / hdr /
+    // cyc above belong to THAT vehicle there (the general-geometry kernel keeps them per slot)
+    int dctl, ds, dlane;             // t < number of controlled vehicles; its slot and lane
+    double dp, djerk, dcloser;       // its position, this tick's jerk (handed over through virdis), closer_p (ref :302)
     double act;                      // this tick's action of the slot (loaded with the state, used by S1)
     double next_arr;                 // lane t < 12 that spawns: its next arrival time (loaded in LOCK, stored in FIN)
     double act_nx;                   // k_rollout: next tick's action of this slot (global load in flight under FX .. LOCK2)
@@ -494,8 +520,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             sh.tabC[t >> 2][t & 3] = c.vdC[t >> 2][t & 3];
         }
         if (t < NL * 4) {
-            sh.l2l[t >> 2][t & 3] = c.l2l[t >> 2][t & 3];
-            sh.l2l_inv[t >> 2][t & 3] = c.l2l_inv[t >> 2][t & 3];
+            const int L = c.l2l[t >> 2][t & 3];
+            sh.l2lp[t >> 2][t & 3] = (uint8_t)((L < 0 ? 15 : L) | ((c.l2l_inv[t >> 2][t & 3] & 3) << 4));
         }
     }
 
@@ -549,6 +575,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                  (brake_needed(c, r.p, r.v, sh.p1[t - 1], sh.v1[t - 1]) << 1);
         }
         sh.bb[t] = (uint8_t)bb;
+        if constexpr (Sh::DENSE) {                        // dense mapping: the c-th controlled vehicle lives in slot t
+            if (r.alive && r.ctl) sh.slot_of[mask_rank<NW>(sh.m_ctl, t)] = (uint8_t)t;
+        }
     }
 
     // ============================================================== S3: resolve the in-lane chain
@@ -579,9 +608,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         int cnt = 0;
         if (t < NL * 5) {                                 // lane t: segment k of list d
             const int d = t / 5, k = t - d * 5;
-            const int L = (k == 0) ? d : (int)sh.l2l[d][k - 1];
-            if (L >= 0)
-                cnt = mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L + 1]) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[L]);
+            const int Lp = (k == 0) ? d : (int)(sh.l2lp[d][k == 0 ? 0 : k - 1] & 15);
+            if (Lp != 15) {
+                const int b0 = mask_below<NW>(sh.m_ctl, sh.hd.lane_start[Lp]);
+                cnt = mask_below<NW>(sh.m_ctl, sh.hd.lane_start[Lp + 1]) - b0;
+                if (k == 0) { sh.cstart[d] = (int16_t)b0; if (d == NL - 1) sh.cstart[NL] = (int16_t)(b0 + cnt); }
+            }
         }
 #if PVE_DEVICE_CODE
         const int incl = wave_incl_scan(t, cnt, nullptr);           // all 60 segments live in wave 0
@@ -597,7 +629,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const int base = d ? sh.pref[5 * d - 1] : 0;
             const int mine = t ? sh.pref[t - 1] : 0;
             sh.segoff[d][k] = (int16_t)(mine - base);
-            if (k == 0) { sh.loff[d] = (int16_t)base; sh.lcnt[d] = (int16_t)(sh.pref[t] - base); sh.nfin[d] = sh.pref[t] - base; }
+            if (k == 0) { sh.loff[d] = (int16_t)base; sh.nfin[d] = sh.pref[t] - base; }   // (own segment: all finite)
         }
         if (t == NL * 5) sh.loff[NL] = sh.pref[NL * 5 - 1];
     }
@@ -607,23 +639,30 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_build(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         sh.rew_ovr[t] = 0; sh.hdr[t] = -1;                // their storage was bb / pref until the barrier before BUILD
-        sh.virdis[t] = r.vir_dis;                         // carried in LDS, not in a register (WALK overwrites it for the
-                                                          // controlled vehicles, FIN reads it back): 2 VGPRs less across the phases
-        if (!(r.alive && r.ctl)) return;
-        const int lane = r.lane;
-        get_xy_f32(c, r.p, lane, sh.xy32[t][0], sh.xy32[t][1]);
-        const int q = mask_below<NW>(sh.m_ctl, t) - mask_below<NW>(sh.m_ctl, sh.hd.lane_start[lane]);
+        // carried in LDS, not in a register (WALK overwrites it for the controlled vehicles, FIN reads it back).  A controlled
+        // vehicle's old vir_dis is dead (ref :1348-1354 rewrite it): its cell hands this tick's jerk to the dense thread.
+        sh.virdis[t] = (r.alive && r.ctl) ? r.jerk : r.vir_dis;
+        // ---- dense mapping from here: thread t works for the t-th controlled vehicle
+        r.dctl = t < mask_count<NW>(sh.m_ctl);
+        r.ds = 0; r.dlane = 0; r.dp = 0;
+        if (!r.dctl) return;
+        const int sl = sh.slot_of[t];
+        const int lane = sh.lane_of[sl];
+        const double p = sh.p[sl];
+        r.ds = sl; r.dlane = lane; r.dp = p;
+        get_xy_f32(c, p, lane, sh.xy32[sl][0], sh.xy32[sl][1]);
+        const int q = t - sh.cstart[lane];                    // its rank among the controlled vehicles of its lane
         {
             const int e = sh.loff[lane] + q;                  // own lane: vd = p (ref :242-249)
-            sh.u_vd[e] = r.p; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)lane;
+            sh.u_vd[e] = p; sh.u_slot[e] = (uint8_t)sl; sh.u_list[e] = (uint8_t)lane;
         }
         if (lane % 3 == 2) return;                            // right turns conflict with nobody (ref :156)
         // three batches of independent LDS reads (lane tables, distance tables + list offsets), then the writes: written
         // as one loop per k the compiler emits four serial chains of three round trips each
-        const int dpk = *(const int *)sh.l2l[lane], kpk = *(const int *)sh.l2l_inv[lane];   // 4 x int8 each
+        const int pk = *(const int *)sh.l2lp[lane];           // 4 x (lane | position << 4)
         int d[4], kk[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { d[k] = (dpk >> (8 * k)) & 0xff; kk[k] = (kpk >> (8 * k)) & 0xff; }   // (>= 0 on these lanes)
+        for (int k = 0; k < 4; k++) { d[k] = (pk >> (8 * k)) & 15; kk[k] = (pk >> (8 * k + 4)) & 3; }   // (none = 15 never on these lanes)
         double tA[4], tB[4], tC[4]; int lo[4], so[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -635,10 +674,10 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         for (int k = 0; k < 4; k++) { PVE_PIN(tA[k]); PVE_PIN(tB[k]); PVE_PIN(tC[k]); PVE_PIN(lo[k]); PVE_PIN(so[k]); }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const double delta = r.p - tA[k] + tB[k];                          // ref :733-803 (the relation is symmetric: kk =
-            const double vd = (delta > 0) ? (tC[k] + delta) : INFINITY;        // our position inside lane2lane[d]); not chosen -> sorts last
+            const double delta = p - tA[k] + tB[k];                            // ref :733-803 (the relation is symmetric: kk =
+            const double vd = (delta > 0) ? (tC[k] + delta) : INFINITY;        // our position inside lane2lane[d]); not chosen -> never sorted
             const int e = lo[k] + so[k] + q;
-            sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)t; sh.u_list[e] = (uint8_t)d[k];
+            sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)sl; sh.u_list[e] = (uint8_t)d[k];
             lds_add(&sh.nfin[d[k]], (delta > 0) ? 1 : 0);                       // (unconditional: no guarded block per entry)
         }
     }
@@ -677,7 +716,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const int myslot = sh.u_slot[e];
             if (Sh::DIRECT) { sh.s_vd[lo + pos] = vd; sh.s_slot[lo + pos] = (uint8_t)myslot; }
             else sh.s_idx[lo + pos] = (uint16_t)e;
-            if (e - lo < sh.lcnt[d]) sh.mypos[myslot] = (int16_t)pos;   // own-lane segment comes first
+            if (e - lo < sh.cstart[d + 1] - sh.cstart[d]) sh.mypos[myslot] = (uint8_t)pos;   // own-lane segment comes first
         }
     }
 
@@ -902,60 +941,58 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // ============================================================== WALK: predecessor, 6 nearest, reward, hit
     static PVE_HD void ph_scan(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
-        r.reward = 0; r.hit = 0; r.hdr = -1;
+        r.reward = 0; r.hit = 0; r.hdr = -1; r.djerk = 0;
 #pragma unroll
         for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
-        const bool ctl = r.alive && r.ctl;
-        const bool head_thread = r.alive && r.j == 0;     // lane non-empty -> its list is rebuilt (ref :234)
-        if (!(ctl || head_thread)) return;
-        const int lane = r.lane;
-        const double ps = r.p;
-        const int base = sh.loff[lane], n = sh.nfin[lane];  // (entries with a finite distance: the sorted list)
-        if (head_thread) {                                // persisted for next tick's step (ref :1517)
-            if (n > 0) {
+        if (t < NL && sh.hd.lane_start[t < NL ? t + 1 : 0] > sh.hd.lane_start[t < NL ? t : 0]) {
+            // thread d < 12: lane d is non-empty -> its list was rebuilt (ref :234); head persisted for next tick's step (ref :1517)
+            const int base = sh.loff[t];
+            if (sh.nfin[t] > 0) {
                 const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[sh.s_idx[base]];
-                lds_or(&sh.hd.head_valid, 1 << lane);
+                lds_or(&sh.hd.head_valid, 1 << t);
                 int hl = sh.lane_of[hr];
-                sh.hd.head_lane[lane] = hl;
-                sh.hd.head_j[lane] = hr - sh.hd.lane_start[hl];
+                sh.hd.head_lane[t] = hl;
+                sh.hd.head_j[t] = hr - sh.hd.lane_start[hl];
             } else {
-                lds_and(&sh.hd.head_valid, ~(1 << lane));
+                lds_and(&sh.hd.head_valid, ~(1 << t));
             }
         }
-        if (!ctl) return;
+        if (!r.dctl) return;
+        const int sl = r.ds, lane = r.dlane;
+        const double ps = r.dp;
+        const int base = sh.loff[lane], n = sh.nfin[lane];    // (entries with a finite distance: the sorted list)
         int pr; double pvd;
-        walk_window(sh, base, n, sh.mypos[t], ps, r, pr, pvd);
+        walk_window(sh, base, n, sh.mypos[sl], ps, r, pr, pvd);
         // ref :1348-1354
         r.hdr = pr;
-        r.vir_dis = (pr >= 0) ? (ps - pvd) : 100.0;
-        sh.hdr[t] = (int16_t)pr;
-        sh.virdis[t] = r.vir_dis;
-        r.count += 1;                                                             // ref :292
+        const double vd = (pr >= 0) ? (ps - pvd) : 100.0;
+        r.djerk = sh.virdis[sl];                              // (parked there by the slot's thread in BUILD)
+        sh.hdr[sl] = (int16_t)pr;
+        sh.virdis[sl] = vd;
     }
 
     // ============================================================== REWARD: reward terms + XY collision test
     static PVE_HD void ph_reward(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
-        if (!(r.alive && r.ctl)) return;
-        const int lane = r.lane;
-        const double ps = r.p;
-        const double myv = sh.v[t];                       // (published in S3: v and a are not carried in registers through WALK)
+        r.dcloser = 150;
+        if (!r.dctl) return;
+        const int sl = r.ds, lane = r.dlane;
+        const double ps = r.dp;
+        const double myv = sh.v[sl];                      // (published in S3)
         // ref :280-310
         double t_distance = 2, d_distance = 10;
         const int n0 = r.kr[0];
         if (n0 >= 0) {
             const double vdn = r.kv[0];
             d_distance = fabs(ps - vdn);
-            r.closer_p = vdn;
+            r.dcloser = vdn;
             if (d_distance != 0) t_distance = (ps - vdn) / (myv - sh.v[n0] + 0.0001);
-        } else {
-            r.closer_p = 150;
         }
         // ref :311-320
         double r_ = 0;
         if (0 < t_distance && t_distance < 4) r_ += reward_coth_term(t_distance);
         // divisions by constants become multiplications in these reward-only terms (no decision reads them)
-        const double jd = r.jerk * c.inv_dt;
+        const double jd = r.djerk * c.inv_dt;
         r_ -= jd * jd * (3.0 / 3600.0);
         if (d_distance < 10) {
             double q1 = d_distance * 0.1, q2 = q1 * q1;
@@ -964,13 +1001,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         r_ += (myv - c.vm) * c.inv_span * 2.0;
         r_ = (r_ > -20) ? r_ : -20;
         r.reward = (r_ < 20) ? r_ : 20;
-        r.jerk_sum += fabs(jd);                                                   // ref :321
         // ref :322-334
         // pre-filter in single precision: the exact FP64 positions (two divisions + polynomials each) are only
         // evaluated when the pair is within 5 cm of the threshold band -- the decision itself is always FP64
         bool near = false;
         if (n0 >= 0) {
-            const float fx = sh.xy32[n0][0] - sh.xy32[t][0], fy = sh.xy32[n0][1] - sh.xy32[t][1];
+            const float fx = sh.xy32[n0][0] - sh.xy32[sl][0], fy = sh.xy32[n0][1] - sh.xy32[sl][1];
             const float lim = (float)c.collision_thr + 0.05f;
             near = fx * fx + fy * fy < lim * lim;
         }
@@ -981,8 +1017,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             double dx = bx - ax, dy = by - ay;
             double dxy = sqrt(dx * dx + dy * dy);
             if (fabs(dxy) < c.collision_thr) {
-                r.hit = 1;
-                lds_add(&sh.cnt[n0], (t < n0) ? 1 : (1 << 16));   // seen by n0 this tick only if we precede it
+                lds_add(&sh.cnt[sl], 1);                          // our own hit (ref :333), seen this tick
+                lds_add(&sh.cnt[n0], (sl < n0) ? 1 : (1 << 16));  // seen by n0 this tick only if we precede it
             }
         }
     }
@@ -998,32 +1034,39 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
 #endif
         r.del = 0; r.fin = 0; r.coll_seen = 0; r.coll_fin = 0;
+        int code = 0;                                     // what happens to the vehicle's reward (held by its dense thread)
         if (r.alive) {
-            const int cc = sh.cnt[t];
+            const int cc = sh.cnt[t];                     // hits: the vehicle's own one and those of the vehicles before it |
+            sh.cnt[t] = 0;                                // those of the vehicles behind it << 16 (the cell is re-used by LOCK)
             const int prev = (r.meta >> M_COLL_SHIFT) & M_COLL_MASK;
-            r.coll_seen = prev + r.hit + (cc & 0xffff);                           // ref :337-340
+            r.coll_seen = prev + (cc & 0xffff);                                   // ref :337-340
             r.coll_fin = r.coll_seen + (cc >> 16);
-            if (r.ctl && r.coll_seen > 0) lds_add(&sh.acc_collisions, r.coll_seen);   // ref :337
+            if (r.ctl) {
+                r.count += 1;                                                     // ref :292
+                r.jerk_sum += fabs(r.jerk * c.inv_dt);                            // ref :321
+                if (r.coll_seen > 0) lds_add(&sh.acc_collisions, r.coll_seen);    // ref :337
+            }
             if (r.p < c.exit_p || r.coll_seen > 0) {                              // ref :341-349
                 r.del = 1;
                 if (r.coll_seen > 0) {
-                    if (r.ctl) r.reward = -10;
+                    if (r.ctl) code = 1;                                          // reward = -10
                     else {                                                        // reward[-1] of someone else
                         int pv = mask_prev<NW>(sh.m_ctl, t);
                         if (pv >= 0) sh.rew_ovr[pv] = 1;
                     }
                 }
                 r.meta |= M_DONE;
-                r.hdr = -1; sh.hdr[t] = -1;
+                sh.hdr[t] = -1;
             } else if (r.p < 0 && (r.meta & M_CONTROL)) {                         // ref :350-359
                 r.fin = 1;
                 r.meta |= M_DONE | M_FINISH;
                 r.meta &= ~(M_CONTROL | M_LOCK);
-                r.hdr = -1; sh.hdr[t] = -1;
-                r.reward = 5;
+                sh.hdr[t] = -1;
+                code = 2;                                                         // reward = 5
                 lds_add(&sh.acc_passed_steps, r.step);
             }
         }
+        sh.fxcode()[t] = (uint8_t)code;
         vote<NW>(sh.m_del, t, r.del);
         vote<NW>(sh.m_fin, t, r.fin);
         vote<NW>(sh.m_ctlnow, t, r.alive && !r.del && (r.meta & M_CONTROL));
@@ -1043,6 +1086,59 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
     }
     static PVE_HD void ph_lock(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
+    {
+        if (r.dctl) {                                     // what FX decided for the vehicle's reward (ref :346, :357; reward[-1] -> rew_ovr)
+            const int fx = sh.fxcode()[r.ds];
+            const bool m10 = (sh.rew_ovr[r.ds] != 0) | (fx == 1);
+            r.reward = m10 ? -10.0 : (fx == 2 ? 5.0 : r.reward);
+        }
+        block_sum(sh.red_reward, t, r.dctl ? r.reward : 0.0);
+        block_sum(sh.red_jerk, t, r.fin ? r.jerk_sum : 0.0);                      // ref :358
+        // Dead-lock scan (ref :365-370, :1469-1499), member-parallel: every controlled vehicle follows the
+        // virtual-header pointers for <= 10 hops; if the walk returns to itself it is on a cycle.  Cycles are rare:
+        // the first walk only chases pointers; a member then walks its cycle again and learns the smallest slot (= the
+        // member that discovers the cycle in the reference's (lane, j) scan order) and its own rank in the reference's
+        // sorted record list [vir_dis, lane, j, ...] (ref :1486-1492).  The first member reserves a scratch range for the
+        // cycle; the verdict word goes to the slot's thread through cnt[] (free since FX).
+        bool lead = false;
+        if (r.dctl && mask_test(sh.m_ctlnow, r.ds)) {
+            const int s0 = r.ds;
+            int cur = s0, len = 0;
+            for (int hop = 0; hop < 10; hop++) {                                  // ref :1470-1478
+                cur = sh.hdr[cur];
+                if (cur < 0) break;
+                if (cur == s0) { len = hop + 1; break; }
+            }
+            if (len) {
+                const double dv = sh.virdis[s0];
+                int mn = s0, rank = 0;
+                cur = s0;
+                for (int hop = 1; hop < len; hop++) {
+                    cur = sh.hdr[cur];
+                    const double d = sh.virdis[cur];
+                    rank += (d < dv || (d == dv && cur < s0)) ? 1 : 0;
+                    mn = cur < mn ? cur : mn;
+                }
+                sh.cnt[s0] = 1 | (len << 1) | (rank << 5) | (mn << 9);
+                lead = (mn == s0);
+                if (lead) sh.cyc_off[s0] = (uint8_t)lds_claim(&sh.lead_n, len);
+            }
+        }
+        vote<NW>(sh.m_lead, t, lead);
+    }
+    // LOCK2 (after a barrier): every cycle member files its record at its rank inside the cycle's scratch range
+    // (u_vd / u_list are dead after the walk phase) = the reference's record_.sort() (ref :1492)
+    static PVE_HD void ph_lock2(int t, Sh &sh, Regs &r)
+    {
+        r.cyc = sh.cnt[t];                                // (0 unless the dense thread of this slot's vehicle found a cycle)
+        if (r.cyc & 1) {
+            const int e = sh.cyc_off[r.cyc >> 9] + ((r.cyc >> 5) & 15);
+            sh.u_vd[e] = sh.virdis[t];
+            sh.lk_slot[e] = (uint8_t)t;
+        }
+    }
+    // the same two phases with everything per slot (general-geometry kernel: no dense mapping there)
+    static PVE_HD void ph_lock_slot(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         if (r.alive && r.ctl && sh.rew_ovr[t]) r.reward = -10;                    // ref :346 via reward[-1]
         block_sum(sh.red_reward, t, (r.alive && r.ctl) ? r.reward : 0.0);
@@ -1069,14 +1165,14 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             if (found) {
                 r.cyc = 1 | (len << 1) | (rank << 5) | (mn << 9);
                 lead = (mn == t);
-                if (lead) sh.cyc_off[t] = (int16_t)lds_claim(&sh.lead_n, len);
+                if (lead) sh.cyc_off[t] = lds_claim(&sh.lead_n, len);
             }
         }
         vote<NW>(sh.m_lead, t, lead);
     }
     // LOCK2 (after a barrier): every cycle member files its record at its rank inside the cycle's scratch range
     // (u_vd / u_list are dead after the walk phase) = the reference's record_.sort() (ref :1492)
-    static PVE_HD void ph_lock2(int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_lock2_slot(int t, Sh &sh, Regs &r)
     {
         if (r.cyc & 1) {
             const int e = sh.cyc_off[r.cyc >> 9] + ((r.cyc >> 5) & 15);
@@ -1093,11 +1189,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // (it was not controlled this tick either) also skips jerk_sum / vir_dis / closer_p / count, which only the
     // controlled branch of scene_update touches (ref :292, :302, :321, :1348-1354).
     template <class R> static PVE_HD void store_slot(const PVE_AS4 Params &P, size_t g, const R &r, int meta, int hdr_word,
-                                                     bool with_ids = true, bool with_carry = true)
+                                                     bool with_ids = true, bool with_carry = true, bool with_closer = true)
     {
         P.f64[F_P][g] = r.p; P.f64[F_V][g] = r.v; P.f64[F_A][g] = r.a; P.f64[F_JERK][g] = r.jerk;
         if (with_carry) {
-            P.f64[F_JERK_SUM][g] = r.jerk_sum; P.f64[F_VIR_DIS][g] = r.vir_dis; P.f64[F_CLOSER_P][g] = r.closer_p;
+            P.f64[F_JERK_SUM][g] = r.jerk_sum; P.f64[F_VIR_DIS][g] = r.vir_dis;
+            if (with_closer) P.f64[F_CLOSER_P][g] = r.closer_p;
             P.i32[I_COUNT][g] = r.count;
         }
         if (with_ids) { P.i32[I_ID][g] = r.id; P.i32[I_SEQ][g] = r.seq; P.i32[I_VNUM][g] = r.vnum; }
@@ -1155,17 +1252,18 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 }
             }
             if (r.del) meta |= M_DEL;
-            r.hdr = sh.hdr[t];                             // (kept in LDS since WALK / FX)
-            r.vir_dis = sh.virdis[t];
-            hdr_word = pack_lanej(sh, r.hdr);
+            r.vir_dis = sh.virdis[t];                      // (kept in LDS since WALK / FX, like the header)
+            hdr_word = pack_lanej(sh, sh.hdr[t]);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
+                // (closer_p of a controlled vehicle is with its dense thread, which stores it below)
                 if (!RES)
-                    store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
+                    store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t, !r.ctl);
                 else {                     // EARLY staging: these registers die here, as in the single-tick kernel
                     const int s = new_slot;
                     sh.template stf<Sh::SF_JERK>()[s] = r.jerk; sh.template stf<Sh::SF_JERK_SUM>()[s] = r.jerk_sum;
-                    sh.template stf<Sh::SF_VIR_DIS>()[s] = r.vir_dis; sh.template stf<Sh::SF_CLOSER_P>()[s] = r.closer_p;
+                    sh.template stf<Sh::SF_VIR_DIS>()[s] = r.vir_dis;
+                    if (!r.ctl) sh.template stf<Sh::SF_CLOSER_P>()[s] = r.closer_p;
                     sh.template sti<I_ID>()[s] = r.id; sh.template sti<I_SEQ>()[s] = r.seq; sh.template sti<I_VNUM>()[s] = r.vnum;
                     sh.template sti<I_STEP>()[s] = r.step; sh.template sti<I_COUNT>()[s] = r.count;
                     sh.template sti<I_META>()[s] = meta; sh.template sti<I_HDR>()[s] = hdr_word;
@@ -1268,10 +1366,20 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
         // per-slot outputs other than `flags` are written for the slots that held a vehicle only (`flags` = 0 marks
         // the rest): 36 B x ~43 empty slots per env are 6 MB per launch, i.e. ~0.8 us of store burst
-        if (O.reward && r.alive) O.reward[gpre] = r.ctl ? r.reward : 0.0;
+        if (O.reward && r.alive && !r.ctl) O.reward[gpre] = 0.0;
         if (O.lanej && r.alive) O.lanej[gpre] = (r.lane << 16) | r.j;
         if (O.new_slot && r.alive) O.new_slot[gpre] = new_slot;
-        if (r.alive && r.ctl) {
+        // ---- dense mapping: what the t-th controlled vehicle (slot ds) puts out
+        if (r.dctl) {
+            const int sl = r.ds;
+            const size_t gd = (size_t)env * CAP + sl;                 // pre-compaction indexing, as above
+            int ns = -1;
+            if (mask_test(keep, sl)) ns = mask_below<NW>(keep, sl) + __builtin_popcount(sp & ((1u << r.dlane) - 1u));
+            if (ns >= 0) {                                            // ref :302 (closer_p), stored where the vehicle goes
+                if (RES) sh.template stf<Sh::SF_CLOSER_P>()[ns] = r.dcloser;
+                else P.f64[F_CLOSER_P][(size_t)env * CAP + ns] = r.dcloser;
+            }
+            if (O.reward) O.reward[gd] = r.reward;
             // the 6 neighbours' speed, acceleration, lane and lane start: two batches of unconditional LDS gathers on clamped
             // slots (one guarded block per neighbour = six serial round trips), shared by the neighbour ids and the row
             int xc[NNB], nln[NNB], nls[NNB]; double nv[NNB], na[NNB];
@@ -1280,6 +1388,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 xc[k] = r.kr[k] < 0 ? 0 : r.kr[k];
                 nln[k] = sh.lane_of[xc[k]]; nv[k] = sh.v[xc[k]]; na[k] = sh.a[xc[k]];
             }
+            const double myv = sh.v[sl], mya = sh.a[sl];
 #pragma unroll
             for (int k = 0; k < NNB; k++) { PVE_PIN(nln[k]); PVE_PIN(nv[k]); PVE_PIN(na[k]); }
 #pragma unroll
@@ -1287,37 +1396,37 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 #pragma unroll
             for (int k = 0; k < NNB; k++) PVE_PIN(nls[k]);
             if (O.nbr) {                               // controlled vehicles only (PVE_F_CTL in flags)
-                int *nb = O.nbr + gpre * NNB;
+                int *nb = O.nbr + gd * NNB;
 #pragma unroll
                 for (int k = 0; k < NNB; k++) nb[k] = r.kr[k] < 0 ? -1 : ((nln[k] << 16) | (xc[k] - nls[k]));
             }
-          if (O.obs_pre || (O.obs_post && new_slot >= 0)) {
-            // row 0 of the state, ref :1325-1337
-            double row[OBSW];
-            row[0] = r.p; row[1] = r.v; row[2] = r.a; row[3] = (double)r.lane;
+            if (O.obs_pre || (O.obs_post && ns >= 0)) {
+                // row 0 of the state, ref :1325-1337
+                double row[OBSW];
+                row[0] = r.dp; row[1] = myv; row[2] = mya; row[3] = (double)r.dlane;
 #pragma unroll
-            for (int k = 0; k < NNB; k++) {
-                const bool has = r.kr[k] >= 0;
-                row[4 + 4 * k] = has ? r.kv[k] : 0.0; row[5 + 4 * k] = has ? nv[k] : 0.0;
-                row[6 + 4 * k] = has ? na[k] : 0.0; row[7 + 4 * k] = has ? (double)nln[k] : 0.0;
-            }
-            if (O.obs_pre) {
-                double *o = O.obs_pre + gpre * OBSW;
-#pragma unroll
-                for (int k = 0; k < OBSW; k++) o[k] = row[k];
-            }
-            if (O.obs_post && new_slot >= 0) {
-                if (P.obs_f32) {                    // uniform: float32 rows (half the bytes of the largest output)
-                    float *o = (float *)O.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
-#pragma unroll
-                    for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
-                } else {
-                    double *o = O.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+                for (int k = 0; k < NNB; k++) {
+                    const bool has = r.kr[k] >= 0;
+                    row[4 + 4 * k] = has ? r.kv[k] : 0.0; row[5 + 4 * k] = has ? nv[k] : 0.0;
+                    row[6 + 4 * k] = has ? na[k] : 0.0; row[7 + 4 * k] = has ? (double)nln[k] : 0.0;
+                }
+                if (O.obs_pre) {
+                    double *o = O.obs_pre + gd * OBSW;
 #pragma unroll
                     for (int k = 0; k < OBSW; k++) o[k] = row[k];
                 }
+                if (O.obs_post && ns >= 0) {
+                    if (P.obs_f32) {                    // uniform: float32 rows (half the bytes of the largest output)
+                        float *o = (float *)O.obs_post + ((size_t)env * CAP + ns) * OBSW;
+#pragma unroll
+                        for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
+                    } else {
+                        double *o = O.obs_post + ((size_t)env * CAP + ns) * OBSW;
+#pragma unroll
+                        for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                    }
+                }
             }
-          }
         }
     }
     // the tick kernel's FIN
@@ -1447,16 +1556,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // Runs after a workgroup barrier + fence so that obs_pre rows of the other threads are visible.
     static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
-        if (!P.out.state_pre || !(r.alive && r.ctl)) return;
+        if (!P.out.state_pre || !r.dctl) return;          // (dense mapping: the rows of the vehicle in slot ds)
         const size_t base = (size_t)env * CAP;
-        double *dst = P.out.state_pre + (base + t) * (size_t)((NNB + 1) * OBSW);
-        const double *own = P.out.obs_pre + (base + t) * OBSW;
+        const int sl = r.ds;
+        double *dst = P.out.state_pre + (base + sl) * (size_t)((NNB + 1) * OBSW);
+        const double *own = P.out.obs_pre + (base + sl) * OBSW;
         for (int k = 0; k < OBSW; k++) dst[k] = own[k];
         for (int q = 0; q < NNB; q++) {
             const int x = r.kr[q];
             double *row = dst + (q + 1) * OBSW;
             if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = 0.0; continue; }
-            const double *src = (x < t) ? (P.out.obs_pre + (base + x) * OBSW)
+            const double *src = (x < sl) ? (P.out.obs_pre + (base + x) * OBSW)
                                         : (P.out.obs_prev_post + (base + x) * OBSW);
             for (int k = 0; k < OBSW; k++) row[k] = src[k];
         }

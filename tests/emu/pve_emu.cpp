@@ -117,8 +117,8 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_reward(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_effects(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_prefetch_arrival(P, env, t, sh, regs[t], g.lane_num);
-        for (int t = 0; t < CAP; t++) B::ph_lock(g.base, t, sh, regs[t]);
-        for (int t = 0; t < CAP; t++) B::ph_lock2(t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) B::ph_lock_slot(g.base, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) B::ph_lock2_slot(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_final(g, P, env, t, sh, regs[t]);
         if (P.out.state_pre)
             for (int t = 0; t < CAP; t++) T::ph_state(P, env, t, sh, regs[t]);
