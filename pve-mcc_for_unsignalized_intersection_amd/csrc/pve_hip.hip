@@ -195,12 +195,17 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         PVE_PHASE_MARK(8)
         T::ph_park_action(t, sh, r);
         const Outputs O = T::tick_outputs(P, R, k);
-        T::template ph_final<true>(c, P, O, env, t, sh, r, fc);
+        T::template ph_final<true>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks);
         PVE_PHASE_MARK(9)
-        lds_barrier();                                // A: nobody reads the tick's work arrays any more
-        T::ph_stage(c, t, sh, r, fc);
-        lds_barrier();                                // B: the staging area is complete
-        if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
+        if (fc.still) {                               // (uniform) nobody moves: the registers carry over
+            T::ph_stage_header(t, sh, fc);
+            T::ph_carry_over(t, sh, r, fc);
+        } else {
+            lds_barrier();                            // A: nobody reads the tick's work arrays any more
+            T::ph_stage(c, t, sh, r, fc);
+            lds_barrier();                            // B: the staging area is complete
+            if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
+        }
         PVE_PHASE_MARK(10)
     }
     {

@@ -290,6 +290,7 @@ struct Regs {
 // k_rollout: what FIN hands over to the staging step behind the next barrier (values read from the header / the work
 // arrays before anybody rewrites them)
 struct FinCarry {
+    int still, meta;                 // nobody moves this tick (uniform): registers carry over, `meta` = the slot's new flags word
     int new_slot;                    // of the vehicle in slot t (< 0: deleted or empty)
     int ls;                          // t <= NL: lane_start[t] after re-pack + spawn
     int sp_slot, sp_id, sp_vnum;     // t < NL: slot / id / id_info[1] of the vehicle lane t spawns (sp_slot < 0: none)
@@ -1091,6 +1092,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const int fx = sh.fxcode()[r.ds];
             const bool m10 = (sh.rew_ovr[r.ds] != 0) | (fx == 1);
             r.reward = m10 ? -10.0 : (fx == 2 ? 5.0 : r.reward);
+            ((double *)sh.xy32)[r.ds] = r.dcloser;        // closer_p (ref :302) back to the slot's thread; xy32 is dead after REWARD
         }
         block_sum(sh.red_reward, t, r.dctl ? r.reward : 0.0);
         block_sum(sh.red_jerk, t, r.fin ? r.jerk_sum : 0.0);                      // ref :358
@@ -1131,6 +1133,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_lock2(int t, Sh &sh, Regs &r)
     {
         r.cyc = sh.cnt[t];                                // (0 unless the dense thread of this slot's vehicle found a cycle)
+        if (r.alive && r.ctl) r.closer_p = ((double *)sh.xy32)[t];
         if (r.cyc & 1) {
             const int e = sh.cyc_off[r.cyc >> 9] + ((r.cyc >> 5) & 15);
             sh.u_vd[e] = sh.virdis[t];
@@ -1189,12 +1192,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // (it was not controlled this tick either) also skips jerk_sum / vir_dis / closer_p / count, which only the
     // controlled branch of scene_update touches (ref :292, :302, :321, :1348-1354).
     template <class R> static PVE_HD void store_slot(const PVE_AS4 Params &P, size_t g, const R &r, int meta, int hdr_word,
-                                                     bool with_ids = true, bool with_carry = true, bool with_closer = true)
+                                                     bool with_ids = true, bool with_carry = true)
     {
         P.f64[F_P][g] = r.p; P.f64[F_V][g] = r.v; P.f64[F_A][g] = r.a; P.f64[F_JERK][g] = r.jerk;
         if (with_carry) {
-            P.f64[F_JERK_SUM][g] = r.jerk_sum; P.f64[F_VIR_DIS][g] = r.vir_dis;
-            if (with_closer) P.f64[F_CLOSER_P][g] = r.closer_p;
+            P.f64[F_JERK_SUM][g] = r.jerk_sum; P.f64[F_VIR_DIS][g] = r.vir_dis; P.f64[F_CLOSER_P][g] = r.closer_p;
             P.i32[I_COUNT][g] = r.count;
         }
         if (with_ids) { P.i32[I_ID][g] = r.id; P.i32[I_SEQ][g] = r.seq; P.i32[I_VNUM][g] = r.vnum; }
@@ -1212,9 +1214,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // RES = false: the tick kernel -- state and header go back to HBM (`O` = P.out).
     // RES = true:  k_rollout -- outputs only (`O` = this tick's block of the output buffers); the persistent fields and
     //              the header updates are handed to ph_stage through `fc` and stay on the chip.
+    // k_rollout, `still` ticks: when nobody is deleted and nobody spawns every vehicle keeps its slot, so nothing has to
+    // move: no staging, no barriers A / B, no reload -- the registers simply carry over (about every second tick at the bench
+    // load).  `full` (uniform) forces the staged form: the last tick of a launch, whose state FLUSH takes from the staging area.
     template <bool RES, class OutT>
     static PVE_HD void ph_final(const PVE_AS4 Const &c, const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh,
-                                Regs &r, FinCarry &fc)
+                                Regs &r, FinCarry &fc, bool full = true)
     {
         EnvHeader &gh = P.headers[env];
         const int N = sh.hd.n_alive;
@@ -1230,6 +1235,10 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         u64 keep[NW];
 #pragma unroll
         for (int k = 0; k < NW; k++) keep[k] = fused ? (sh.m_alive[k] & ~sh.m_del[k]) : sh.m_alive[k];
+        bool still = RES && !full && sp == 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) still = still && (sh.m_del[k] == 0);
+        fc.still = still; fc.meta = 0;
         // ---- per-slot meta
         int meta = 0, hdr_word = -1, new_slot = -1, lockf = 0;
         if (r.alive) {
@@ -1252,18 +1261,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 }
             }
             if (r.del) meta |= M_DEL;
+            fc.meta = meta;
             r.vir_dis = sh.virdis[t];                      // (kept in LDS since WALK / FX, like the header)
             hdr_word = pack_lanej(sh, sh.hdr[t]);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
-                // (closer_p of a controlled vehicle is with its dense thread, which stores it below)
                 if (!RES)
-                    store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t, !r.ctl);
-                else {                     // EARLY staging: these registers die here, as in the single-tick kernel
+                    store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
+                else if (!still) {         // EARLY staging: these registers die here, as in the single-tick kernel
                     const int s = new_slot;
                     sh.template stf<Sh::SF_JERK>()[s] = r.jerk; sh.template stf<Sh::SF_JERK_SUM>()[s] = r.jerk_sum;
-                    sh.template stf<Sh::SF_VIR_DIS>()[s] = r.vir_dis;
-                    if (!r.ctl) sh.template stf<Sh::SF_CLOSER_P>()[s] = r.closer_p;
+                    sh.template stf<Sh::SF_VIR_DIS>()[s] = r.vir_dis; sh.template stf<Sh::SF_CLOSER_P>()[s] = r.closer_p;
                     sh.template sti<I_ID>()[s] = r.id; sh.template sti<I_SEQ>()[s] = r.seq; sh.template sti<I_VNUM>()[s] = r.vnum;
                     sh.template sti<I_STEP>()[s] = r.step; sh.template sti<I_COUNT>()[s] = r.count;
                     sh.template sti<I_META>()[s] = meta; sh.template sti<I_HDR>()[s] = hdr_word;
@@ -1375,10 +1383,6 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const size_t gd = (size_t)env * CAP + sl;                 // pre-compaction indexing, as above
             int ns = -1;
             if (mask_test(keep, sl)) ns = mask_below<NW>(keep, sl) + __builtin_popcount(sp & ((1u << r.dlane) - 1u));
-            if (ns >= 0) {                                            // ref :302 (closer_p), stored where the vehicle goes
-                if (RES) sh.template stf<Sh::SF_CLOSER_P>()[ns] = r.dcloser;
-                else P.f64[F_CLOSER_P][(size_t)env * CAP + ns] = r.dcloser;
-            }
             if (O.reward) O.reward[gd] = r.reward;
             // the 6 neighbours' speed, acceleration, lane and lane start: two batches of unconditional LDS gathers on clamped
             // slots (one guarded block per neighbour = six serial round trips), shared by the neighbour ids and the row
@@ -1488,6 +1492,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             sh.hd.next_arr[t] = r.next_arr;
         }
         if (t <= NL) sh.hd.lane_start[t] = fc.ls;
+        ph_stage_header(t, sh, fc);
+    }
+    // the accumulators of the header: only thread 0 reads or writes them, so a still tick needs no barrier around this
+    static PVE_HD void ph_stage_header(int t, Sh &sh, const FinCarry &fc)
+    {
         if (t == 0) {
             sh.hd.n_alive = fc.n_post;
             sh.hd.id_seq += fc.n_sp;
@@ -1502,6 +1511,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             sh.hd.locks += fc.n_lock;
             sh.hd.overflow += fc.n_over;
         }
+    }
+    // a still tick: the vehicle stays in the registers, only the flags word and the next action change hands
+    static PVE_HD void ph_carry_over(int t, Sh &sh, Regs &r, const FinCarry &fc)
+    {
+        r.meta = fc.meta;
+        r.act = sh.act_next[t];                           // (parked by this very thread at the top of FIN)
     }
     // RELOAD (after barrier B): slot t's vehicle from the staging arrays, its action from the prefetch
     static PVE_HD void ph_reload(int t, Sh &sh, Regs &r)
