@@ -68,9 +68,12 @@ template <int NW> PVE_HD int mask_below(const u64 *m, int t)   // set bits at po
 template <int NW> PVE_HD int mask_rank(const u64 *m, int t)
 {
 #if PVE_DEVICE_CODE
-    const u64 w = m[t >> 6];
+    // (NW <= 2; both words are read and selected: m may live in registers, where a per-lane index would go through scratch)
+    const u64 w0 = m[0], w1 = m[NW - 1];
+    const bool up = NW > 1 && t >= 64;
+    const u64 w = up ? w1 : w0;
     int c = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(w >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)w, 0u));
-    if (NW > 1) c += (t >= 64) ? __builtin_popcountll(m[0]) : 0;
+    c += up ? __builtin_popcountll(w0) : 0;
     return c;
 #else
     return mask_below<NW>(m, t);
@@ -1265,7 +1268,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             r.vir_dis = sh.virdis[t];                      // (kept in LDS since WALK / FX, like the header)
             hdr_word = pack_lanej(sh, sh.hdr[t]);
             if (mask_test(keep, t)) {
-                new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
+                new_slot = mask_rank<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
                 if (!RES)
                     store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
                 else if (!still) {         // EARLY staging: these registers die here, as in the single-tick kernel
