@@ -273,13 +273,13 @@ def main(argv=None, env_factory=None):
         # LOAD / FIN bursts of one sub-batch overlap the compute phases of the other), DESIGN.md 5
         env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=n_sub, device=dev, outputs=outputs,
                                                  lane_num=lane_num, intentions=choice, obs_dtype=obs_dtype)
-    # auto: pve_step_many (state resident on the chip, host out of the loop) where it is the faster product path --
-    # capacity 64 always (one wave per intersection, all 4096 resident at once: 16.3 vs 21.9 us per tick); capacity 128
-    # when the timed region is long enough for launches of 25 ticks per sub-batch to keep the chip full (36.1 vs 36.9 us);
-    # short runs use one pve_step_all launch per tick and sub-batch (finer launch granularity, shorter tail)
-    mode = args.mode or ("rollout" if (not emu and lane_num == 12 and not args.actor and (cap == 64 or K >= 100)) else "step")
+    # auto: pve_step_many (state resident on the chip, host out of the loop) is the faster product path for the 12-lane
+    # layout -- capacity 64: one wave per intersection, all 4096 resident at once (14.8 vs 20.6 us per tick); capacity 128:
+    # launches of 25 ticks per sub-batch keep the chip full (30.0 vs 32.9 us); a short timed region (the driver's --steps
+    # 20) takes launches of 5 ticks so that the two sub-batches still interleave (35.3 vs 36.6 us incl. fill and drain)
+    mode = args.mode or ("rollout" if (not emu and lane_num == 12 and not args.actor) else "step")
     if mode == "rollout" and args.chunk == 0 and cap == 128:
-        args.chunk = 25
+        args.chunk = 25 if K >= 100 else 5
     if mode == "rollout" and not hasattr(env, "step_many"):
         sys.exit("--mode rollout: this build has no pve_step_many")
     pool = torch.as_tensor(pool_np, device=dev)

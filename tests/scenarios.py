@@ -162,6 +162,7 @@ def check_fuzz_vs_oracle(backend, n_envs, capacity, ticks, rate, seed, action_sc
     b.reset()
     oracles = [OracleEnv(arr[e]) for e in range(n_envs)]
     tot_coll = tot_lock = 0
+    check_fuzz_vs_oracle.max_ctl = 0          # (most controlled vehicles any env held: the dense mapping's second wave)
     for t in range(ticks):
         acts = rng.uniform(-action_scale, action_scale, size=(n_envs, capacity)).astype(np.float32).astype(np.float64)
         if quantize:
@@ -174,6 +175,7 @@ def check_fuzz_vs_oracle(backend, n_envs, capacity, ticks, rate, seed, action_sc
             _vid, ctlm, _ = o.alive_view()
             rec = o.tick(np.where(ctlm != 0, acts[e, :n], 0.0))
             ctl = (flags[e, :n] & 2) != 0
+            check_fuzz_vs_oracle.max_ctl = max(check_fuzz_vs_oracle.max_ctl, int(ctl.sum()))
             assert int(eo[e, 0]) == n and int(ctl.sum()) == len(rec["ids"]), "controlled set: tick %d env %d" % (t, e)
             assert int(eo[e, 2]) == rec["collisions"] and int(eo[e, 3]) == rec["lock"], "counters: tick %d env %d" % (t, e)
             assert np.array_equal(flags[e, :n][ctl] >> 8, rec["coll_pv"]), "coll_pv: tick %d env %d" % (t, e)

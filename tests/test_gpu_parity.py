@@ -141,6 +141,19 @@ def test_gpu_fuzz_random_tapes(seed, rate, cap, quant):
     assert coll > 0 and lock > 0
 
 
+def test_gpu_fuzz_more_than_64_controlled_vehicles():
+    """Dense traffic (1400 / 1500 veh/h/lane, gentle actions): more than 64 controlled vehicles per intersection, i.e. the
+    second wave takes part in the dense-mapped phases; 16 envs vs 16 oracles every tick, no deferred spawn."""
+    for rate, seed in ((1400.0, 5), (1500.0, 6)):
+        scenarios.check_fuzz_vs_oracle(BACKEND, n_envs=16, capacity=128, ticks=420, rate=rate, seed=seed, action_scale=0.3)
+        assert scenarios.check_fuzz_vs_oracle.max_ctl > 64
+
+
+def test_gpu_step_many_in_dense_traffic():
+    """pve_step_many == single ticks bit for bit at 1500 veh/h/lane (more than 64 controlled vehicles, few still ticks)."""
+    scenarios.check_step_many(BACKEND, "pool", n_envs=6, prefill=320, rate=1500.0, chunks=(25, 7), trajectory_chunk=10, seed=9)
+
+
 def test_gpu_reset_replays_the_same_episode():
     scenarios.check_reset_reproducible(BACKEND)
 
