@@ -6,6 +6,9 @@ run() { "$@" 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print(d['config']['mode'], 'ms/step %.4f' % d['ms_per_step'], 'kern %.4f' % d['roofline']['kernel_ms'], 'alive %.1f' % d['mean_alive_per_env'], 'ovf', d['overflow'])"; }
 B="python bench.py --no-cpu-baseline --no-copy-peak"
-echo -n "base rollout p2: "; run $B --mode rollout
-echo -n "exp  rollout p2: "; PVE_LIBRARY_PATH=build/libpveenv_exp.so run $B --mode rollout
-echo -n "exp  rollout p3: "; PVE_LIBRARY_PATH=build/libpveenv_exp.so run $B --mode rollout --pipeline 3
+for lib in "" build/libpveenv_exp.so; do
+  echo "lib: ${lib:-product}"
+  echo -n "  lanes8 p3: "; PVE_LIBRARY_PATH=$lib run $B --lane-num 8 --pipeline 3 --steps 300
+  echo -n "  lanes8 p2: "; PVE_LIBRARY_PATH=$lib run $B --lane-num 8 --pipeline 2 --steps 300
+  echo -n "  lanes4 cap64 p2: "; PVE_LIBRARY_PATH=$lib run $B --lane-num 4 --capacity 64 --steps 300
+done
