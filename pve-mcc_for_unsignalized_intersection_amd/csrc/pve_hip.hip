@@ -3,6 +3,8 @@
 //   k_tick<CAP>     one workgroup (CAP = 64 or 128 threads = 1 or 2 wave64) per intersection:
 //                   fused step* + scene_update + delete_vehicle, state staged in LDS, phases of
 //                   pve_tick_core.h separated by workgroup barriers.
+//   k_rollout<CAP>  pve_step_many: the same phases in a loop, the state resident on the chip between ticks
+//   k_tick_geo<CAP> the 4- / 8-lane layouts (pve_tick_geo.h)
 //   k_compact<CAP>  delete_vehicle() alone (split protocol of the single-env compat class)
 //   k_reset<CAP>    constructor warm-up, one thread per intersection
 //
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 }
 
 // General-geometry tick (lane_num 4 / 8): same workgroup-per-intersection structure, phases of
-// pve_tick_geo.h.  Correctness-first (per-vehicle scans instead of sorted lists).
+// pve_tick_geo.h (per-route sorted lists: PAIRS -> RANK -> WALK; the membership scan only as the overflow fallback).
 template <int CAP, bool PROF = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tick_geo(const GeoConst g_arg, const Params P_arg)
 {

@@ -14,10 +14,11 @@
 //   - step() tests the head of virtual_lane_4[LANE index] (ref :1517) and forces aM on lanes 2, 5, 8, 11 (ref :1519)
 //     whatever the layout: both quirks are part of the behaviour and are kept.
 //
-// Slots stay sorted by (lane, j); one workgroup = one intersection, thread t = slot t.  The step chain, the
-// dead-lock scan and the compaction are the phases of pve_tick_core.h (Tick<CAP, SharedGeo<CAP>>); the
-// neighbour search is a per-vehicle scan over the controlled vehicles (no sorted lists: this path is the
-// correctness-first one, the 12-lane fast path is where the optimisation work went).
+// Slots stay sorted by (lane, j); one workgroup = one intersection, thread t = slot t in every phase (the dense
+// mapping of the 12-lane kernels is not used here).  The step chain, the dead-lock scan (ph_lock_slot) and the
+// compaction are the phases of pve_tick_core.h (Tick<CAP, SharedGeo<CAP>>); the neighbour search works on per-route
+// lists sorted by counting sort and the shared window walk (Tick::walk_window), with the membership scan over the
+// controlled vehicles as the fallback when the entry pool overflows.
 #pragma once
 #include "pve_tick_core.h"
 
