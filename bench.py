@@ -127,7 +127,8 @@ def pmc_traffic(envs_per_launch, cap, outputs, mode, ticks_per_launch, other):
     if not files:
         return None, None
     files.sort(key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)))
-    t = json.load(open(files[-1])).get(mode)
+    j = json.load(open(files[-1]))
+    t = j.get("%s%d" % (mode, ticks_per_launch)) or j.get(mode)      # (a launch shape of its own, e.g. rollout5, else the mode's)
     if not t or int(t.get("envs_per_launch", 4096)) != envs_per_launch or t.get("csrc_sha") != csrc_sha() \
             or int(t.get("ticks_per_launch", 1)) != ticks_per_launch:
         return None, None

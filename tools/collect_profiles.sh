@@ -31,6 +31,9 @@ for m in rollout step; do
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch_$m -o r -- $NB --mode $m --steps 100 > /dev/null 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write_$m -o r -- $NB --mode $m --steps 100 > /dev/null 2>&1
 done
+# (the driver's short protocol runs launches of 5 ticks: its own traffic figure)
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch_rollout5 -o r -- $NB --mode rollout --chunk 5 --steps 100 > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write_rollout5 -o r -- $NB --mode rollout --chunk 5 --steps 100 > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/probe -o r -- python tools/traffic_probe.py > $O/probe.log 2>&1
 # ---- phase profiles
 python tools/phase_profile.py --ticks 100 > $O/phase_profile_step.txt 2>&1

@@ -26,7 +26,7 @@ summary(os.path.join(src, "stats_step", "r_results.db"), prefix + "_kernel_stats
 summary(os.path.join(src, "stats_cap64", "r_results.db"), prefix + "_kernel_stats_cap64.txt", 30)
 summary(os.path.join(src, "stats_actor", "r_results.db"), prefix + "_kernel_stats_actor.txt", 300)
 summary(os.path.join(src, "stats_lanes8", "r_results.db"), prefix + "_kernel_stats_lanes8.txt", 300)
-for m in ("rollout", "step"):
+for m in ("rollout", "rollout5", "step"):
     summary(os.path.join(src, "fetch_" + m, "r_results.db"), prefix + "_pmc_fetch_%s.txt" % m, 30)
     summary(os.path.join(src, "write_" + m, "r_results.db"), prefix + "_pmc_write_%s.txt" % m, 30)
 summary(os.path.join(src, "probe", "r_results.db"), prefix + "_pmc_probe_calibration.txt", 10)
@@ -51,14 +51,18 @@ try:
     known_kib = 4096 * 128 * 72 / 1024.0
     corr = known_kib / probe
     out = {}
-    for mode, kernel, bl in (("rollout", "k_rollout", "bench_default.json"), ("step", "k_tick", "bench_step.json")):
-        fetch = last_avg(os.path.join(src, "fetch_" + mode, "r_results.db"), "FETCH_SIZE", kernel, 8 if mode == "rollout" else 60)
-        write = last_avg(os.path.join(src, "write_" + mode, "r_results.db"), "WRITE_SIZE", kernel, 8 if mode == "rollout" else 60)
+    for mode, kernel, bl in (("rollout", "k_rollout", "bench_default.json"), ("rollout5", "k_rollout", "bench_driver_like.json"),
+                             ("step", "k_tick", "bench_step.json")):
+        if not os.path.isfile(os.path.join(src, "fetch_" + mode, "r_results.db")):
+            continue
+        nlast = {"rollout": 8, "rollout5": 30, "step": 60}[mode]
+        fetch = last_avg(os.path.join(src, "fetch_" + mode, "r_results.db"), "FETCH_SIZE", kernel, nlast)
+        write = last_avg(os.path.join(src, "write_" + mode, "r_results.db"), "WRITE_SIZE", kernel, nlast)
         b = json.load(open(os.path.join(src, bl)))
         envs_per_launch = int(b["roofline"].get("envs_per_launch", 4096))
         tpl = int(b["config"].get("ticks_per_launch", 1))
         out[mode] = dict(
-            kernel=kernel + "<128>", mode=mode, envs_per_launch=envs_per_launch, ticks_per_launch=tpl, csrc_sha=bench.csrc_sha(),
+            kernel=kernel + "<128>", mode=mode.rstrip("5"), envs_per_launch=envs_per_launch, ticks_per_launch=tpl, csrc_sha=bench.csrc_sha(),
             workload="%d envs x 128 slots x %d tick(s) per launch, default bench outputs, steady state (last launches of the run)"
                      % (envs_per_launch, tpl),
             fetch_size_kib_reported=fetch, write_size_kib_reported=write,
