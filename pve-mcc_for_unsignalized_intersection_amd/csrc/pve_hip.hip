@@ -269,6 +269,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     T::ph_pairs_fill(g, t, sh);
     lds_barrier();
     PVE_PHASE_MARK(4)
+    T::ph_load_late(P, env, t, sh, r);
     T::ph_rank(t, sh);
     lds_barrier();
     PVE_PHASE_MARK(5)

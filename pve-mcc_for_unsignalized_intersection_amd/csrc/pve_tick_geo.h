@@ -158,13 +158,23 @@ template <int CAP> struct TickGeo {
             if (P.actions) r.act = P.actions[gi];
             r.p = P.f64[F_P][gi]; r.v = P.f64[F_V][gi]; r.a = P.f64[F_A][gi];
             r.meta = P.i32[I_META][gi]; r.step = P.i32[I_STEP][gi];
-            r.jerk_sum = P.f64[F_JERK_SUM][gi]; r.vir_dis = P.f64[F_VIR_DIS][gi]; r.closer_p = P.f64[F_CLOSER_P][gi];
-            r.id = P.i32[I_ID][gi]; r.seq = P.i32[I_SEQ][gi]; r.vnum = P.i32[I_VNUM][gi];
-            r.count = P.i32[I_COUNT][gi];
+            r.seq = P.i32[I_SEQ][gi]; r.vnum = P.i32[I_VNUM][gi]; r.count = P.i32[I_COUNT][gi];
         }
         sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
         if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
         if (t < ND) { sh.rc[t] = 0; sh.rfill[t] = 0; sh.fill[t] = 0; sh.cnt2[t] = 0; }
+    }
+
+    // jerk_sum, closer_p and vir_dis are first touched in WALK / REWARD (ref :302, :321, :1348), the id only by FIN: their
+    // loads are issued behind the list phases, not with the rest of the state -- seven registers less to carry through
+    // the register peak of PAIRS (four were spilled; which fields move was settled by the compiler's spill count)
+    static PVE_HD void ph_load_late(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        if (t < 64 || t < sh.hd.n_alive) {
+            const size_t gi = (size_t)env * CAP + t;
+            r.jerk_sum = P.f64[F_JERK_SUM][gi]; r.closer_p = P.f64[F_CLOSER_P][gi]; r.vir_dis = P.f64[F_VIR_DIS][gi];
+            r.id = P.i32[I_ID][gi];                       // (FIN only, for a vehicle that moves)
+        }
     }
 
     // ============================================================== S1..S3: step() -- the 12-lane phases; the head

@@ -117,6 +117,7 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_pairs_exact(t, sh, P.geo_scan != 0);
         for (int t = 0; t < CAP; t++) T::ph_pairs_apply(t, sh);
         for (int t = 0; t < CAP; t++) T::ph_pairs_fill(g, t, sh);
+        for (int t = 0; t < CAP; t++) T::ph_load_late(P, env, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
         for (int t = 0; t < CAP; t++) T::ph_scan(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_reward(g, t, sh, regs[t]);
