@@ -228,7 +228,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
 // General-geometry tick (lane_num 4 / 8): same workgroup-per-intersection structure, phases of
 // pve_tick_geo.h (per-route sorted lists: PAIRS -> RANK -> WALK; the membership scan only as the overflow fallback).
-template <int CAP, bool PROF = false>
+template <int CAP, bool PROF = false, bool FIX4 = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tick_geo(const GeoConst g_arg, const Params P_arg)
 {
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     T::ph_rank(t, sh);
     lds_barrier();
     PVE_PHASE_MARK(5)
-    T::ph_scan(g, t, sh, r);
+    T::template ph_scan<FIX4>(g, t, sh, r);
     PVE_PHASE_MARK(11)
     T::ph_reward(g, t, sh, r);
     lds_barrier();
@@ -435,7 +435,14 @@ struct Backend {
     static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)
     {
         hipStream_t s = (hipStream_t)stream;
-        if (P.phase_cycles) {                                        // diagnostics build (pve_debug_phase_cycles)
+        // (the 4-lane layout's far-conflict path is a kernel of its own: FIX4)
+        if (g.lane_num == 4) {
+            if (P.phase_cycles) {                                    // diagnostics build (pve_debug_phase_cycles)
+                if (cap == 64) hipLaunchKernelGGL((k_tick_geo<64, true, true>), dim3(P.n_envs), dim3(64), 0, s, g, P);
+                else hipLaunchKernelGGL((k_tick_geo<128, true, true>), dim3(P.n_envs), dim3(128), 0, s, g, P);
+            } else if (cap == 64) hipLaunchKernelGGL((k_tick_geo<64, false, true>), dim3(P.n_envs), dim3(64), 0, s, g, P);
+            else hipLaunchKernelGGL((k_tick_geo<128, false, true>), dim3(P.n_envs), dim3(128), 0, s, g, P);
+        } else if (P.phase_cycles) {
             if (cap == 64) hipLaunchKernelGGL((k_tick_geo<64, true>), dim3(P.n_envs), dim3(64), 0, s, g, P);
             else hipLaunchKernelGGL((k_tick_geo<128, true>), dim3(P.n_envs), dim3(128), 0, s, g, P);
         } else if (cap == 64) hipLaunchKernelGGL((k_tick_geo<64, false>), dim3(P.n_envs), dim3(64), 0, s, g, P);

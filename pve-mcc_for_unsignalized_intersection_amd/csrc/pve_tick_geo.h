@@ -48,7 +48,8 @@ template <int CAP> struct SharedGeo {
     };
     double s_vd[1];
     uint16_t s_idx[PE];
-    uint8_t u_slot[PE], u_list[PE], s_slot[1];
+    uint8_t u_slot[PE], u_list[PE];
+    uint8_t s_slot[PE];                     // slot of the entry at every sorted position (read by the 4-lane left-turn egos)
     int16_t mypos[CAP];                     // sorted position of every controlled vehicle's own entry in its route's list
     int rc[ND], rfill[ND], fill[ND], cnt2[ND], pool_ok;   // controlled vehicles per route, claimed so far; entries filed per list;
                                             // exact member counts (only when the upper bounds overflow the pool)
@@ -336,6 +337,7 @@ template <int CAP> struct TickGeo {
             if (eq > 1)                                   // exact vd ties (rare): lower slot first
                 for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
             sh.s_idx[lo + pos] = (uint16_t)e;
+            sh.s_slot[lo + pos] = (uint8_t)slot;
             if (d == sh.route_of[slot]) sh.mypos[slot] = (int16_t)pos;          // the vehicle's own entry (vd = p)
         }
     }
@@ -366,11 +368,11 @@ template <int CAP> struct TickGeo {
     // re-written it (the adjusted copy is stored back at ref :286-287, so the adjustments compound)
     static PVE_HD double adjusted(const PVE_AS4 GeoConst &g, const Sh &sh, int m, int ls, int le, int t, double vc)
     {
+        const int hi = (le < t + 1) ? le : t + 1;               // the egos of the route in slots [ls, hi)
         for (int w2 = 0; w2 < NW; w2++) {
-            u64 eb = sh.m_ctl[w2] & sh.m_int[m][w2];
+            u64 eb = sh.m_ctl[w2] & sh.m_int[m][w2] & below_sel(hi - w2 * 64) & ~below_sel(ls - w2 * 64);
             for (; eb; eb &= eb - 1) {
                 const int e = w2 * 64 + __builtin_ctzll(eb);
-                if (e < ls || e >= le || e > t) continue;
                 const double pe = sh.p[e];
                 const double ori = vc + g.fix_d;                                       // ref :1304
                 if (pe < ori) {                                                        // ref :1305-1312
@@ -386,6 +388,9 @@ template <int CAP> struct TickGeo {
     }
 
     // ============================================================== SCAN: list heads, predecessor, 6 nearest
+    // FIX4 = false compiles the 4-lane far-conflict path out (the launcher picks it for lane_num 8 / 12: the registers
+    // that path needs would otherwise be spilled in the common phases of every layout)
+    template <bool FIX4 = true>
     static PVE_HD void ph_scan(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
     {
         r.reward = 0; r.hit = 0; r.hdr = -1;
@@ -422,7 +427,7 @@ template <int CAP> struct TickGeo {
         // (b) every controlled vehicle goes through the members of its route's list
         const int d = r.route, li = r.lane, m = r.intent;
         const double me = r.p;                                   // own entry: vd = p, never adjusted
-        const bool fix = (g.lane_num == 4) && (d % 3 == 0);      // ref :1301
+        const bool fix = FIX4 && (g.lane_num == 4) && (d % 3 == 0);      // ref :1301
         const int opp = sh.tab.opp[d];
         const int ls = sh.hd.lane_start[li], le = sh.hd.lane_start[li + 1];
         const unsigned mroutes = sh.tab.mroutes[d];                  // routes that can appear in list d (cheap early reject)
@@ -480,7 +485,77 @@ template <int CAP> struct TickGeo {
         }
         if (lists) {
             // 4-lane left-turn routes: the entries of the opposing left-turn route are re-written ego by ego (ref
-            // :1301-1319), so these egos still look at every member of their list
+            // :1301-1319), so these egos look at every member of their list.  FAST FORM: the members are visited in list
+            // order, 8 at a time (two batches of independent LDS reads per 8 members); each becomes a 32-bit key = the
+            // float32 image of |current distance - own| with its low 7 bits replaced by the list position; the 7 smallest
+            // keys are kept by a min / max chain.  The 6 winners are then re-derived in float64 and must be strictly
+            // ordered by (distance, position), and the 7th key must differ from the 6th above the position bits --
+            // otherwise (near ties) the exact insertion below decides.
+            const int base = sh.lbase[d], n = sh.fill[d], mp = sh.mypos[t];
+            bool done = false;
+            {
+                unsigned k7[NNB + 1];
+#pragma unroll
+                for (int k = 0; k < NNB + 1; k++) k7[k] = ~0u;
+                for (int i0 = 0; i0 < n; i0 += 8) {
+                    int xs[8], es[8], rts[8]; double vos[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int i = (i0 + k < n) ? i0 + k : n - 1;
+                        xs[k] = sh.s_slot[base + i]; es[k] = sh.s_idx[base + i];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { PVE_PIN(xs[k]); PVE_PIN(es[k]); }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { vos[k] = sh.u_vd[es[k]]; rts[k] = sh.route_of[xs[k]]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { PVE_PIN(vos[k]); PVE_PIN(rts[k]); }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int i = i0 + k;
+                        const bool valid = (i < n) & (i != mp);
+                        double vc = vos[k];
+                        if (valid && rts[k] == opp) vc = adjusted(g, sh, m, ls, le, t, vc);
+                        const unsigned key = valid ? ((Base::f32_bits((float)fabs(vc - me)) & ~127u) | (unsigned)i) : ~0u;
+                        unsigned c = key;                     // insertion into the sorted 7: one min / max pair per place
+#pragma unroll
+                        for (int q = 0; q < NNB + 1; q++) { const unsigned lo_ = Base::umin(k7[q], c), hi_ = Base::umax(k7[q], c); k7[q] = lo_; c = hi_; }
+                    }
+                }
+                // the winners in float64 (their current values are what the observation row carries anyway)
+                int wx[NNB], wp[NNB]; double wv[NNB], wd[NNB];
+                bool ok = (k7[NNB] == ~0u) | (((k7[NNB] ^ k7[NNB - 1]) >> 7) != 0u) | (k7[NNB - 1] == ~0u);
+#pragma unroll
+                for (int k = 0; k < NNB; k++) {
+                    const bool has = k7[k] != ~0u;
+                    const int i = has ? (int)(k7[k] & 127u) : 0;
+                    const int x = sh.s_slot[base + i];
+                    double vc = sh.u_vd[sh.s_idx[base + i]];
+                    if (has && sh.route_of[x] == opp) vc = adjusted(g, sh, m, ls, le, t, vc);
+                    wx[k] = has ? x : -1; wp[k] = i; wv[k] = has ? vc : 0.0; wd[k] = has ? fabs(vc - me) : INFINITY;
+                }
+#pragma unroll
+                for (int k = 1; k < NNB; k++)
+                    ok = ok & ((wx[k] < 0) | (wd[k - 1] < wd[k]) | ((wd[k - 1] == wd[k]) & (wp[k - 1] < wp[k])));
+                if (ok) {
+#pragma unroll
+                    for (int k = 0; k < NNB; k++) { r.kr[k] = wx[k]; r.kv[k] = wv[k]; }
+                    // predecessor in list order (ref :1353) with its current value
+                    int bs = -1; double bv = 0;
+                    if (mp > 0) {
+                        bs = sh.s_slot[base + mp - 1];
+                        bv = sh.u_vd[sh.s_idx[base + mp - 1]];
+                        if (sh.route_of[bs] == opp) bv = adjusted(g, sh, m, ls, le, t, bv);
+                    }
+                    r.hdr = bs;                                                             // ref :1348-1354
+                    r.vir_dis = (bs >= 0) ? (me - bv) : 100.0;
+                    sh.hdr[t] = (int16_t)bs;
+                    sh.virdis[t] = r.vir_dis;
+                    r.count += 1;                                                           // ref :292
+                    done = true;
+                }
+            }
+            if (done) return;
             const int e1 = sh.lbase[d] + sh.fill[d];
             for (int e = sh.lbase[d]; e < e1; e++) {
                 const int x = sh.u_slot[e];
