@@ -738,7 +738,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // instead of a float64 compare and six selects.  The result is exact when (a) the 6 (winner, loser) pairs of the merge
     // step differ in the upper 28 bits, (b) the float64 distances of the sorted winners do not decrease (checked on the
     // values that are read for the output anyway) and (c) no two LEFT neighbours (incl. the first one beyond the window)
-    // share the same vd (such a run is emitted in ascending slot, i.e. against the walking direction).  Anything else
+    // share the same float64 DISTANCE -- equal vd, or vd one ulp apart so that the subtraction rounds them together (such a
+    // run is emitted in list order = ascending vd, slot, i.e. against the walking direction).  Anything else
     // -- near ties, ~1e-6 relative, or equal-vd runs -- takes walk_window_exact below, which decides on float64 keys.
     static PVE_HD unsigned f32_bits(float x)
     {
@@ -782,14 +783,20 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             PVE_PIN(prs);
         }
         pr = (s > 0) ? prs : -1; pvd = (s > 0) ? lraw[0] : 0.0;                      // ref :1353-1354
-        bool amb = false;                             // (bitwise, not short-circuit: six compares, no branches)
+        // Two LEFT neighbours with the same float64 distance (equal vd, or vd one ulp apart: the subtraction rounds) come in
+        // list order, i.e. ascending vd = against the walking direction: such a run (incl. the first entry beyond the
+        // window) takes the exact path.  (bitwise, not short-circuit: six compares, no branches)
+        double dl[NNB + 1];
 #pragma unroll
-        for (int i = 1; i < NNB + 1; i++) amb = amb | ((s - 1 - i >= 0) & (lraw[i] == lraw[i - 1]));
+        for (int i = 0; i < NNB + 1; i++) dl[i] = fabs(lraw[i] - ps);                 // ref :1388
+        bool amb = false;
+#pragma unroll
+        for (int i = 1; i < NNB + 1; i++) amb = amb | ((s - 1 - i >= 0) & (dl[i] == dl[i - 1]));
         unsigned kl[NNB], kq[NNB];
 #pragma unroll
         for (int i = 0; i < NNB; i++) {
             const unsigned cl = (unsigned)i, cr = 8u + (unsigned)i;
-            const unsigned bl = f32_bits((float)fabs(lraw[i] - ps)), br = f32_bits((float)fabs(rraw[i] - ps));   // ref :1388
+            const unsigned bl = f32_bits((float)dl[i]), br = f32_bits((float)fabs(rraw[i] - ps));
             kl[i] = (s - 1 - i >= 0) ? ((bl & ~15u) | cl) : (0xFF800000u | (cl << 4) | cl);
             kq[i] = (s + 1 + i <= last) ? ((br & ~15u) | cr) : (0xFF800000u | (cr << 4) | cr);
         }
@@ -863,9 +870,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 #pragma unroll
         for (int i = 0; i < NNB; i++) { const int pos = s + 1 + i; rv[i] = pos <= last ? sv(pos <= last ? pos : last) : INFINITY; }
         const double pvd = lv[0];
-        bool tie = false;
+        bool tie = false;                             // (runs of equal DISTANCE on the left: equal vd, or vd one ulp apart)
 #pragma unroll
-        for (int i = 1; i < NNB + 1; i++) tie = tie || (s - 1 - i >= 0 && lv[i] == lv[i - 1]);
+        for (int i = 1; i < NNB + 1; i++) tie = tie || (s - 1 - i >= 0 && fabs(lv[i] - ps) == fabs(lv[i - 1] - ps));
         // candidate = (d, code): code = walking index on the left (0..5) or 8 + index on the right.  min(L_i, R_5-i)
         // (left wins equal d) are the 6 smallest overall; they are then sorted by d alone with a 12-comparator
         // network.  If two of the 6 winners still share the same d (exact |d| ties, quantised states) the order
@@ -904,11 +911,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 r.kv[k] = ok ? sv(ok ? pos : 0) : 0.0;
             }
         } else {
-            // GENERAL PATH: pointer walk; a run of equal vd on the left is emitted in ascending slot
+            // GENERAL PATH: pointer walk; a run of equal distance on the left is emitted in list order (ascending vd, slot)
 #pragma unroll
             for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
             int hi = s - 1, lo = hi, cur, rr = s + 1;
-            if (hi >= 0) { const double vh = pvd; while (lo > 0 && sv(lo - 1) == vh) lo--; }
+            if (hi >= 0) { const double dh = fabs(pvd - ps); while (lo > 0 && fabs(sv(lo - 1) - ps) == dh) lo--; }
             cur = lo;
             for (int k = 0; k < NNB; k++) {
                 const bool hasL = hi >= 0;
@@ -926,7 +933,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                     cur++;
                     if (cur > hi) {
                         hi = lo - 1; lo = hi;
-                        if (hi >= 0) { const double vh = sv(hi); while (lo > 0 && sv(lo - 1) == vh) lo--; }
+                        if (hi >= 0) { const double dh = fabs(sv(hi) - ps); while (lo > 0 && fabs(sv(lo - 1) - ps) == dh) lo--; }
                         cur = lo;
                     }
                 } else {

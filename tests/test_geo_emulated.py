@@ -46,6 +46,13 @@ def test_geo_fuzz_random_tapes(lane_num, rate, cap, quant, seed):
     assert coll > 0 and lock > 0
 
 
+def test_left_neighbours_one_ulp_apart_share_a_distance():
+    """Regression (found by tools/soak.py): two LEFT neighbours whose virtual distances differ by one ulp have the same
+    float64 |vd - vd_self|; the reference's stable sort then keeps LIST order (ascending vd), i.e. the farther one first.
+    Env 5 of this seed meets that at tick 152 (quantised actions; distances 48.50999999999991 / 48.509999999999906)."""
+    scenarios.check_geo_fuzz_vs_oracle(BACKEND, 8, n_envs=24, capacity=128, ticks=160, rate=1600.0, seed=3110, quantize=1.0)
+
+
 @pytest.mark.parametrize("lane_num", [4, 8])
 def test_geo_overflow_empty_exhausted(lane_num):
     scenarios.check_geo_overflow_and_empty(BACKEND, lane_num)

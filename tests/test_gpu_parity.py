@@ -220,6 +220,12 @@ def test_gpu_geo_fuzz_random_tapes(lane_num, rate, cap, quant, seed):
     assert coll > 0 and lock > 0
 
 
+def test_gpu_left_neighbours_one_ulp_apart_share_a_distance():
+    """Regression (found by tools/soak.py): two left neighbours whose virtual distances differ by one ulp have the same
+    float64 distance to the ego; the reference keeps list order (ascending vd) for them.  8 lanes, seed 3110, tick 152."""
+    scenarios.check_geo_fuzz_vs_oracle(BACKEND, 8, n_envs=24, capacity=128, ticks=160, rate=1600.0, seed=3110, quantize=1.0)
+
+
 @pytest.mark.parametrize("name,ticks", [("geo_g4_sin2", 400), ("geo_g8_sin3", 400)])
 def test_gpu_compat_class_4_and_8_lanes(name, ticks):
     from tests.test_compat_class import run_compat

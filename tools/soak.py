@@ -10,9 +10,10 @@ from tests import scenarios  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--ticks", type=int, default=3000)
+ap.add_argument("--seed", type=int, default=0, help="offset added to every tape / arrival seed")
 a = ap.parse_args()
 t0 = time.time()
-c, l = scenarios.check_fuzz_vs_oracle("hip", n_envs=32, capacity=128, ticks=a.ticks, rate=1100.0, seed=101, quantize=0.5)
+c, l = scenarios.check_fuzz_vs_oracle("hip", n_envs=32, capacity=128, ticks=a.ticks, rate=1100.0, seed=101 + a.seed, quantize=0.5)
 print("12 lanes: %d ticks x 32 envs OK, collisions %d, locks %d, %.0f s" % (a.ticks, c, l, time.time() - t0))
 for seed, rate, cap, scale, quant in ((201, 1100.0, 128, 3.0, None), (202, 1350.0, 128, 0.3, None), (203, 450.0, 64, 1.0, None),
                                       (204, 1300.0, 128, 1.0, 0.25)):
@@ -20,7 +21,7 @@ for seed, rate, cap, scale, quant in ((201, 1100.0, 128, 3.0, None), (202, 1350.
     # joins the dense-mapped phases), one-wave workgroups
     t0 = time.time()
     n = min(a.ticks, 600) if rate > 1300 else a.ticks      # (dense traffic fills the 128 slots sooner or later: a full
-    c, l = scenarios.check_fuzz_vs_oracle("hip", n_envs=32, capacity=cap, ticks=n, rate=rate, seed=seed,   # env defers spawns,
+    c, l = scenarios.check_fuzz_vs_oracle("hip", n_envs=32, capacity=cap, ticks=n, rate=rate, seed=seed + a.seed,   # env defers spawns,
                                           action_scale=scale, quantize=quant)                          # the reference does not)
     print("12 lanes, %.0f veh/h/lane, cap %d, |a| <= %.1f: %d ticks x 32 envs OK, collisions %d, locks %d, most controlled %d, %.0f s"
           % (rate, cap, scale, n, c, l, scenarios.check_fuzz_vs_oracle.max_ctl, time.time() - t0))
@@ -28,10 +29,10 @@ for src, rate, cap in (("pool", 1100.0, 128), ("pool", 300.0, 128), ("pool", 140
     # pve_step_many (still ticks, staged ticks, chunked launches) == single ticks, bit for bit
     t0 = time.time()
     scenarios.check_step_many("hip", src, n_envs=24, capacity=cap, rate=rate, prefill=300, chunks=(1, 2, 25, 60, 7, 100),
-                              trajectory_chunk=20, seed=300 + int(rate))
+                              trajectory_chunk=20, seed=300 + int(rate) + a.seed)
     print("pve_step_many == single ticks (%s, %.0f veh/h/lane, cap %d) OK, %.0f s" % (src, rate, cap, time.time() - t0))
 for ln, rate, cap in ((4, 2000.0, 64), (8, 1600.0, 128)):
     t0 = time.time()
-    c, l = scenarios.check_geo_fuzz_vs_oracle("hip", ln, n_envs=24, capacity=cap, ticks=a.ticks, rate=rate, seed=102 + ln,
+    c, l = scenarios.check_geo_fuzz_vs_oracle("hip", ln, n_envs=24, capacity=cap, ticks=a.ticks, rate=rate, seed=102 + ln + a.seed,
                                               quantize=1.0)
     print("%d lanes: %d ticks x 24 envs OK, collisions %d, locks %d, %.0f s" % (ln, a.ticks, c, l, time.time() - t0))
