@@ -151,6 +151,20 @@ def check_empty_and_exhausted(backend):
     assert info.n_alive == orc.n_alive and info.passed_veh == 2
 
 
+class CapacityOverflow(Exception):
+    """The workload filled every slot of an intersection: the batched env defers the spawn (documented deviation,
+    counted in metrics()['overflow']), the reference / oracle does not -- the comparison ends there."""
+
+
+def _overflow_guard(b, fn):
+    try:
+        fn()
+    except (AssertionError, ValueError) as ex:
+        if b.metrics()["overflow"] > 0:
+            raise CapacityOverflow(str(ex))
+        raise
+
+
 def check_fuzz_vs_oracle(backend, n_envs, capacity, ticks, rate, seed, action_scale=3.0, quantize=None):
     """Random action tapes (uniform in [-scale, scale], optionally quantised to provoke exact ties), every env
     compared with its own oracle every tick: controlled set, rewards, collision counters, lock counts, and the
@@ -163,29 +177,32 @@ def check_fuzz_vs_oracle(backend, n_envs, capacity, ticks, rate, seed, action_sc
     oracles = [OracleEnv(arr[e]) for e in range(n_envs)]
     tot_coll = tot_lock = 0
     check_fuzz_vs_oracle.max_ctl = 0          # (most controlled vehicles any env held: the dense mapping's second wave)
-    for t in range(ticks):
-        acts = rng.uniform(-action_scale, action_scale, size=(n_envs, capacity)).astype(np.float32).astype(np.float64)
-        if quantize:
-            acts = np.round(acts / quantize) * quantize
-        out = b.step(torch.as_tensor(acts).to(b.device))
-        rew, flags, eo = _np(out["reward"]), _np(out["flags"]), _np(out["env_out"])
-        nbr, obs = _np(out["nbr"]), _np(out["obs_pre"])
-        for e, o in enumerate(oracles):
-            n = o.n_alive
-            _vid, ctlm, _ = o.alive_view()
-            rec = o.tick(np.where(ctlm != 0, acts[e, :n], 0.0))
-            ctl = (flags[e, :n] & 2) != 0
-            check_fuzz_vs_oracle.max_ctl = max(check_fuzz_vs_oracle.max_ctl, int(ctl.sum()))
-            assert int(eo[e, 0]) == n and int(ctl.sum()) == len(rec["ids"]), "controlled set: tick %d env %d" % (t, e)
-            assert int(eo[e, 2]) == rec["collisions"] and int(eo[e, 3]) == rec["lock"], "counters: tick %d env %d" % (t, e)
-            assert np.array_equal(flags[e, :n][ctl] >> 8, rec["coll_pv"]), "coll_pv: tick %d env %d" % (t, e)
-            nb = nbr[e, :n][ctl].astype(np.int64)
-            nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)
-            assert np.array_equal(nb, rec["nbr"]), "neighbours: tick %d env %d" % (t, e)
-            assert close(rec["reward"], rew[e, :n][ctl], 1e-9), "reward: tick %d env %d" % (t, e)
-            assert close(rec["obs0"], obs[e, :n][ctl], 1e-9), "obs: tick %d env %d" % (t, e)
-            tot_coll += rec["collisions"]
-            tot_lock += rec["lock"]
+    def run_ticks():
+        nonlocal tot_coll, tot_lock
+        for t in range(ticks):
+            acts = rng.uniform(-action_scale, action_scale, size=(n_envs, capacity)).astype(np.float32).astype(np.float64)
+            if quantize:
+                acts = np.round(acts / quantize) * quantize
+            out = b.step(torch.as_tensor(acts).to(b.device))
+            rew, flags, eo = _np(out["reward"]), _np(out["flags"]), _np(out["env_out"])
+            nbr, obs = _np(out["nbr"]), _np(out["obs_pre"])
+            for e, o in enumerate(oracles):
+                n = o.n_alive
+                _vid, ctlm, _ = o.alive_view()
+                rec = o.tick(np.where(ctlm != 0, acts[e, :n], 0.0))
+                ctl = (flags[e, :n] & 2) != 0
+                check_fuzz_vs_oracle.max_ctl = max(check_fuzz_vs_oracle.max_ctl, int(ctl.sum()))
+                assert int(eo[e, 0]) == n and int(ctl.sum()) == len(rec["ids"]), "controlled set: tick %d env %d" % (t, e)
+                assert int(eo[e, 2]) == rec["collisions"] and int(eo[e, 3]) == rec["lock"], "counters: tick %d env %d" % (t, e)
+                assert np.array_equal(flags[e, :n][ctl] >> 8, rec["coll_pv"]), "coll_pv: tick %d env %d" % (t, e)
+                nb = nbr[e, :n][ctl].astype(np.int64)
+                nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)
+                assert np.array_equal(nb, rec["nbr"]), "neighbours: tick %d env %d" % (t, e)
+                assert close(rec["reward"], rew[e, :n][ctl], 1e-9), "reward: tick %d env %d" % (t, e)
+                assert close(rec["obs0"], obs[e, :n][ctl], 1e-9), "obs: tick %d env %d" % (t, e)
+                tot_coll += rec["collisions"]
+                tot_lock += rec["lock"]
+    _overflow_guard(b, run_ticks)
     for e, o in enumerate(oracles):
         info, vi, vf = state_snapshot(b, e)
         ovi, ovf, _ = o.vehicles()
@@ -297,32 +314,35 @@ def check_geo_fuzz_vs_oracle(backend, lane_num, n_envs, capacity, ticks, rate, s
     b.reset()
     oracles = [OracleGeoEnv(arr[e], lane_num, choice=None if ch is None else ch[e]) for e in range(n_envs)]
     tot_coll = tot_lock = 0
-    for t in range(ticks):
-        acts = rng.uniform(-action_scale, action_scale, size=(n_envs, capacity)).astype(np.float32).astype(np.float64)
-        if quantize:
-            acts = np.round(acts / quantize) * quantize
-        out = b.step(torch.as_tensor(acts).to(b.device))
-        rew, flags, eo = _np(out["reward"]), _np(out["flags"]).astype(np.int64), _np(out["env_out"])
-        nbr, obs, lanej = _np(out["nbr"]), _np(out["obs_pre"]), _np(out["lanej"]).astype(np.int64)
-        for e, o in enumerate(oracles):
-            n = o.n_alive
-            _vid, ctlm, _ = o.alive_view()
-            rec = o.tick(np.where(ctlm != 0, acts[e, :n], 0.0))
-            f = flags[e, :n]
-            order = np.lexsort((lanej[e, :n] & 0xFFFF, (f >> 6) & 3, lanej[e, :n] >> 16))
-            ctl = order[((f & 2) != 0)[order]]
-            assert int(eo[e, 0]) == n and len(ctl) == len(rec["ids"]), "controlled set: tick %d env %d" % (t, e)
-            ids = np.stack([lanej[e, ctl] >> 16, lanej[e, ctl] & 0xFFFF], -1)
-            assert np.array_equal(ids, rec["ids"]), "ids order: tick %d env %d" % (t, e)
-            assert int(eo[e, 2]) == rec["collisions"] and int(eo[e, 3]) == rec["lock"], "counters: tick %d env %d" % (t, e)
-            assert np.array_equal(f[ctl] >> 8, rec["coll_pv"]), "coll_pv: tick %d env %d" % (t, e)
-            nb = nbr[e, ctl].astype(np.int64)
-            nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)
-            assert np.array_equal(nb, rec["nbr"]), "neighbours: tick %d env %d" % (t, e)
-            assert close(rec["reward"], rew[e, ctl], 1e-9), "reward: tick %d env %d" % (t, e)
-            assert close(rec["obs0"], obs[e, ctl], 1e-9), "obs: tick %d env %d" % (t, e)
-            tot_coll += rec["collisions"]
-            tot_lock += rec["lock"]
+    def run_ticks():
+        nonlocal tot_coll, tot_lock
+        for t in range(ticks):
+            acts = rng.uniform(-action_scale, action_scale, size=(n_envs, capacity)).astype(np.float32).astype(np.float64)
+            if quantize:
+                acts = np.round(acts / quantize) * quantize
+            out = b.step(torch.as_tensor(acts).to(b.device))
+            rew, flags, eo = _np(out["reward"]), _np(out["flags"]).astype(np.int64), _np(out["env_out"])
+            nbr, obs, lanej = _np(out["nbr"]), _np(out["obs_pre"]), _np(out["lanej"]).astype(np.int64)
+            for e, o in enumerate(oracles):
+                n = o.n_alive
+                _vid, ctlm, _ = o.alive_view()
+                rec = o.tick(np.where(ctlm != 0, acts[e, :n], 0.0))
+                f = flags[e, :n]
+                order = np.lexsort((lanej[e, :n] & 0xFFFF, (f >> 6) & 3, lanej[e, :n] >> 16))
+                ctl = order[((f & 2) != 0)[order]]
+                assert int(eo[e, 0]) == n and len(ctl) == len(rec["ids"]), "controlled set: tick %d env %d" % (t, e)
+                ids = np.stack([lanej[e, ctl] >> 16, lanej[e, ctl] & 0xFFFF], -1)
+                assert np.array_equal(ids, rec["ids"]), "ids order: tick %d env %d" % (t, e)
+                assert int(eo[e, 2]) == rec["collisions"] and int(eo[e, 3]) == rec["lock"], "counters: tick %d env %d" % (t, e)
+                assert np.array_equal(f[ctl] >> 8, rec["coll_pv"]), "coll_pv: tick %d env %d" % (t, e)
+                nb = nbr[e, ctl].astype(np.int64)
+                nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)
+                assert np.array_equal(nb, rec["nbr"]), "neighbours: tick %d env %d" % (t, e)
+                assert close(rec["reward"], rew[e, ctl], 1e-9), "reward: tick %d env %d" % (t, e)
+                assert close(rec["obs0"], obs[e, ctl], 1e-9), "obs: tick %d env %d" % (t, e)
+                tot_coll += rec["collisions"]
+                tot_lock += rec["lock"]
+    _overflow_guard(b, run_ticks)
     for e, o in enumerate(oracles):
         info, vi, vf = state_snapshot(b, e)
         ovi, ovf, _, ointent = o.vehicles()
