@@ -1,0 +1,50 @@
+"""Randomised-configuration parity soak on the GPU (not part of the test-suite): layout, capacity, arrival rate, action
+scale and quantisation are drawn per run; every env against its own sequential oracle, every tick.
+python tools/soak_random.py [--runs 40] [--seed 1]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from tests import scenarios  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--runs", type=int, default=40)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--backend", default="hip")
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+# (layout, capacity) -> arrival rates that keep the intersections below their capacity for ~1000 ticks with most tapes
+RATES = {(12, 128): (300.0, 1250.0), (12, 64): (150.0, 480.0), (8, 128): (400.0, 1700.0), (8, 64): (200.0, 750.0),
+         (4, 128): (600.0, 3000.0), (4, 64): (300.0, 2000.0)}
+ok = stopped = 0
+for k in range(a.runs):
+    ln = int(rng.choice([12, 12, 12, 8, 8, 4]))
+    cap = int(rng.choice([64, 128, 128]))
+    lo, hi = RATES[(ln, cap)]
+    rate = float(rng.uniform(lo, hi))
+    scale = float(rng.choice([0.2, 0.5, 1.0, 2.0, 3.0]))
+    quant = rng.choice([0.0, 0.0, 0.1, 0.25, 0.5, 1.0, 3.0])
+    quant = None if quant == 0.0 or quant > scale * 2 else float(quant)
+    ticks = int(rng.integers(500, 1300))
+    n_envs = int(rng.choice([8, 16, 24]))
+    seed = int(rng.integers(1, 1 << 30))
+    what = "run %2d: %2d lanes cap %3d rate %6.0f |a|<=%.1f quant %-5s %4d ticks x %2d envs seed %d" % (
+        k, ln, cap, rate, scale, quant, ticks, n_envs, seed)
+    t0 = time.time()
+    try:
+        if ln == 12:
+            c, l = scenarios.check_fuzz_vs_oracle(a.backend, n_envs=n_envs, capacity=cap, ticks=ticks, rate=rate, seed=seed,
+                                                  action_scale=scale, quantize=quant)
+        else:
+            c, l = scenarios.check_geo_fuzz_vs_oracle(a.backend, ln, n_envs=n_envs, capacity=cap, ticks=ticks, rate=rate,
+                                                      seed=seed, action_scale=scale, quantize=quant)
+        ok += 1
+        print("%s OK (collisions %d, locks %d) %.0f s" % (what, c, l, time.time() - t0), flush=True)
+    except scenarios.CapacityOverflow as ex:
+        stopped += 1
+        print("%s stopped by a full intersection (%s) %.0f s" % (what, str(ex)[:60], time.time() - t0), flush=True)
+print("%d runs: %d green, %d ended at a deferred spawn, 0 differences" % (a.runs, ok, stopped))
