@@ -31,16 +31,10 @@ typedef __attribute__((address_space(4))) const char *KernargPtr;
         tprev_ = now_;                                                                   \
     }
 
-// LDS-only workgroup barrier: orders LDS accesses (lgkmcnt) but does not wait for this wave's outstanding global
-// loads / stores (no vmcnt(0)), so that prefetches and the output stores of one tick stay in flight across the phases
-// of the next.  __syncthreads() remains where global memory must be ordered.
-__device__ __forceinline__ void lds_barrier_x()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
+// The workgroup barrier between two phases.  __syncthreads() = workgroup-scope release + s_barrier + acquire; on gfx950
+// outside threadgroup-split mode this compiles to `s_waitcnt lgkmcnt(0)` + `s_barrier` (checked in the ISA): LDS accesses
+// are ordered, and so are the global accesses of the workgroup's waves (one CU, one in-order vector-memory path) WITHOUT
+// a vmcnt(0) -- prefetches and the output stores of one tick stay in flight across the phases of the next.
 __device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 // CAP = 128: 5 waves per SIMD (<= 96 VGPR) + the 15.1 KB LDS block = 10 workgroups of 128 threads per CU instead of 8: with
 // the sub-batches pipelined on several streams the tick scales almost linearly with the resident workgroups.
@@ -197,7 +191,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         T::ph_lock(c, t, sh, r);
         lds_barrier();
         T::ph_lock2(t, sh, r);
-        __syncthreads();                              // vmcnt(0): the previous tick's output stores precede this tick's
+        lds_barrier();                                // (also what orders the previous tick's output stores before this tick's)
         PVE_PHASE_MARK(8)
         T::ph_park_action(t, sh, r);
         const Outputs O = T::tick_outputs(P, R, k);
