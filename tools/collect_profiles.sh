@@ -23,6 +23,7 @@ timeout 300 $NB --lane-num 4 --capacity 64 --rate 1200 --steps 300 2>/dev/null |
 # ---- per-kernel durations (rocprofv3 --kernel-trace --stats), same commands
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o r -- $NB > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_step -o r -- $NB --mode step > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_driver_like -o r -- $NB --steps 20 --warmup 5 > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_cap64 -o r -- $NB --capacity 64 > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_actor -o r -- $NB --actor --steps 300 > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_lanes8 -o r -- $NB --lane-num 8 --steps 300 --pipeline 3 > /dev/null 2>&1

@@ -23,6 +23,7 @@ def summary(db, out, tail):
 
 summary(os.path.join(src, "stats", "r_results.db"), prefix + "_kernel_stats.txt", 30)
 summary(os.path.join(src, "stats_step", "r_results.db"), prefix + "_kernel_stats_step.txt", 1000)
+summary(os.path.join(src, "stats_driver_like", "r_results.db"), prefix + "_kernel_stats_driver_like.txt", 8)
 summary(os.path.join(src, "stats_cap64", "r_results.db"), prefix + "_kernel_stats_cap64.txt", 30)
 summary(os.path.join(src, "stats_actor", "r_results.db"), prefix + "_kernel_stats_actor.txt", 300)
 summary(os.path.join(src, "stats_lanes8", "r_results.db"), prefix + "_kernel_stats_lanes8.txt", 300)
