@@ -14,6 +14,7 @@ from tests import scenarios  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--runs", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--many", type=int, default=0, help="additional pve_step_many == single-tick runs")
 ap.add_argument("--backend", default="hip")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
@@ -48,3 +49,19 @@ for k in range(a.runs):
         stopped += 1
         print("%s stopped by a full intersection (%s) %.0f s" % (what, str(ex)[:60], time.time() - t0), flush=True)
 print("%d runs: %d green, %d ended at a deferred spawn, 0 differences" % (a.runs, ok, stopped))
+# pve_step_many (k_rollout: still ticks, staged ticks, chunked launches, trajectory outputs) == single ticks, bit for bit
+for k in range(a.many):
+    cap = int(rng.choice([64, 128, 128]))
+    lo, hi = RATES[(12, cap)]
+    rate = float(rng.uniform(lo * 0.3, hi * 1.15))          # (deferred spawns are deterministic: both paths agree on them too)
+    n_envs = int(rng.choice([3, 8, 17]))
+    chunks = tuple(int(x) for x in rng.integers(1, 90, size=int(rng.integers(2, 6))))
+    src = str(rng.choice(["pool", "pool", "zero"]))
+    seed = int(rng.integers(1, 1 << 30))
+    t0 = time.time()
+    scenarios.check_step_many(a.backend, src, n_envs=n_envs, capacity=cap, rate=rate, prefill=int(rng.choice([0, 150, 320])),
+                              chunks=chunks, trajectory_chunk=int(rng.integers(2, 30)), seed=seed)
+    print("many %2d: cap %3d rate %6.0f %s chunks %s x %2d envs seed %d OK %.0f s" % (k, cap, rate, src, chunks, n_envs, seed,
+                                                                                time.time() - t0), flush=True)
+if a.many:
+    print("%d pve_step_many runs: all bit-identical to single ticks" % a.many)
