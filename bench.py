@@ -34,7 +34,7 @@ B_ALG_OBS_F32 = 268.0   # the same with float32 observation rows (--obs-f32): 38
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
 N_POOL = 16
 PREFILL_MIN, PREFILL_CHUNK, PREFILL_MAX = 300, 50, 1000
-CPU_WARM, CPU_TICKS = 300, 200           # cpu_baseline sample: fixed, independent of --steps / --warmup
+CPU_WARM, CPU_TICKS = 300, 600           # cpu_baseline sample: fixed, independent of --steps / --warmup (~1 s on 256 threads)
 
 
 def action_pool(n_envs, cap, seed):
@@ -255,7 +255,7 @@ def main(argv=None, env_factory=None):
     K, W = args.steps, args.warmup
     prefill_min = max(0, args.prefill)
     prefill_cap = max(prefill_min, PREFILL_MAX) if prefill_min >= PREFILL_MIN else prefill_min
-    horizon = (K + W + prefill_cap) * 0.1 + 20.0
+    horizon = max((K + W + prefill_cap) * 0.1 + 20.0, (CPU_WARM + CPU_TICKS) * 0.1 + 10.0)   # (the CPU sample replays the same streams)
     # weak scaling: every rank owns its own n_envs environments (global env index = rank*n_envs + e)
     arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=horizon, seed=20250213 + rank * n_envs, lane_num=lane_num)
     choice = synthetic_intentions(n_envs, arr.shape[1], seed=20250213 + rank * n_envs) if lane_num == 8 else None
