@@ -31,6 +31,11 @@ sys.path.insert(0, ROOT)
 
 B_ALG_FP64 = 380.0      # algorithmic bytes per vehicle-slot-step, FP64 layout
 B_ALG_OBS_F32 = 268.0   # the same with float32 observation rows (--obs-f32): 380 - 28 x 4 (SURVEY.md §8d, FP32 output)
+# of which the persistent state: read 56 B (everything but the action), written 68 B (everything but reward / row /
+# neighbour ids / done mask).  pve_step_many keeps the state on the chip: a launch of T ticks moves it once, not T times.
+B_STATE_IN, B_STATE_OUT = 56.0, 68.0
+N_SIMD, VALU_CYCLES = 1024, 4      # MI355X: 256 CUs x 4 SIMD16; one wave64 VALU instruction occupies its SIMD for 4 cycles
+VERIFY_ENVS, VERIFY_TOL = 8, 1e-9
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
 N_POOL = 16
 PREFILL_MIN, PREFILL_CHUNK, PREFILL_MAX = 300, 50, 1000
@@ -135,6 +140,76 @@ def pmc_traffic(envs_per_launch, cap, outputs, mode, ticks_per_launch, other):
     return t, os.path.relpath(files[-1], ROOT)
 
 
+def binding_profile(mode, ticks_per_launch, cap, other):
+    """What actually binds the dominant kernel (it is not bandwidth): instruction counts per wave and tick, LDS bank
+    conflicts and wait share from the committed SQ counter passes of this very build (profiles/r*_binding.json,
+    tools/collect_profiles.sh); null unless the kernel sources are the profiled ones."""
+    import glob
+    import re
+    if other or cap != 128:
+        return None, None
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_binding.json"))
+    if not files:
+        return None, None
+    files.sort(key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)))
+    j = json.load(open(files[-1]))
+    t = j.get("%s%d" % (mode, ticks_per_launch)) or j.get(mode)
+    if not t or t.get("csrc_sha") != csrc_sha():
+        return None, None
+    return t, os.path.relpath(files[-1], ROOT)
+
+
+def verify_against_oracle(locate, last_outputs, arr, pool_np, total_ticks, lane_num, choice, n_sample=VERIFY_ENVS):
+    """Outside the timed region: `n_sample` of the envs this rank just timed are replayed from reset by the CPU oracle
+    (the checker; oracle/README.md) on the same arrival stream and the same action pool for the same number of ticks;
+    the final persistent state (ints exact, floats 1e-9) and the last tick's outputs (controlled set, rewards, collision /
+    dead-lock counters) must agree.  -> dict(verified=bool, ...)."""
+    from oracle.oracle import OracleEnv
+    from oracle.record import close
+    n_envs = arr.shape[0]
+    sample = sorted(set(np.linspace(0, n_envs - 1, n_sample).astype(int).tolist()))
+    res = dict(verified=True, envs=sample, ticks_replayed=int(total_ticks), tol=VERIFY_TOL, checker="oracle (CPU restatement)",
+               compared="final state of every vehicle (13 int fields exact, p v a jerk jerk_sum at tol) + last tick: "
+                        "controlled set, rewards, collision and dead-lock counters")
+    if total_ticks < 1:
+        res.update(verified=None, reason="no tick executed")
+        return res
+    try:
+        for e in sample:
+            if lane_num == 12:
+                o = OracleEnv(arr[e])
+            else:
+                from oracle.oracle_geo import OracleGeoEnv
+                o = OracleGeoEnv(arr[e], lane_num, choice=None if choice is None else choice[e])
+            if total_ticks > 1:
+                o.run_pool(total_ticks - 1, pool_np[:, e, :], 0)
+            vi = o.vehicles()[0]
+            n = vi.shape[0]
+            acts = np.where(vi[:, 5] != 0, pool_np[(total_ticks - 1) % N_POOL, e, :n], 0.0)
+            rec = o.tick(acts)
+            slot_of = {(int(l), int(j)): k for k, (l, j) in enumerate(vi[:, :2])}
+            batch, le = locate(e)
+            out = last_outputs(e)
+            eo, flags = out["env_out"], out["flags"].astype(np.int64)
+            assert int(eo[0]) == n, "env %d: %d vehicles before the last tick, oracle %d" % (e, int(eo[0]), n)
+            want = [slot_of[(int(l), int(j))] for l, j in rec["ids"]]
+            got = np.nonzero(flags[:n] & 2)[0].tolist()
+            assert sorted(want) == got, "env %d: controlled set of the last tick differs" % e
+            assert close(rec["reward"], out["reward"][want], VERIFY_TOL), "env %d: rewards of the last tick differ" % e
+            assert int(eo[2]) == rec["collisions"] and int(eo[3]) == rec["lock"], "env %d: collision / lock counters differ" % e
+            vs = batch.read_vehicles(le)
+            ovi, ovf = o.vehicles()[:2]
+            assert len(vs) == ovi.shape[0], "env %d: %d vehicles at the end, oracle %d" % (e, len(vs), ovi.shape[0])
+            gi = np.array([[v.lane, v.j, v.id, v.seq_in_lane, v.vnum, v.control, v.finish, v.done, v.collision, v.step,
+                            v.count, v.lock, v.lock_a] for v in vs], np.int64).reshape(len(vs), 13)
+            gf = np.array([[v.p, v.v, v.a, v.jerk, v.jerk_sum] for v in vs], np.float64).reshape(len(vs), 5)
+            assert np.array_equal(gi, ovi[:, :13].astype(np.int64)), "env %d: integer state differs" % e
+            assert close(ovf[:, :5], gf, VERIFY_TOL), "env %d: float state differs" % e
+    except AssertionError as ex:
+        res.update(verified=False, mismatch=str(ex))
+    return res
+
+
 def self_launch(args_list, n):
     """--gpus N without an outer torchrun: start the N ranks as a child process group (this process has not touched the
     GPU), forward stdout (rank 0's JSON line) and return the children's exit code."""
@@ -202,6 +277,12 @@ def main(argv=None, env_factory=None):
                          "one call per sub-batch with the action source (pool / actor) on the device")
     ap.add_argument("--chunk", type=int, default=0,
                     help="rollout mode: ticks per kernel launch (0 = the whole call in one launch)")
+    ap.add_argument("--trajectory", type=int, default=None, choices=(0, 1),
+                    help="rollout mode: 1 = every tick's outputs are RETAINED (trajectory roll-outs into a ring of two "
+                         "chunk buffers per sub-batch, what a trainer consumes, main.py:397-441); 0 = each tick overwrites "
+                         "the previous tick's outputs")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the oracle replay of %d sampled envs after the timed region" % VERIFY_ENVS)
     ap.add_argument("--obs-f64", action="store_true",
                     help="with --actor: keep float64 observation rows (default there: float32, the type the actor consumes, "
                          "model_agent_maddpg.py:15; identical trajectories, tests/actor_scenarios.py)")
@@ -283,6 +364,9 @@ def main(argv=None, env_factory=None):
         args.chunk = 25 if K >= 100 else 5
     if mode == "rollout" and not hasattr(env, "step_many"):
         sys.exit("--mode rollout: this build has no pve_step_many")
+    traj_on = bool(args.trajectory) if args.trajectory is not None else False
+    if traj_on and (mode != "rollout" or args.actor):
+        sys.exit("--trajectory 1 needs --mode rollout with the action pool")
     pool = torch.as_tensor(pool_np, device=dev)
     sync()                                            # the pool upload precedes every sub-batch stream's first launch
     env.reset()
@@ -295,12 +379,22 @@ def main(argv=None, env_factory=None):
         env.set_action_pool(pool)
     tick = [0]
     step_kw = {"wait": False} if sub_streams else {}     # the pool upload was synchronised above
+    # retained per-tick outputs: a ring of two chunk buffers per sub-batch (the consumer reads one while the next fills)
+    traj_len = (args.chunk if args.chunk > 0 else 25) if traj_on else 0
+    ring = [env.alloc_trajectory(traj_len) for _ in range(2)] if traj_on else None
+    ring_pos = [0, None, 0]                              # next buffer, (buffer, ticks) of the last call
 
     def run_ticks(n):
         """n ticks of every env of this rank, enqueued (not synchronised)."""
         if n <= 0:
             return
-        if mode == "rollout":
+        if traj_on:
+            for c0 in range(0, n, traj_len):
+                m = min(traj_len, n - c0)
+                env.step_many(m, trajectory=ring[ring_pos[0]], update_views=False)
+                ring_pos[1], ring_pos[2] = ring_pos[0], m
+                ring_pos[0] ^= 1
+        elif mode == "rollout":
             env.step_many(n, actor=args.actor, chunk=args.chunk)
         elif args.actor:
             for _ in range(n):
@@ -362,40 +456,114 @@ def main(argv=None, env_factory=None):
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
+    wall_local = wall
     m1 = env.metrics()
     delta = {k: m1[k] - m0[k] for k in m1}
-    per_rank, tot = gather_metrics(delta, dev)          # the single RCCL all-gather (metrics only)
+    # the single RCCL all-gather (metrics only; the rank's own wall-clock and first global env index ride along)
+    per_rank, tot = gather_metrics(delta, dev, extra=(wall_local * 1e3, rank * n_envs))
+    NM = len(pve_mcc_amd._capi.METRIC_NAMES)
+    rank_ms = [float(x) for x in per_rank[:, NM]]
+    rank_env0 = [int(x) for x in per_rank[:, NM + 1]]
+    rank_ticks = [float(x) / n_envs for x in per_rank[:, pve_mcc_amd._capi.METRIC_NAMES.index("ticks")]]
+
+    # ---- self-check, outside the timed region: the envs that were timed against the CPU oracle
+    verify = dict(verified=None, reason="skipped (--no-verify)")
+    if args.actor:
+        verify = dict(verified=None, reason="closed loop: the actor's float32 actions have an action-level bar only "
+                                            "(tests/actor_scenarios.py), no trajectory-level oracle")
+    elif not args.no_verify:
+        subs = getattr(env, "subs", None)
+
+        def locate(e):
+            if subs is None:
+                return env, e
+            k, le = env.sub_of(e)
+            return subs[k], le
+
+        def last_outputs(e):
+            b, le = locate(e)
+            if traj_on:
+                k = env.sub_of(e)[0] if subs is not None else 0
+                tr = ring[ring_pos[1]]
+                tr = tr[k] if subs is not None else tr
+                return {n: tr[n][ring_pos[2] - 1, le].cpu().numpy() for n in ("flags", "reward", "env_out")}
+            return {n: b.out[n][le].cpu().numpy() for n in ("flags", "reward", "env_out")}
+        if all(n in outputs for n in ("flags", "reward", "env_out")):
+            sync()
+            verify = verify_against_oracle(locate, last_outputs, arr, pool_np, tick[0], lane_num, choice)
+        else:
+            verify = dict(verified=None, reason="needs the flags, reward and env_out outputs")
+    ok_flag = 0.0 if verify["verified"] is False else 1.0
+    if world > 1:
+        tv = torch.tensor([ok_flag], dtype=torch.float64, device=dev)
+        dist.all_reduce(tv, op=dist.ReduceOp.MIN)
+        if float(tv.item()) < 1.0 and verify["verified"]:
+            verify = dict(verify, verified=False, mismatch="another rank's envs differ from the oracle")
+        ok_flag = float(tv.item())
 
     if rank == 0:
         slot_steps = float(cap) * n_envs * K * world
         value = slot_steps / wall
-        b_alg = B_ALG_OBS_F32 if args.obs_f32 else B_ALG_FP64
         envs_per_launch = n_envs / float(n_sub)
+        tpl = (traj_len if traj_on else (args.chunk if args.chunk > 0 else K)) if mode == "rollout" else 1      # ticks per kernel launch
+        # ---- algorithmic bytes.  SURVEY 8d's per-unit figure (380 B per vehicle-slot-step, FP64 layout) assumes the
+        # persistent state is read and written every tick.  pve_step_many keeps it on the chip: a launch of T ticks
+        # moves the state once, so per slot-step it must move 380 - 124 + 124 / T bytes.  `achieved` / `frac` charge what
+        # the measured mode has to move; `nominal` is the 8d figure whatever the mode (an "equivalent" rate).
+        b_nom = B_ALG_OBS_F32 if args.obs_f32 else B_ALG_FP64
+        b_alg = b_nom if mode != "rollout" else b_nom - (B_STATE_IN + B_STATE_OUT) * (1.0 - 1.0 / tpl)
         # per GPU: algorithmic bytes of one tick of all the rank's envs / wall-clock per tick (NOT per-launch x launches)
         achieved = b_alg * cap * n_envs / (wall / K) / 1e9
+        nominal = b_nom * cap * n_envs / (wall / K) / 1e9
         kern_s = gpu_ms * 1e-3 / K                      # one tick of one sub-batch (n_envs / n_sub envs) on its stream
         per_launch = b_alg * cap * envs_per_launch / kern_s / 1e9
         kname = (("k_rollout<%d>" if mode == "rollout" else "k_tick<%d>") if lane_num == 12 else "k_tick_geo<%d>") % cap
-        tpl = (args.chunk if args.chunk > 0 else K) if mode == "rollout" else 1      # ticks per kernel launch
-        tr, traffic_src = (None, None) if (emu or not steady) else pmc_traffic(
-            int(envs_per_launch), cap, outputs, mode, tpl, args.actor or lane_num != 12 or args.obs_f32)
+        other = args.actor or lane_num != 12 or args.obs_f32 or traj_on
+        tr, traffic_src = (None, None) if (emu or not steady) else pmc_traffic(int(envs_per_launch), cap, outputs, mode, tpl, other)
         traffic = tr["hbm_bytes_per_launch"] if tr else None
         counter_rate = (traffic / tpl * n_sub / (wall / K) / 1e9) if traffic else None
         peak_meas = None if (emu or args.no_copy_peak) else measured_copy_peak(torch, dev)
         mean_alive = tot["alive_steps"] / (K * n_envs * world)
+        # ---- what binds: VALU issue (SQ counters of this build), not bandwidth
+        bp, bind_src = (None, None) if emu else binding_profile(mode, tpl, cap, other or tuple(outputs) != (
+            "obs_post", "reward", "flags", "nbr", "new_slot", "env_out"))
+        binding = None
+        if bp:
+            waves_per_tick = n_envs * cap / 64.0
+            issue_us = waves_per_tick * bp["valu_per_wave_tick"] * VALU_CYCLES / (N_SIMD * bp["shader_clock_ghz"] * 1e3)
+            binding = {"kind": "valu-issue", "frac": issue_us / (wall / K * 1e6), "valu_issue_us_per_tick": issue_us,
+                       "valu_per_wave_tick": bp["valu_per_wave_tick"], "salu_per_wave_tick": bp["salu_per_wave_tick"],
+                       "lds_per_wave_tick": bp["lds_per_wave_tick"],
+                       "lds_bank_conflict_frac": bp["lds_bank_conflict_frac"], "wait_frac": bp["wait_frac"],
+                       "shader_clock_ghz": bp["shader_clock_ghz"], "profiled_in": bind_src,
+                       "definition": "frac = (waves per tick x VALU instructions per wave and tick x 4 cycles / 1024 SIMDs / "
+                                     "shader clock) / measured time per tick: the share of the tick during which the vector "
+                                     "pipes HAVE to be busy; lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS; "
+                                     "wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
+        pool_desc = ("sin action pool indexed by SLOT, pool[k][env][slot] = float32(sin(phase_env + 0.37 slot + 0.35 k)), 16 "
+                     "entries (BASELINE.md 3 indexes its sin tape by vehicle id: sin(0.37 id + 0.05 tick); a slot-indexed "
+                     "tape needs no feedback from the device and costs the same per tick)")
         line = {
             "metric": "env-steps/sec (vehicles x envs x steps/s) at 128 veh x 4096 envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "synthetic (injected test environment: timings meaningless)",
+            "verified": verify["verified"], "verification": verify,
             "config": {"workload": "%d parallel %d-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
-                                      if args.actor else "sin action pool"),
+                                      if args.actor else pool_desc),
                        "envs_per_gpu": n_envs, "capacity": cap, "mode": mode, "ticks_per_launch": tpl,
+                       "per_tick_outputs": ("every tick's outputs written to their own block (trajectory roll-out, ring of 2 "
+                                            "chunk buffers per sub-batch)" if traj_on else
+                                            ("overwritten by the next tick of the same launch (only the last tick of a call "
+                                             "can be read; --trajectory 1 retains them)" if mode == "rollout" else
+                                             "readable after every tick (one launch per tick)")),
                        "parallelism": "env-parallel x%d" % world + (", %d stream-pipelined sub-batches of %d envs per GPU"
                                                                    % (n_sub, int(envs_per_launch)) if n_sub > 1 else ""),
                        "outputs": list(outputs), "obs_dtype": "f32" if args.obs_f32 else "f64"},
+            "ranks": {"seen": len(rank_ms), "ms": rank_ms, "ticks": rank_ticks, "first_env": rank_env0,
+                      "envs_per_rank": n_envs, "arrival_seeds": "20250213 + first_env + e"},
             "population": "steady" if steady else "cold",
             "prefill_ticks": prefill, "prefill_drift": drift,
             "alive_steps_per_s": tot["alive_steps"] / wall,
@@ -405,20 +573,27 @@ def main(argv=None, env_factory=None):
             "overflow": tot["overflow"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "alg_bytes_per_slot_step": b_alg,
+                         "nominal": {"alg_bytes_per_slot_step": b_nom, "achieved": nominal, "frac": nominal / HBM_PEAK_GBS,
+                                     "note": "SURVEY 8d's figure charged every tick whatever the mode (state re-read and "
+                                             "re-written per tick); equals `achieved` in step mode"},
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_profiled_in": traffic_src,
                          "achieved_counter_bytes": counter_rate,
                          "frac_counter_bytes": (counter_rate / HBM_PEAK_GBS) if counter_rate else None,
                          "peak_measured": peak_meas,
                          "frac_of_peak_measured": (achieved / peak_meas) if peak_meas else None,
+                         "binding": binding,
                          "kernel": kname, "kernel_ms": kern_s * 1e3,
-                         "alg_bytes_per_slot_step": b_alg, "envs_per_launch": int(envs_per_launch),
+                         "envs_per_launch": int(envs_per_launch),
                          "concurrent_launches": n_sub, "per_launch_achieved": per_launch,
-                         "definition": "achieved = algorithmic bytes (380 B x capacity x envs of the GPU, every slot counted, "
-                                       "SURVEY 8d) / wall-clock per tick; per_launch_achieved = the bytes of one sub-batch / "
+                         "definition": "achieved = algorithmic bytes the measured mode must move (step: 380 B per slot-step, "
+                                       "SURVEY 8d; pve_step_many launch of T ticks: 380 - 124 (1 - 1/T), the persistent state "
+                                       "crosses HBM once per launch) x capacity x envs of the GPU, every slot counted / "
+                                       "wall-clock per tick; per_launch_achieved = the bytes of one sub-batch / "
                                        "its tick time on its own stream (HIP events), sub-batches overlap; "
                                        "achieved_counter_bytes = HBM bytes the PMC counters saw (traffic, profiled on this "
                                        "very build and config, else null) / wall-clock per tick; peak_measured = 1 GiB "
-                                       "device copy, read + write"},
+                                       "device copy, read + write; binding = the roofline that actually limits the kernel"},
         }
         if args.actor:
             line["roofline"]["note"] = "closed loop: actor + tick per step; achieved uses the tick's algorithmic bytes only"
@@ -431,6 +606,8 @@ def main(argv=None, env_factory=None):
     if world > 1:
         dist.barrier()                # every rank leaves together (rank 0 may still be timing the CPU baseline)
         dist.destroy_process_group()
+    if ok_flag < 1.0:
+        sys.exit("bench.py: the timed environments do NOT match the oracle (%s)" % verify.get("mismatch"))
 
 
 if __name__ == "__main__":

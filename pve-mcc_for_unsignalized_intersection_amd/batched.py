@@ -219,6 +219,15 @@ class BatchedIntersections:
         if self._stream_obj is None:
             self.lib.pve_set_stream(self._h, self._stream_ptr())
 
+    def _own_stream(self):
+        """Context in which torch's allocations / fills / copies are ordered with this handle's kernels: the handle's own
+        stream when it has one (a torch side stream is non-blocking: nothing else orders a `torch.zeros` or `copy_` on
+        the current stream against kernels launched on it), else a no-op (the kernels follow the current stream)."""
+        import contextlib
+        if self._stream_obj is not None and self.device.type == "cuda":
+            return torch.cuda.stream(self._stream_obj)
+        return contextlib.nullcontext()
+
     def step(self, actions=None):
         """One fused tick for every env. actions: float64 [n_envs, capacity] indexed by current slot
         (None = zeros). Returns the dict of output tensors (views, overwritten by the next call)."""
@@ -280,12 +289,29 @@ class BatchedIntersections:
 
     _TRAJ_SHAPES = dict(reward=(), flags=(), lanej=(), new_slot=(), nbr=(6,))
 
-    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0):
+    def alloc_trajectory(self, n_ticks):
+        """Reusable [n_ticks, ...] output buffers for step_many(trajectory=<this dict>): a trainer that collects
+        roll-outs chunk by chunk hands the same buffers (or a ring of them) to every call instead of paying an allocation
+        and a zero-fill of several GB per chunk.  Slots that hold no vehicle are marked by flags == 0; their other
+        per-slot outputs keep whatever an earlier tick left there."""
+        E, K, dev = self.n_envs, self.capacity, self.device
+        traj = {}
+        with self._own_stream():
+            if self._obs is not None:
+                traj["obs_post"] = torch.zeros(n_ticks, E, K, 28, dtype=self.obs_dtype, device=dev)
+            for n, tns in self.out.items():
+                traj[n] = torch.zeros((n_ticks,) + tuple(tns.shape), dtype=tns.dtype, device=dev)
+        return traj
+
+    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0, update_views=True):
         """n_ticks fused ticks in ONE call, the action source on the device (the reference's episode loop
         main.py:397-441 without the host in it): source = "pool" (set_action_pool), "actor" (set_actor; closed loop)
         or "zero".  Bit-identical to n_ticks step() / step_with_actor() calls.
         trajectory=False: returns the usual output dict holding the LAST tick's outputs.
-        trajectory=True: returns a dict of [n_ticks, ...] tensors with every tick's outputs (a roll-out)."""
+        trajectory=True: returns a dict of freshly allocated [n_ticks, ...] tensors with every tick's outputs (a roll-out).
+        trajectory=<dict from alloc_trajectory(m), m >= n_ticks>: the same into the caller's buffers (blocks 0 .. n_ticks-1).
+        update_views=False (trajectory roll-outs only): skip the copy of the last tick into the handle's single-tick views
+        (`obs`, `out`) -- not with source="actor", whose next call reads `obs`."""
         n_ticks = int(n_ticks)
         if source is None:
             source = "actor" if actor else ("pool" if getattr(self, "_pool", None) is not None else "zero")
@@ -304,6 +330,8 @@ class BatchedIntersections:
                 raise PveError("step_many(source='actor'): call set_actor first")
             ro.source, ro.actor_weights = _capi.SRC_ACTOR, self._actor_w.data_ptr()
             ro.actor_obs, ro.actor_actions = self._obs[self._obs_cur].data_ptr(), self._actor_actions.data_ptr()
+            if not update_views:
+                raise PveError("step_many(source='actor') reads the handle's observation view: update_views must stay True")
         elif source == "zero":
             ro.source = _capi.SRC_ZERO
         else:
@@ -315,21 +343,27 @@ class BatchedIntersections:
             check(self.lib, self.lib.pve_step_many(self._h, C.byref(ro), C.byref(o)), "pve_step_many")
             self.ticks += n_ticks
             return self._out_dicts[self._obs_cur]
-        E, K, dev = self.n_envs, self.capacity, self.device
-        traj, o = {}, PveOutputs()
-        if self._obs is not None:
-            traj["obs_post"] = torch.zeros(n_ticks, E, K, 28, dtype=self.obs_dtype, device=dev)
-        for n, tns in self.out.items():
-            traj[n] = torch.zeros((n_ticks,) + tuple(tns.shape), dtype=tns.dtype, device=dev)
-        for n, tns in traj.items():
-            setattr(o, n, tns.data_ptr())
-        check(self.lib, self.lib.pve_step_many(self._h, C.byref(ro), C.byref(o)), "pve_step_many")
-        self.ticks += n_ticks
-        if n_ticks > 0:                      # the handle's single-tick views keep showing the latest tick
-            if self._obs is not None:
-                self._obs[self._obs_cur].copy_(traj["obs_post"][-1])
-            for n, tns in self.out.items():
-                tns.copy_(traj[n][-1])
+        o = PveOutputs()
+        # the zero-fill of fresh trajectory buffers, the roll-out and the copy-back of the last tick are one ordered
+        # sequence on the stream the kernels run on (the returned tensors belong to that stream: consume them there or
+        # after synchronize())
+        with self._own_stream():
+            if isinstance(trajectory, dict):
+                traj = trajectory
+                want = set(self.out) | ({"obs_post"} if self._obs is not None else set())
+                if set(traj) != want or any(t.shape[0] < n_ticks for t in traj.values()):
+                    raise PveError("step_many: trajectory buffers must come from alloc_trajectory(m) of this batch, m >= n_ticks")
+            else:
+                traj = self.alloc_trajectory(n_ticks)
+            for n, tns in traj.items():
+                setattr(o, n, tns.data_ptr())
+            check(self.lib, self.lib.pve_step_many(self._h, C.byref(ro), C.byref(o)), "pve_step_many")
+            self.ticks += n_ticks
+            if n_ticks > 0 and update_views:     # the handle's single-tick views keep showing the latest tick
+                if self._obs is not None:
+                    self._obs[self._obs_cur].copy_(traj["obs_post"][n_ticks - 1])
+                for n, tns in self.out.items():
+                    tns.copy_(traj[n][n_ticks - 1])
         return traj
 
     def scene_update(self, actions=None):
@@ -473,11 +507,17 @@ class PipelinedIntersections:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
-    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0):
+    def alloc_trajectory(self, n_ticks):
+        return [sub.alloc_trajectory(n_ticks) for sub in self.subs]
+
+    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0, update_views=True):
         """n_ticks of every sub-batch, one pve_step_many call each (on its own stream).  chunk > 0 splits every call into
         launches of `chunk` ticks: a launch lasts as long as its slowest intersection, and the other sub-batches'
-        workgroups fill the slots its fast ones free, so short launches keep the chip full."""
-        return [sub.step_many(n_ticks, actor=actor, source=source, trajectory=trajectory, chunk=chunk) for sub in self.subs]
+        workgroups fill the slots its fast ones free, so short launches keep the chip full.
+        trajectory: False / True / the list alloc_trajectory() returned (one dict per sub-batch)."""
+        tr = trajectory if isinstance(trajectory, (list, tuple)) else [trajectory] * self.n_sub
+        return [sub.step_many(n_ticks, actor=actor, source=source, trajectory=tr[k], chunk=chunk, update_views=update_views)
+                for k, sub in enumerate(self.subs)]
 
     def synchronize(self):
         for sub in self.subs:

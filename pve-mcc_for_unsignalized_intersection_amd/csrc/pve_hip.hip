@@ -464,7 +464,7 @@ struct Backend {
     {
         // persistent workgroups of 4 waves (the dense kernels are staged in LDS once per workgroup): 4 per CU, one wave
         // per intersection at a time
-        static const int wgs = getenv("PVE_ACTOR_GRID") ? atoi(getenv("PVE_ACTOR_GRID")) : 1024;
+        static const int wgs = [] { const char *g = getenv("PVE_ACTOR_GRID"); const int v = g ? atoi(g) : 0; return v > 0 ? v : 1024; }();
         const int grid = (n_envs + 3) / 4 < wgs ? (n_envs + 3) / 4 : wgs;
         if (exact_f32) {
             if (cap == 64) hipLaunchKernelGGL((k_actor_t<64, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);

@@ -578,6 +578,28 @@ def check_step_many_pipelined(backend, n_envs=5, n_sub=2, capacity=128, ticks=40
     m1, m2 = one.metrics(), pipe.metrics()
     for k in ("alive_steps", "ctl_steps", "spawned", "passed", "collided", "locks", "passed_steps", "ticks"):
         assert m1[k] == m2[k], (k, m1[k], m2[k])
+    # trajectory roll-outs of the sub-batches: buffers allocated, filled and copied back on each sub-batch's OWN stream
+    # (a zero-fill / copy-back on torch's current stream is not ordered with the kernels), twice in a row so
+    # that the second call's allocations can recycle the first call's memory
+    for rep in range(2):
+        n = 9
+        trajs = pipe.step_many(n, trajectory=True, chunk=4)
+        for k in range(n):
+            o1 = one.step(pool_d[one.ticks % 4])
+            f1 = _np(o1["flags"])
+            f2 = np.concatenate([_np(tr["flags"][k]) for tr in trajs], 0)
+            assert np.array_equal(f1, f2), "pipelined trajectory, flags of tick %d" % k
+            alive = (f1 & 1) != 0
+            r2 = np.concatenate([_np(tr["reward"][k]) for tr in trajs], 0)
+            assert np.array_equal(_np(o1["reward"])[alive], r2[alive]), "pipelined trajectory, reward of tick %d" % k
+            post_ctl = (_np(one.state_field("meta")) & 1) != 0
+            ob2 = np.concatenate([_np(tr["obs_post"][k]) for tr in trajs], 0)
+            assert np.array_equal(_np(one.obs)[post_ctl], ob2[post_ctl]), "pipelined trajectory, rows of tick %d" % k
+        # the handles' single-tick views show the last tick (copied back on the sub-batch stream)
+        pipe.synchronize()
+        post_ctl = (_np(one.state_field("meta")) & 1) != 0
+        assert np.array_equal(_np(one.obs)[post_ctl], np.concatenate([_np(sub.obs) for sub in pipe.subs], 0)[post_ctl])
+        assert np.array_equal(_np(one.out["flags"]), np.concatenate([_np(sub.out["flags"]) for sub in pipe.subs], 0))
 
 
 def check_full_size_vs_oracle(backend, n_envs, capacity, rate, ticks=420, n_sample=16, seed=20250213, many=0,
@@ -643,6 +665,80 @@ def check_full_size_vs_oracle(backend, n_envs, capacity, rate, ticks=420, n_samp
     m = b.metrics()
     assert m["ticks"] == ticks * n_envs
     assert m["overflow"] == 0, "deferred spawns at %g veh/h/lane x %d slots (peak of the sampled envs: %d)" % (rate, capacity, peak)
+    return m, peak
+
+
+def check_driver_shape_vs_oracle(backend, n_envs=4096, n_sub=2, capacity=128, rate=1100.0, chunk=5, n_sample=16,
+                                 calls=(50, 50, 50, 50, 50, 50, 5, 20), n_pool=16, seed=20250213, trajectory=False):
+    """Exactly the launch shape the driver's `bench.py --steps 20 --warmup 5` runs:
+    PipelinedIntersections, `n_sub` sub-batches on their own streams, pve_step_many calls of 50 (prefill) / 5 (warm-up) /
+    20 (timed) ticks split into launches of `chunk` ticks, action pool of 16 slot-indexed entries.  `n_sample` envs spread
+    over the batch are shadowed by their own oracles: after EVERY call the last tick's outputs (controlled set, rewards,
+    counters, neighbour ids, observation rows) and at the end the state field by field; overflow == 0 over the whole
+    batch.  trajectory=True: the calls write into a ring of two trajectory buffers (bench.py --trajectory 1) and EVERY
+    tick's outputs are compared."""
+    from pve_mcc_amd.batched import PipelinedIntersections
+    from tests.hip_adapter import emulator_lib
+    rng = np.random.default_rng(seed)
+    total = sum(calls)
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed)
+    outs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
+    kw = dict(device="cpu", _lib=emulator_lib()) if backend == "emu" else dict(device="cuda")
+    pipe = PipelinedIntersections(n_envs, capacity, arr, n_sub=n_sub, outputs=outs, **kw)
+    pipe.reset()
+    pool_np = rng.uniform(-3, 3, size=(n_pool, n_envs, capacity)).astype(np.float32).astype(np.float64)
+    pipe.set_action_pool(torch.as_tensor(pool_np))
+    sample = sorted(set(np.linspace(0, n_envs - 1, n_sample).astype(int).tolist()))
+    oracles = {e: OracleEnv(arr[e]) for e in sample}
+    ring = [pipe.alloc_trajectory(max(calls)) for _ in range(2)] if trajectory else None
+    t, peak = 0, 0
+
+    def compare_tick(e, o, tk, flags, rew, eo, nbr, new_slot, obs_post):
+        nonlocal peak
+        n = o.n_alive
+        peak = max(peak, n)
+        _vid, ctlm, _ = o.alive_view()
+        rec = o.tick(np.where(ctlm != 0, pool_np[tk % n_pool, e, :n], 0.0))
+        ctl = (flags[:n] & 2) != 0
+        assert int(eo[0]) == n and int(ctl.sum()) == len(rec["ids"]), "controlled set: tick %d env %d" % (tk, e)
+        assert int(eo[2]) == rec["collisions"] and int(eo[3]) == rec["lock"], "counters: tick %d env %d" % (tk, e)
+        nb = nbr[:n][ctl].astype(np.int64)
+        nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)
+        assert np.array_equal(nb, rec["nbr"]), "neighbours: tick %d env %d" % (tk, e)
+        assert close(rec["reward"], rew[:n][ctl], 1e-9), "reward: tick %d env %d" % (tk, e)
+        ns = new_slot[:n][ctl]
+        kept = ns >= 0
+        assert close(rec["obs0"][kept], obs_post[ns[kept]], 1e-9), "obs rows: tick %d env %d" % (tk, e)
+
+    for ci, n in enumerate(calls):
+        if trajectory:
+            trajs = pipe.step_many(n, trajectory=ring[ci & 1], chunk=chunk, update_views=False)
+        else:
+            pipe.step_many(n, chunk=chunk)
+        pipe.synchronize()
+        for e in sample:
+            k, le = pipe.sub_of(e)
+            o = oracles[e]
+            if trajectory:
+                tr = trajs[k]
+                host = {x: _np(tr[x][:n, le]) for x in ("flags", "reward", "env_out", "nbr", "new_slot", "obs_post")}
+                for q in range(n):
+                    compare_tick(e, o, t + q, *(host[x][q] for x in ("flags", "reward", "env_out", "nbr", "new_slot", "obs_post")))
+            else:
+                sub = pipe.subs[k]
+                if n > 1:
+                    o.run_pool(n - 1, pool_np[:, e, :], t)
+                compare_tick(e, o, t + n - 1, *(_np(sub.out[x][le]) for x in ("flags", "reward", "env_out", "nbr", "new_slot")),
+                             _np(sub.obs[le]))
+        t += n
+    for e in sample:
+        k, le = pipe.sub_of(e)
+        info, vi, vf = state_snapshot(pipe.subs[k], le)
+        ovi, ovf, _ = oracles[e].vehicles()
+        assert np.array_equal(vi[:, :13], ovi[:, :13]), "final state ints, env %d" % e
+        assert close(ovf[:, :5], vf[:, :5], 1e-9), "final state floats, env %d" % e
+    m = pipe.metrics()
+    assert m["ticks"] == total * n_envs and m["overflow"] == 0, (m["ticks"], m["overflow"], peak)
     return m, peak
 
 

@@ -40,6 +40,14 @@ def check_line(out, n):
     # roofline.achieved follows from the line's own wall clock: B_alg x slots of ONE GPU / time per tick
     assert abs(r["achieved"] - 380.0 * 64 * 12 / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
     assert d["population"] in ("steady", "cold") and "mean_alive_per_env" in d and "prefill_ticks" in d
+    # the line certifies itself: sampled envs of the timed run replayed by the oracle
+    assert d["verified"] is True and d["verification"]["ticks_replayed"] == 9 and len(d["verification"]["envs"]) == 8
+    # ... and shows that n ranks took part, each with its own envs (item 2d / 7)
+    rk = d["ranks"]
+    assert rk["seen"] == n and len(rk["ms"]) == n and rk["ticks"] == [6.0] * n
+    assert rk["first_env"] == [12 * k for k in range(n)] and rk["envs_per_rank"] == 12      # disjoint env ranges = disjoint seeds
+    assert all(ms > 0 for ms in rk["ms"]) and max(rk["ms"]) <= d["ms_per_step"] * 6 * (1 + 1e-9)
+    assert r["nominal"]["alg_bytes_per_slot_step"] == 380.0 and "binding" in r
     return d
 
 
@@ -81,3 +89,31 @@ def test_bench_self_launches_two_ranks():
     assert p.returncode == 0
     d = check_line(p.stdout, 2)
     assert d["config"]["parallelism"] == "env-parallel x2"
+
+
+def test_bench_verification_detects_a_wrong_tape():
+    """verify_against_oracle is a real check: the same envs replayed with another action pool do not verify."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    import pve_mcc_amd
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    from tests.hip_adapter import emulator_lib
+    n_envs, cap, ticks = 4, 64, 80
+    arr = synthetic_arrivals(n_envs, rate=500.0, horizon_s=40.0, seed=5)
+    pool_np = bench.action_pool(n_envs, cap, seed=3)
+    b = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device="cpu", outputs=("obs_post", "reward", "flags", "env_out"),
+                                         _lib=emulator_lib())
+    b.reset()
+    pool = torch.as_tensor(pool_np)
+    for t in range(ticks):
+        b.step(pool[t % bench.N_POOL])
+    locate = lambda e: (b, e)
+    last = lambda e: {n: b.out[n][e].numpy() for n in ("flags", "reward", "env_out")}
+    good = bench.verify_against_oracle(locate, last, arr, pool_np, ticks, 12, None, n_sample=4)
+    assert good["verified"] is True and good["envs"] == [0, 1, 2, 3]
+    bad = bench.verify_against_oracle(locate, last, arr, -pool_np, ticks, 12, None, n_sample=4)
+    assert bad["verified"] is False and "env 0" in bad["mismatch"]
+    off = bench.verify_against_oracle(locate, last, arr, pool_np, ticks - 1, 12, None, n_sample=4)
+    assert off["verified"] is False

@@ -311,6 +311,15 @@ def test_gpu_full_size_oracle_spot_checks(cap, rate, many):
     assert peak <= cap
 
 
+@pytest.mark.parametrize("trajectory", [False, True])
+def test_gpu_driver_launch_shape_vs_oracle(trajectory):
+    """The exact launch shape of the driver's `bench.py --steps 20 --warmup 5` at 4096 x 128 (PipelinedIntersections,
+    2 x 2048 envs, pve_step_many calls in launches of 5 ticks, 325 ticks) against 16 oracles; and the same with the
+    per-tick outputs retained in the trajectory ring (every tick compared)."""
+    m, peak = scenarios.check_driver_shape_vs_oracle(BACKEND, trajectory=trajectory)
+    assert m["alive_steps"] / m["ticks"] > 50 and peak <= 128
+
+
 def test_gpu_full_size_actor_closed_loop_matches_small_batch():
     """step_with_actor on 4096 envs == the same streams stepped as a 16-env batch (config 5 at full size)."""
     from pve_mcc_amd.arrivals import synthetic_arrivals

@@ -68,3 +68,10 @@ def test_step_many_equals_single_ticks(source):
 def test_step_many_capacity_64_and_pipelined():
     scenarios.check_step_many(BACKEND, "pool", n_envs=3, capacity=64, rate=450.0, chunks=(5, 30), trajectory_chunk=4)
     scenarios.check_step_many_pipelined(BACKEND)
+
+
+def test_emulated_driver_launch_shape_vs_oracle():
+    """Small-batch CPU version of the driver-shape test (the GPU test runs it at 4096 x 128)."""
+    for traj in (False, True):
+        m, _ = scenarios.check_driver_shape_vs_oracle(BACKEND, n_envs=7, n_sub=2, n_sample=7, calls=(30, 30, 5, 20), trajectory=traj)
+        assert m["ctl_steps"] > 0
