@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PVE_ABI_VERSION 3
+#define PVE_ABI_VERSION 4
 #define PVE_LANES 12          /* physical lanes: lane_num = 4, 8 or 12 (arrays are padded to 12) */
 #define PVE_MAX_DIRS 16       /* virtual-lane lists (routes): 12 for lane_num 4 / 12, 16 for lane_num 8 (ref :86, :132, :167) */
 #define PVE_OBS_WIDTH 28      /* (o_agent_num + 1) * 4, ref :1295 */
@@ -183,12 +183,18 @@ int pve_compact(pve_handle h, double *obs_post /* optional: rows are moved with 
  * vehicle with batch 1 from main.py:36-45, 404): for every controlled vehicle
  *   actions[env][slot] = 3*tanh(Dense1(relu(LN(Dense64(relu(LN(Dense64(LN(obs[env][slot]))))))))   (float32; the two dense
  *   layers on the matrix cores with split-half operands unless PVE_CFG_ACTOR_F32, see pve_config.flags),
- * 0 for every other slot (main.py:401).  weights: DEVICE float32[PVE_ACTOR_N_WEIGHTS] in the order
+ * 0 for every other slot (main.py:401).
+ * pve_set_actor installs the policy (the reference restores it once per run, main.py:380-384 `saver.restore`): weights =
+ * DEVICE float32[PVE_ACTOR_N_WEIGHTS] in the order
  * LayerNorm{gamma[28],beta[28]}, dense{kernel[28][64],bias[64]}, LayerNorm_1{gamma,beta}[64],
  * dense_1{kernel[64][64],bias[64]}, LayerNorm_2{gamma,beta}[64], dense_2{kernel[64],bias[1]} (TF variable
- * layouts, checkpoint names `agent1actor/...`).  obs: [n_envs][cap][28] float64 (= obs_post of the previous
- * tick, zeros after reset); actions: [n_envs][cap] float64 out. */
+ * layouts, checkpoint names `agent1actor/...`); they are copied into the handle's workspace (flat, and packed for the
+ * matrix cores: centered over the output units, split into half pairs, in operand order), so the caller's buffer may be
+ * reused afterwards; call it again after every update of the weights.
+ * pve_actor_forward: obs = [n_envs][cap][28] float64 (= obs_post of the previous tick, zeros after reset);
+ * actions: [n_envs][cap] float64 out.  `weights` = NULL uses the installed actor; non-NULL = pve_set_actor(weights) first. */
 #define PVE_ACTOR_N_WEIGHTS 6393
+int pve_set_actor(pve_handle h, const float *weights);
 int pve_actor_forward(pve_handle h, const float *weights, const void *obs /* float64, or float32 with PVE_CFG_OBS_F32 */,
                       double *actions);
 
@@ -209,7 +215,9 @@ int pve_step_all_actor(pve_handle h, const float *weights, const void *obs_in, d
  *                  which is therefore required (and may be the same buffer as actor_obs when trajectory = 0)
  * and the results are bit-identical to n_ticks separate calls (tested).  For lane_num = 12 the ticks run inside one
  * kernel launch with the intersection state resident on the chip between ticks (k_rollout: no state traffic to HBM, only
- * the per-tick outputs); other layouts enqueue n_ticks launches from C.
+ * the per-tick outputs) -- PVE_SRC_ACTOR included: the actor runs inside that kernel on the rows its dense threads have
+ * just built (with PVE_CFG_ACTOR_F32: an actor launch + a tick launch per tick); other layouts enqueue n_ticks launches
+ * from C.
  * trajectory = 0: every tick overwrites the `out` buffers (the last tick's outputs remain; metrics accumulate in the
  * handle as usual); trajectory = 1: every non-NULL `out` buffer holds n_ticks consecutive per-tick blocks
  * ([n_ticks][n_envs][cap]...), the roll-out a trainer consumes.  obs_pre / state_pre are not available here. */
@@ -219,9 +227,10 @@ typedef struct pve_rollout {
     int32_t source;               /* PVE_SRC_* */
     const double *pool;           /* PVE_SRC_POOL */
     int32_t n_pool, pool_tick0;
-    const float *actor_weights;   /* PVE_SRC_ACTOR: DEVICE float32[PVE_ACTOR_N_WEIGHTS] */
+    const float *actor_weights;   /* PVE_SRC_ACTOR: NULL = the actor installed by pve_set_actor; else DEVICE float32[PVE_ACTOR_N_WEIGHTS], installed first */
     const void *actor_obs;        /* PVE_SRC_ACTOR: rows the first tick's actor reads (float64, or float32 with PVE_CFG_OBS_F32) */
-    double *actor_actions;        /* PVE_SRC_ACTOR: DEVICE scratch float64 [n_envs][capacity] (holds the last tick's actions) */
+    double *actor_actions;        /* PVE_SRC_ACTOR: DEVICE scratch float64 [n_envs][capacity] (per-tick launches only: the resident
+                                     kernel keeps the actions on the chip and does not touch it) */
     int32_t trajectory;
     int32_t chunk_ticks;          /* 0: all n_ticks in one launch; > 0: launches of at most chunk_ticks ticks each (same results).
                                      Every workgroup of a launch runs its intersection for all the ticks of the launch, so a

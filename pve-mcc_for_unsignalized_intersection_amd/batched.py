@@ -254,14 +254,17 @@ class BatchedIntersections:
         w = torch.as_tensor(weights, dtype=torch.float32).contiguous()
         if w.numel() != _capi.PVE_ACTOR_N_WEIGHTS:
             raise PveError("actor needs %d float32 weights, got %d" % (_capi.PVE_ACTOR_N_WEIGHTS, w.numel()))
-        self._actor_w = w.to(self.device)
-        self._actor_actions = torch.zeros(self.n_envs, self.capacity, dtype=torch.float64, device=self.device)
+        with self._own_stream():
+            self._actor_w = w.to(self.device)
+            self._actor_actions = torch.zeros(self.n_envs, self.capacity, dtype=torch.float64, device=self.device)
+            self._bind_stream()
+            # copied into the handle's workspace (flat + packed for the matrix cores) on the handle's stream
+            check(self.lib, self.lib.pve_set_actor(self._h, C.c_void_p(self._actor_w.data_ptr())), "pve_set_actor")
 
     def act(self):
         """actions [n_envs, capacity] = actor(obs) for the controlled slots, 0 elsewhere (device tensor)."""
         self.lib.pve_set_stream(self._h, self._stream_ptr())
-        check(self.lib, self.lib.pve_actor_forward(self._h, C.c_void_p(self._actor_w.data_ptr()),
-                                                   C.c_void_p(self.obs.data_ptr()),
+        check(self.lib, self.lib.pve_actor_forward(self._h, None, C.c_void_p(self.obs.data_ptr()),
                                                    C.c_void_p(self._actor_actions.data_ptr())), "pve_actor_forward")
         return self._actor_actions
 
@@ -271,8 +274,7 @@ class BatchedIntersections:
         self._bind_stream()
         obs_in = self._obs[self._obs_cur]
         o = self._outputs_struct(flip_obs=True)
-        check(self.lib, self.lib.pve_step_all_actor(self._h, C.c_void_p(self._actor_w.data_ptr()),
-                                                    C.c_void_p(obs_in.data_ptr()),
+        check(self.lib, self.lib.pve_step_all_actor(self._h, None, C.c_void_p(obs_in.data_ptr()),
                                                     C.c_void_p(self._actor_actions.data_ptr()), C.byref(o)),
               "pve_step_all_actor")
         self.ticks += 1
@@ -328,7 +330,7 @@ class BatchedIntersections:
         elif source == "actor":
             if getattr(self, "_actor_w", None) is None:
                 raise PveError("step_many(source='actor'): call set_actor first")
-            ro.source, ro.actor_weights = _capi.SRC_ACTOR, self._actor_w.data_ptr()
+            ro.source, ro.actor_weights = _capi.SRC_ACTOR, None          # (installed by set_actor)
             ro.actor_obs, ro.actor_actions = self._obs[self._obs_cur].data_ptr(), self._actor_actions.data_ptr()
             if not update_views:
                 raise PveError("step_many(source='actor') reads the handle's observation view: update_views must stay True")

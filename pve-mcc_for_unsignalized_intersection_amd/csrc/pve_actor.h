@@ -309,65 +309,267 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_actor_h: the same network with every float32 operand split into two halves, x = hi + lo (hi = half(x), lo =
-// half(x - hi): 22 significant bits; gfx950's matrix cores honour f16 subnormals -- tools/mfma_layout_probe.hip), and
-// three v_mfma_f32_16x16x32_f16 per product block (hi*hi + hi*lo + lo*hi, float32 accumulation; the lo*lo term is
-// 2^-22 relative).  The f16 instruction contracts K = 32 at 16x the rate of the f32 one, so a 16-vehicle tile costs 36
-// MFMAs x 16 cycles instead of 92 x 32.  Same transposed formulation: lane (j, q) supplies B[k = 8 q + e][j] as 8
-// consecutive halves -- for layer 2 exactly the two accumulator registers h[2 b], h[2 b + 1] it already holds for K-block
-// b (k = 32 b + 8 q + e  <->  hidden unit 16 (2 b + e / 4) + 4 q + e % 4) -- and the weights are staged in LDS in the
-// A-operand layout ([block][unit tile][lane][8 halves]: one conflict-free 16-byte read per MFMA).
-// Not bit-identical to the float32 chain of k_actor_t (actor_canonical): ~1e-6 relative per dot product; the action
-// parity bar is 5e-4 (tests/actor_scenarios.py).  PVE_CFG_ACTOR_F32 selects k_actor_t.
+// The split-half actor (default): every float32 operand is split into two halves, x = hi + lo (hi = half(x), lo =
+// half(x - hi): 22 significant bits; gfx950's matrix cores honour f16 subnormals -- tools/mfma32_layout_probe.hip), and
+// each product block is three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, float32 accumulation; the lo*lo term is
+// 2^-22 relative).  One TILE = 32 vehicles on one wave: lane (j = lane & 31, hf = lane >> 5) holds, for vehicle j,
+//   inputs   x[c], c = 0..15: feature 16 (c >> 3) + 8 hf + (c & 7)  (features 28..31 = zero padding of K to 32)
+//   hidden   acc[m][r], m = 0..1, r = 0..15: unit u(m, r, hf) = 32 m + 8 (r >> 2) + 4 hf + (r & 3)
+// which is at once the C/D layout of one layer and -- with the contraction index enumerated accordingly -- the B-operand
+// layout of the next (K-block kb = 2 m + g supplies registers r = 8 g .. 8 g + 7 of unit tile m): activations never move.
+//
+// What round 3 changed against the 16-wide tile of round 2 (VALU issue is what bounds the actor, not the matrix pipe):
+//  * the dense kernels are stored CENTERED over their output units (W[k][u] - mean_u W[k][.], b[u] - mean b): the matrix
+//    cores then deliver h - mean(h) directly and LayerNorm's mean pass (sum, exchange, 64 subtractions) disappears;
+//  * a vehicle lives in 2 lanes instead of 4: one v_permlane32_swap per LayerNorm sum instead of two exchanges;
+//  * 1 / sqrt(var + eps) is v_rsq_f32, 3 tanh(z) = 3 - 6 / (exp(2 z) + 1) with v_exp_f32 / v_rcp_f32 (1 ulp each; measured
+//    3.6e-7 absolute on the action), divisions by the layer widths are multiplications;
+//  * every weight is centered, split and laid out in A-operand order ONCE (k_actor_pack, pve_set_actor) instead of by
+//    every workgroup of every launch.
+// The same device function (`actor_wave`) is called by the stand-alone kernel k_actor_h (weights staged in LDS by persistent
+// workgroups) and from inside k_rollout (pve_step_many(PVE_SRC_ACTOR): the closed loop resident on the chip, A operands
+// streamed from L1 / L2), so the two paths are bit-identical by construction.
+// Not bit-identical to the float32 chain of k_actor_t (actor_canonical); the action parity bar is 5e-4
+// (tests/actor_scenarios.py).  PVE_CFG_ACTOR_F32 selects k_actor_t.
 typedef _Float16 pve_v8h __attribute__((ext_vector_type(8)));
+typedef float pve_v16f __attribute__((ext_vector_type(16)));
+typedef float pve_v2f __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void split8(const float (&x)[8], pve_v8h &hi, pve_v8h &lo)
+// packed actor parameters (device buffer written by k_actor_pack), byte offsets
+constexpr int AP_A1 = 0;                                   // _Float16 [hl 2][m 2][kb 2][lane 64][8]
+constexpr int AP_A2 = AP_A1 + 2 * 2 * 2 * 64 * 8 * 2;      // _Float16 [hl 2][m2 2][kb 4][lane 64][8]
+constexpr int AP_PRM = AP_A2 + 2 * 2 * 4 * 64 * 8 * 2;     // float [PV_TOTAL]
+// float parameter vectors in LANE ORDER: vec[(hf * 2 + m) * 16 + r] = parameter of unit u(m, r, hf)
+constexpr int PV_B1 = 0, PV_G1 = 64, PV_BE1 = 128, PV_B2 = 192, PV_G2 = 256, PV_BE2 = 320, PV_W3 = 384,
+              PV_LN0G = 448 /* [hf][c 16] */, PV_LN0B = 480, PV_B3 = 512, PV_A0 = 513 /* action of the all-zero row */,
+              PV_TOTAL = 516;
+constexpr int AP_BYTES = AP_PRM + PV_TOTAL * 4;
+constexpr int AP_BYTES_PADDED = (AP_BYTES + 255) / 256 * 256;
+static_assert(AP_PRM == 24576 && AP_BYTES_PADDED == (int)ACTOR_PACKED_BYTES && AW_TOTAL * 4 <= (int)ACTOR_FLAT_BYTES, "packed actor layout");
+
+__device__ __forceinline__ int actor_unit(int m, int r, int hf) { return 32 * m + 8 * (r >> 2) + 4 * hf + (r & 3); }
+__device__ __forceinline__ int actor_feature(int c, int hf) { return 16 * (c >> 3) + 8 * hf + (c & 7); }
+
+// sum over the two lanes (j, j + 32) that hold one vehicle: lo + hi in every lane (one gfx950 row swap, VALU)
+__device__ __forceinline__ float actor_xsum2(float s)
+{
+    const unsigned u = __float_as_uint(s);
+    const pve_v2u r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0] = [lo | lo], r[1] = [hi | hi]
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void actor_split8(const float *x, pve_v8h &hi, pve_v8h &lo)
 {
 #pragma unroll
     for (int e = 0; e < 8; e++) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
 }
+// 3 tanh(z): exp(2 z) overflows to +inf -> 3, underflows to 0 -> -3
+__device__ __forceinline__ float actor_tanh3(float z)
+{
+    const float t = __expf(2.0f * z);
+    return 3.0f - 6.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
 
+// LayerNorm (input already centered by the centered dense kernel) + ReLU over the 64 hidden units of a vehicle, 32 of
+// them in this lane; gam / bet point at this lane's 32 parameters (lane order)
+__device__ __forceinline__ void actor_ln_relu32(pve_v16f (&v)[2], const float *gam, const float *bet)
+{
+    pve_v16f e = v[0] * v[0];
+    e = __builtin_elementwise_fma(v[1], v[1], e);
+    const float s = ((((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]))) +
+                     (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15]))));
+    const float rstd = __builtin_amdgcn_rsqf(actor_xsum2(s) * (1.0f / (float)ACT_H) + 1e-12f);
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const pve_v16f ga = *(const pve_v16f *)(gam + 16 * m), be = *(const pve_v16f *)(bet + 16 * m);
+        const pve_v16f y = __builtin_elementwise_fma(v[m], ga * rstd, be);
+        pve_v16f z;
+#pragma unroll
+        for (int r = 0; r < 16; r++) z[r] = fmaxf(y[r], 0.f);
+        v[m] = z;
+    }
+}
+
+// One tile: x[16] = this lane's raw observation features (layout above) -> the action of vehicle j (in both of its lanes).
+// A1 / A2: the packed A operands (LDS or global memory), prm: the packed float parameters (LDS).
+// The 12 product blocks (layer 1: unit tile m x K-block kb; layer 2: m2 x kb) run as one software pipeline: the operand pair
+// (hi, lo) of block s + 2 is requested while block s multiplies (three matrix instructions, ~100 cycles), which covers an
+// L1 / L2 round trip when the operands stream from global memory (k_rollout) and keeps at most three pairs (24 registers)
+// in flight.  The opaque offset `o` pins every request to its place: without it the compiler hoists all 24 operand loads
+// to the top (96 registers) and spills.  Unit tiles are processed one after the other (one 16-register accumulator live),
+// all K-blocks of the input are split into half pairs up front.
+__device__ __forceinline__ pve_v8h actor_a_operand(const pve_v8h *A1, const pve_v8h *A2, int s, int hl, int idx)
+{   // block s: 0..3 = layer 1 (m = s >> 1, kb = s & 1), 4..11 = layer 2 (m2 = (s - 4) >> 2, kb = (s - 4) & 3)
+    return s < 4 ? A1[((hl * 2 + (s >> 1)) * 2 + (s & 1)) * 64 + idx] : A2[((hl * 2 + ((s - 4) >> 2)) * 4 + ((s - 4) & 3)) * 64 + idx];
+}
+__device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *A2, const float *prm, const float (&x)[16],
+                                              int lane)
+{
+    const int hf = lane >> 5;
+    int o = lane;
+    asm volatile("" : "+v"(o));
+    pve_v8h ah[3], al[3];                                     // operand ring
+    ah[0] = actor_a_operand(A1, A2, 0, 0, o); al[0] = actor_a_operand(A1, A2, 0, 1, o);
+    ah[1] = actor_a_operand(A1, A2, 1, 0, o); al[1] = actor_a_operand(A1, A2, 1, 1, o);
+    // ---- LayerNorm over the 28 inputs (14 + 14 of them in the two lanes; the padding entries are zeros)
+    float s0 = ((((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) +
+                (((x[8] + x[9]) + (x[10] + x[11])) + ((x[12] + x[13]) + (x[14] + x[15]))));
+    const float mean = actor_xsum2(s0) * (1.0f / (float)ACT_IN);
+    float d[16], var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        d[c] = (c >= 12 && hf) ? 0.f : x[c] - mean;            // features 28..31 do not exist
+        var = fmaf(d[c], d[c], var);
+    }
+    const float rstd0 = __builtin_amdgcn_rsqf(actor_xsum2(var) * (1.0f / (float)ACT_IN) + 1e-12f);
+    pve_v8h bh[4], bl[4];                                     // B operands of the current layer: K-blocks as half pairs
+    {
+        const pve_v16f ga = *(const pve_v16f *)(prm + PV_LN0G + 16 * hf), be = *(const pve_v16f *)(prm + PV_LN0B + 16 * hf);
+        float y[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) y[c] = fmaf(d[c], ga[c] * rstd0, be[c]);
+        actor_split8(y, bh[0], bl[0]);
+        actor_split8(y + 8, bh[1], bl[1]);
+    }
+    pve_v16f h[2], g[2];
+#pragma unroll
+    for (int s = 0; s < 12; s++) {
+        if (s + 2 < 12) {                                     // request block s + 2
+            asm volatile("" : "+v"(o));
+            ah[(s + 2) % 3] = actor_a_operand(A1, A2, s + 2, 0, o); al[(s + 2) % 3] = actor_a_operand(A1, A2, s + 2, 1, o);
+        }
+        if (s == 4) {
+            // ---- LayerNorm_1 + ReLU; K-block kb = 2 m + g of the next layer is exactly registers 8 g .. 8 g + 7 of h[m]
+            actor_ln_relu32(h, prm + PV_G1 + hf * 32, prm + PV_BE1 + hf * 32);
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) {
+                float hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) hv[e] = h[kb >> 1][8 * (kb & 1) + e];
+                actor_split8(hv, bh[kb], bl[kb]);
+            }
+        }
+        const int layer2 = s >= 4, m = layer2 ? (s - 4) >> 2 : s >> 1, kb = layer2 ? (s - 4) & 3 : s & 1;
+        pve_v16f &acc = layer2 ? g[m] : h[m];
+        if (kb == 0) acc = *(const pve_v16f *)(prm + (layer2 ? PV_B2 : PV_B1) + (hf * 2 + m) * 16);   // centered bias
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 3], bh[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 3], bl[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % 3], bh[kb], acc, 0, 0, 0);
+    }
+    actor_ln_relu32(g, prm + PV_G2 + hf * 32, prm + PV_BE2 + hf * 32);
+    // ---- dense 64 -> 1, 3 tanh
+    float part = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const pve_v16f w3 = *(const pve_v16f *)(prm + PV_W3 + (hf * 2 + m) * 16);
+#pragma unroll
+        for (int r = 0; r < 16; r++) part = fmaf(g[m][r], w3[r], part);
+    }
+    return actor_tanh3(actor_xsum2(part) + prm[PV_B3]);
+}
+
+// Every lane of the wave brings ONE vehicle's observation row (row[28], float32; `valid` = it has one) and gets that
+// vehicle's action back.  The two tiles of the wave are formed in registers: tile A = the vehicles of lanes 0..31, tile B =
+// those of lanes 32..63; one v_permlane32_swap per feature pair hands each lane the half row it contracts
+// (swap(F0, F1): a' = [F0.lo | F1.lo] = tile A, b' = [F0.hi | F1.hi] = tile B).  A tile without a valid lane is skipped
+// (wave-uniform).
+__device__ __forceinline__ float actor_wave(const pve_v8h *A1, const pve_v8h *A2, const float *prm, const float (&row)[ACT_IN],
+                                            bool valid, int lane)
+{
+    const unsigned long long vm = __ballot(valid);
+    float xa[16], xb[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const int f0 = 16 * (c >> 3) + (c & 7), f1 = f0 + 8;
+        const unsigned a = __float_as_uint(row[f0]), b = f1 < ACT_IN ? __float_as_uint(row[f1]) : 0u;
+        const pve_v2u r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        xa[c] = __uint_as_float(r[0]); xb[c] = __uint_as_float(r[1]);
+    }
+    float act = 0.f;
+    if ((unsigned)vm != 0u) {                                  // tile A (uniform)
+        const float a = actor_tile32(A1, A2, prm, xa, lane);
+        act = lane < 32 ? a : act;
+    }
+    if ((unsigned)(vm >> 32) != 0u) {                          // tile B (uniform)
+        const float a = actor_tile32(A1, A2, prm, xb, lane);
+        act = lane >= 32 ? a : act;
+    }
+    return act;
+}
+
+// pve_set_actor: flat float32 weights -> the packed buffer (one workgroup of 256 threads)
+__global__ __launch_bounds__(256) void k_actor_pack(const float *__restrict__ W, unsigned char *__restrict__ packed)
+{
+    __shared__ float cm1[ACT_IN], cm2[ACT_H], bm[2];
+    const int tid = threadIdx.x;
+    // means over the OUTPUT units (what LayerNorm subtracts): per input row of each dense kernel, and of the biases
+    if (tid < ACT_IN) { double s = 0; for (int u = 0; u < ACT_H; u++) s += (double)W[AW_W1 + tid * ACT_H + u]; cm1[tid] = (float)(s / ACT_H); }
+    if (tid >= 64 && tid < 64 + ACT_H) { const int k = tid - 64; double s = 0; for (int u = 0; u < ACT_H; u++) s += (double)W[AW_W2 + k * ACT_H + u]; cm2[k] = (float)(s / ACT_H); }
+    if (tid == 128 || tid == 129) { const int o = tid == 128 ? AW_B1 : AW_B2; double s = 0; for (int u = 0; u < ACT_H; u++) s += (double)W[o + u]; bm[tid - 128] = (float)(s / ACT_H); }
+    __syncthreads();
+    pve_v8h *A1 = (pve_v8h *)(packed + AP_A1), *A2 = (pve_v8h *)(packed + AP_A2);
+    float *prm = (float *)(packed + AP_PRM);
+    for (int n = tid; n < (4 + 8) * 64; n += 256) {           // one thread per operand vector (8 halves of one lane)
+        const int l = n & 63, t = n >> 6, hf = l >> 5, i = l & 31;
+        float w[8];
+        if (t < 4) {                                          // layer 1: m = t >> 1, kb = t & 1: A[i][8 hf + e] = W1c[16 kb + 8 hf + e][32 m + i]
+            const int m = t >> 1, kb = t & 1;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const int k = 16 * kb + 8 * hf + e; w[e] = k < ACT_IN ? W[AW_W1 + k * ACT_H + 32 * m + i] - cm1[k] : 0.f; }
+            pve_v8h hi, lo;
+            actor_split8(w, hi, lo);
+            A1[((0 * 2 + m) * 2 + kb) * 64 + l] = hi; A1[((1 * 2 + m) * 2 + kb) * 64 + l] = lo;
+        } else {                                              // layer 2: m2, kb: A[i][8 hf + e] = W2c[u(kb >> 1, 8 (kb & 1) + e, hf)][32 m2 + i]
+            const int m2 = (t - 4) >> 2, kb = (t - 4) & 3;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const int k = actor_unit(kb >> 1, 8 * (kb & 1) + e, hf); w[e] = W[AW_W2 + k * ACT_H + 32 * m2 + i] - cm2[k]; }
+            pve_v8h hi, lo;
+            actor_split8(w, hi, lo);
+            A2[((0 * 2 + m2) * 4 + kb) * 64 + l] = hi; A2[((1 * 2 + m2) * 4 + kb) * 64 + l] = lo;
+        }
+    }
+    if (tid < 64) {                                           // parameter vectors in lane order
+        const int hf = tid >> 5, m = (tid >> 4) & 1, r = tid & 15, u = actor_unit(m, r, hf);
+        prm[PV_B1 + tid] = W[AW_B1 + u] - bm[0]; prm[PV_G1 + tid] = W[AW_LN1_G + u]; prm[PV_BE1 + tid] = W[AW_LN1_B + u];
+        prm[PV_B2 + tid] = W[AW_B2 + u] - bm[1]; prm[PV_G2 + tid] = W[AW_LN2_G + u]; prm[PV_BE2 + tid] = W[AW_LN2_B + u];
+        prm[PV_W3 + tid] = W[AW_W3 + u];
+    }
+    if (tid < 32) {
+        const int hf = tid >> 4, c = tid & 15, f = actor_feature(c, hf);
+        prm[PV_LN0G + tid] = f < ACT_IN ? W[AW_LN0_G + f] : 0.f; prm[PV_LN0B + tid] = f < ACT_IN ? W[AW_LN0_B + f] : 0.f;
+    }
+    if (tid == 0) { prm[PV_B3] = W[AW_B3]; prm[PV_A0] = 0.f; prm[PV_A0 + 1] = 0.f; prm[PV_A0 + 2] = 0.f; }
+    __threadfence();
+    __syncthreads();
+    if (tid < 64) {                                           // the action of an all-zero row (what a newly spawned vehicle gets)
+        float x[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = 0.f;
+        const float a0 = actor_tile32(A1, A2, prm, x, tid);
+        if (tid == 0) prm[PV_A0] = a0;
+    }
+}
+
+// Stand-alone actor pass (pve_actor_forward / pve_step_all_actor): persistent workgroups of 4 waves sharing ONE copy of the
+// packed parameters in LDS; every wave is on its own: it loops over intersections, compacts the controlled vehicles of its
+// intersection with ballots (dense lanes), every lane loads ONE vehicle's row, and actor_wave runs the <= 2 tiles.
 template <int CAP, typename OBS_T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_h(const float *__restrict__ W, const OBS_T *__restrict__ obs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_h(const unsigned char *__restrict__ packed, const OBS_T *__restrict__ obs,
                                                  const int32_t *__restrict__ meta, double *__restrict__ actions,
                                                  int n_envs)
 {
-    // A operands: [hi | lo][unit tile m][lane][8] for layer 1 (K = 28, padded to 32), [hi | lo][K-block b][m][lane][8] for layer 2
-    __shared__ __attribute__((aligned(16))) _Float16 A1[2][4][64][8], A2[2][2][4][64][8];
-    __shared__ __attribute__((aligned(16))) float Wsm[SM_TOTAL];
+    __shared__ __attribute__((aligned(64))) unsigned char sp[AP_BYTES_PADDED];
     __shared__ unsigned char slot_of_s[4][CAP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jl = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char *slot_of = slot_of_s[wave];
     const int stride = gridDim.x * 4;
     int env = blockIdx.x * 4 + wave;
     int mt[CAP / 64];                                         // flags of the wave's next intersection (loaded one ahead)
 #pragma unroll
     for (int sub = 0; sub < CAP / 64; sub++) mt[sub] = env < n_envs ? meta[(size_t)env * CAP + sub * 64 + lane] : 0;
-    // staging: one thread per operand vector (8 halves of one lane: loads 8 weights, splits them, two 16-byte LDS writes)
-    for (int n = tid; n < (4 + 8) * 64; n += 256) {
-        const int l = n & 63, t8 = n >> 6, qq = l >> 4, col = l & 15;
-        float w[8];
-        if (t8 < 4) {                                         // layer 1, unit tile m = t8: W1[8 q + e][16 m + j]
-#pragma unroll
-            for (int e = 0; e < 8; e++) { const int k = 8 * qq + e; w[e] = k < ACT_IN ? W[AW_W1 + k * ACT_H + 16 * t8 + col] : 0.f; }
-        } else {                                              // layer 2, K-block bk, unit tile m: W2[16 (2 bk + e / 4) + 4 q + e % 4][16 m + j]
-            const int bk = (t8 - 4) >> 2, m = (t8 - 4) & 3;
-#pragma unroll
-            for (int e = 0; e < 8; e++) w[e] = W[AW_W2 + (16 * (2 * bk + (e >> 2)) + 4 * qq + (e & 3)) * ACT_H + 16 * m + col];
-        }
-        pve_v8h hi, lo;
-        split8(w, hi, lo);
-        if (t8 < 4) { *(pve_v8h *)&A1[0][t8][l][0] = hi; *(pve_v8h *)&A1[1][t8][l][0] = lo; }
-        else { *(pve_v8h *)&A2[0][(t8 - 4) >> 2][(t8 - 4) & 3][l][0] = hi; *(pve_v8h *)&A2[1][(t8 - 4) >> 2][(t8 - 4) & 3][l][0] = lo; }
-    }
-    if (tid < 2 * ACT_IN) Wsm[SM_LN0_G + tid] = W[AW_LN0_G + tid];
-    if (tid < ACT_H) {
-        Wsm[SM_B1 + tid] = W[AW_B1 + tid]; Wsm[SM_B2 + tid] = W[AW_B2 + tid]; Wsm[SM_W3 + tid] = W[AW_W3 + tid];
-    }
-    if (tid < 2 * ACT_H) { Wsm[SM_LN1_G + tid] = W[AW_LN1_G + tid]; Wsm[SM_LN2_G + tid] = W[AW_LN2_G + tid]; }
-    if (tid == 0) Wsm[SM_B3] = W[AW_B3];
-    __syncthreads();                                          // weights staged
-    const int nf = q < 3 ? 8 : ACT_IN - 24;                   // features 8 q .. 8 q + nf - 1 of the 28 live in this lane
+    for (int n = tid; n < AP_BYTES_PADDED / 16; n += 256) ((uint4 *)sp)[n] = ((const uint4 *)packed)[n];
+    __syncthreads();                                          // parameters staged
+    const pve_v8h *A1 = (const pve_v8h *)(sp + AP_A1), *A2 = (const pve_v8h *)(sp + AP_A2);
+    const float *prm = (const float *)(sp + AP_PRM);
     for (; env < n_envs; env += stride) {
         const size_t base = (size_t)env * CAP;
         int nctl = 0;
@@ -386,87 +588,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int sub = 0; sub < CAP / 64; sub++) mt[sub] = en < n_envs ? meta[(size_t)en * CAP + sub * 64 + lane] : 0;
         }
-        float xr[8];
-        int slot = slot_of[jl < nctl ? jl : 0];
-        if (nctl > 0) {
-            const OBS_T *row = obs + (base + slot) * OBSW + 8 * q;
-#pragma unroll
-            for (int e = 0; e < 8; e++) xr[e] = e < nf ? (float)row[e] : 0.f;
-        }
-        for (int v0 = 0; v0 < nctl; v0 += 16) {              // 16 vehicles per pass
+        for (int v0 = 0; v0 < nctl; v0 += 64) {              // 64 vehicles per pass (one per lane)
             int wo = 0;
             asm volatile("" : "+v"(wo));                      // (keeps the A-operand reads inside the loop)
-            const bool valid = v0 + jl < nctl;
-            const int cur_slot = slot;
-            float x[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) x[e] = xr[e];
-            if (v0 + 16 < nctl) {
-                slot = slot_of[v0 + 16 + jl < nctl ? v0 + 16 + jl : v0 + 16];
-                const OBS_T *row = obs + (base + slot) * OBSW + 8 * q;
-#pragma unroll
-                for (int e = 0; e < 8; e++) xr[e] = e < nf ? (float)row[e] : 0.f;
-            }
-            {   // LayerNorm over the 28 inputs (8, 8, 8, 4 per lane group)
-                float sum = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; e++) sum += x[e];
-                const float mean = actor_xsum(sum) / (float)ACT_IN;
-                float var = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; e++) { const float d = e < nf ? x[e] - mean : 0.f; var = fmaf(d, d, var); }
-                const float rstd = 1.0f / sqrtf(actor_xsum(var) / (float)ACT_IN + 1e-12f);
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int k = e < nf ? 8 * q + e : 0;
-                    const float inv = rstd * Wsm[SM_LN0_G + k];
-                    x[e] = e < nf ? fmaf(x[e], inv, Wsm[SM_LN0_B + k] - mean * inv) : 0.f;
-                }
-            }
-            // ---- dense 28 -> 64 (+ bias)
-            pve_v4f h[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) h[m] = *(const pve_v4f *)(Wsm + SM_B1 + 16 * m + 4 * q);
+            const bool valid = v0 + lane < nctl;
+            const int slot = slot_of[valid ? v0 + lane : 0];
+            float row[ACT_IN];
             {
-                pve_v8h xh, xl;
-                split8(x, xh, xl);
+                const OBS_T *src = obs + (base + slot) * OBSW;
 #pragma unroll
-                for (int m = 0; m < 4; m++) h[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A1[0][m][lane + wo][0], xh, h[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < 4; m++) h[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A1[0][m][lane + wo][0], xl, h[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < 4; m++) h[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A1[1][m][lane + wo][0], xh, h[m], 0, 0, 0);
+                for (int k = 0; k < ACT_IN; k++) row[k] = valid ? (float)src[k] : 0.f;
             }
-            // ---- LayerNorm_1 + ReLU, dense 64 -> 64, LayerNorm_2 + ReLU
-            actor_ln_relu16_lds(h, Wsm + SM_LN1_G, Wsm + SM_LN1_B, q);
-            pve_v4f g[4];
-#pragma unroll
-            for (int m2 = 0; m2 < 4; m2++) g[m2] = *(const pve_v4f *)(Wsm + SM_B2 + 16 * m2 + 4 * q);
-#pragma unroll
-            for (int bk = 0; bk < 2; bk++) {                  // K-block bk: this lane's units of h[2 bk], h[2 bk + 1]
-                float hv[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) hv[e] = h[2 * bk + (e >> 2)][e & 3];
-                pve_v8h hh, hl;
-                split8(hv, hh, hl);
-#pragma unroll
-                for (int m2 = 0; m2 < 4; m2++) g[m2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A2[0][bk][m2][lane + wo][0], hh, g[m2], 0, 0, 0);
-#pragma unroll
-                for (int m2 = 0; m2 < 4; m2++) g[m2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A2[0][bk][m2][lane + wo][0], hl, g[m2], 0, 0, 0);
-#pragma unroll
-                for (int m2 = 0; m2 < 4; m2++) g[m2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const pve_v8h *)&A2[1][bk][m2][lane + wo][0], hh, g[m2], 0, 0, 0);
-            }
-            actor_ln_relu16_lds(g, Wsm + SM_LN2_G, Wsm + SM_LN2_B, q);
-            // ---- dense 64 -> 1, 3 tanh
-            float part = 0.f;
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const pve_v4f w3 = *(const pve_v4f *)(Wsm + SM_W3 + 16 * m + 4 * q);
-#pragma unroll
-                for (int r = 0; r < 4; r++) part = fmaf(g[m][r], w3[r], part);
-            }
-            const float a = 3.0f * tanhf(actor_xsum(part) + Wsm[SM_B3]);
-            if (q == 0 && valid) actions[base + cur_slot] = (double)a;
+            const float a = actor_wave(A1, A2, prm + wo, row, valid, lane);
+            if (valid) actions[base + slot] = (double)a;
         }
     }
 }

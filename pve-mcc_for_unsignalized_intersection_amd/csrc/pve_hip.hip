@@ -102,19 +102,59 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(CAP == 64 ?
     }
 }
 
+// k_rollout<.., ACT>: the actor pass of one resident tick (behind STAGE: the carried state lives in the staging arrays, the
+// registers are free).  The controlled vehicles are the dense threads 0 .. n_ctl-1 -- normally all of them in wave 0, whose
+// chain is the workgroup's critical path -- so the work is split by TILE, not by owner: tile i = dense threads 32 i .. 32 i
+// + 31 goes to wave i % (CAP / 64).  A tile's rows are the float32 images of what FIN stored to obs_post a moment ago (same
+// CU: L1 / L2 hot, ordered by barrier A), addressed through the post-compaction slots the dense threads left in `adsts`
+// (255 = the vehicle is gone); lane (j, hf) fetches the half row it contracts.  act[slot] receives the action of every
+// controlled vehicle that keeps a slot.  The launch's first tick uses the same routine on the rows in HBM.
+template <int CAP>
+__device__ __forceinline__ void rollout_actor(const unsigned char *packed, const float *aprm, double *act, const uint8_t *adsts,
+                                              int n_ctl, const void *rows, bool obs_f32, size_t base, int t)
+{
+    const pve_v8h *A1 = (const pve_v8h *)(packed + AP_A1), *A2 = (const pve_v8h *)(packed + AP_A2);
+    const int lane = t & 63, hf = lane >> 5, j = lane & 31;
+    for (int tile = t >> 6; 32 * tile < n_ctl; tile += CAP / 64) {          // (uniform per wave)
+        const int slot = adsts[32 * tile + j];
+        const size_t g = (base + (slot == 255 ? 0 : slot)) * OBSW + 8 * hf;
+        float x[16];
+        if (obs_f32) {
+            const float *src = (const float *)rows + g;
+#pragma unroll
+            for (int c = 0; c < 16; c++) x[c] = (c < 12 || !hf) ? src[actor_feature(c, 0)] : 0.f;
+        } else {
+            const double *src = (const double *)rows + g;
+#pragma unroll
+            for (int c = 0; c < 16; c++) x[c] = (c < 12 || !hf) ? (float)src[actor_feature(c, 0)] : 0.f;
+        }
+        const float a = actor_tile32(A1, A2, aprm, x, lane);
+        if (lane < 32 && slot != 255) act[slot] = (double)a;
+    }
+}
+
 // pve_step_many: R.n_ticks ticks of one intersection per workgroup, the state resident in registers / LDS between the
 // ticks (pve_tick_core.h, "k_rollout").  Per tick only the outputs go to HBM; the action of the next tick (pool) and
 // the next arrival times are prefetched under the tail of the current one.
 // WPE = waves per SIMD the register allocation is held to: 4 (<= 128 VGPR, no spills: 8 workgroups of 128 threads per CU,
 // i.e. 4096 intersections in exactly two rounds) or 5 (<= 96 VGPR, 10 per CU for stream-pipelined sub-batches).
 // PROF: the diagnostics build (pve_debug_phase_cycles) accumulates per-phase clock ticks over the ticks of the launch.
-template <int CAP, int WPE, bool PROF = false>
+// ACT: pve_step_many(PVE_SRC_ACTOR) -- the closed loop of main.py:398-441 resident on the chip.  The dense thread of every
+// controlled vehicle keeps the float32 observation row it has just built in FIN; behind STAGE (the carried state lives in
+// the staging arrays by then, the registers are free) the wave runs the actor on its <= 2 tiles of 32 vehicles
+// (pve_actor.h: actor_wave, the same function the stand-alone k_actor_h calls), A operands streamed from L1 / L2, the
+// float parameters in 2 KB of LDS, and deposits next tick's actions where RELOAD looks for them (act_next).  No new
+// barrier; still ticks are staged like the others.  The first tick of a launch takes its rows from HBM.
+template <int CAP, int WPE, bool PROF = false, bool ACT = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout(const Const c_arg, const Params P_arg,
                                                                                                const RolloutArgs R_arg)
 {
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     __shared__ Shared<CAP> sh;
+    __shared__ __attribute__((aligned(64))) float aprm[ACT ? PV_TOTAL : 1];
+    __shared__ uint8_t adsts[ACT ? CAP : 1];         // post-compaction slot of every dense thread's vehicle (255: gone)
+    int adst = -1;
     int t0_ = threadIdx.x;
     int env0_ = blockIdx.x;
     // the first wave carries the dense-mapped phases (the critical chain of the workgroup), the second one mostly waits at
@@ -142,7 +182,23 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
         pool_idx = R.pool_tick0;
         n_ticks = R.n_ticks;
+        if constexpr (ACT) {
+            // the first tick's actions = actor(rows in HBM), before the state is loaded (nothing else is live): the controlled
+            // slots are compacted into `adsts` as if they were dense threads (wave 1's ranks follow wave 0's count)
+            const float *gp = (const float *)(R.actor_packed + AP_PRM);
+            for (int n = t0_; n < PV_TOTAL; n += CAP) aprm[n] = gp[n];
+            const int mt = P.i32[I_META][(size_t)env0_ * CAP + t0_];
+            const bool cc = (mt & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
+            vote<CAP / 64>(sh.m_ctl, t0_, cc);
+            lds_barrier();
+            if (cc) adsts[mask_rank<CAP / 64>(sh.m_ctl, t0_)] = (uint8_t)t0_;
+            const int nc = mask_count<CAP / 64>(sh.m_ctl);
+            lds_barrier();                               // parameters staged, list complete
+            rollout_actor<CAP>(R.actor_packed, aprm, sh.act_next, adsts, nc, R.actor_obs, P.obs_f32 != 0, (size_t)env0_ * CAP, t0_);
+            lds_barrier();
+        }
         T::ph_load(c, P, env0_, t0_, sh, r);            // P.actions = the first tick's actions
+        if constexpr (ACT) r.act = sh.act_next[t0_];    // (uncontrolled slots: whatever is there, masked in S1)
     }
     for (int k = 0; k < n_ticks; k++) {
         // The loop body is one tick of the single-tick kernel.  Without the two opaque copies below the compiler's
@@ -193,9 +249,13 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         T::ph_lock2(t, sh, r);
         lds_barrier();                                // (also what orders the previous tick's output stores before this tick's)
         PVE_PHASE_MARK(8)
-        T::ph_park_action(t, sh, r);
+        if constexpr (!ACT) T::ph_park_action(t, sh, r);
         const Outputs O = T::tick_outputs(P, R, k);
-        T::template ph_final<true>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks);
+        if constexpr (ACT) {
+            adst = -1;
+            T::template ph_final<true>(c, P, O, env, t, sh, r, fc, true, &adst);
+            adsts[t] = (uint8_t)(adst < 0 ? 255 : adst);  // (dense thread t; threads >= n_ctl: 255)
+        } else T::template ph_final<true>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks);
         PVE_PHASE_MARK(9)
         if (fc.still) {                               // (uniform) nobody moves: the registers carry over
             T::ph_stage_header(t, sh, fc);
@@ -203,6 +263,14 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         } else {
             lds_barrier();                            // A: nobody reads the tick's work arrays any more
             T::ph_stage(c, t, sh, r, fc);
+            if constexpr (ACT) {
+                // next tick's actions: the vehicle lane t spawns gets the action of an all-zero row (ref :380, :420), the
+                // controlled vehicles that stay get actor(row)
+                if (fc.sp_slot >= 0) sh.act_next[fc.sp_slot] = (double)aprm[PV_A0];
+                if (k + 1 < n_ticks)
+                    rollout_actor<CAP>(R.actor_packed, aprm, sh.act_next, adsts, fc.n_ctl, O.obs_post, P.obs_f32 != 0,
+                                       (size_t)env * CAP, t);
+            }
             lds_barrier();                            // B: the staging area is complete
             if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
         }
@@ -409,7 +477,8 @@ struct Backend {
     static int launch_rollout(const Const &c, const Params &P_in, const RolloutArgs &R, int cap, void *stream, std::string &err)
     {
         static const bool off = getenv("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
-        if (off || R.source == 2 /* PVE_SRC_ACTOR: actor + tick launches */) return 1;
+        static const bool act_off = getenv("PVE_NO_ROLLOUT_ACTOR") != nullptr;   // A/B knob: actor + tick launches instead
+        if (off || (R.source == 2 /* PVE_SRC_ACTOR */ && (act_off || R.exact_f32 || P_in.phase_cycles))) return 1;
         hipStream_t s = (hipStream_t)stream;
         Params P = P_in;
         RolloutArgs Rk = R;
@@ -418,7 +487,10 @@ struct Backend {
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
         static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
-        if (P.phase_cycles) {
+        if (R.source == 2) {
+            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
+            else hipLaunchKernelGGL((k_rollout<128, 4, false, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
+        } else if (P.phase_cycles) {
             if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
             else hipLaunchKernelGGL((k_rollout<128, 4, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
@@ -458,11 +530,19 @@ struct Backend {
         else hipLaunchKernelGGL(k_compact<128>, dim3(P.n_envs), dim3(128), 0, s, P);
         return check_launch(err);
     }
-    template <typename OBS_T>
-    static void launch_actor_t(const float *W, const OBS_T *obs, const int32_t *meta, double *actions, int n_envs, int cap,
-                               bool exact_f32, hipStream_t s)
+    static int pack_actor(const float *W, float *flat, unsigned char *packed, void *stream, std::string &err)
     {
-        // persistent workgroups of 4 waves (the dense kernels are staged in LDS once per workgroup): 4 per CU, one wave
+        hipStream_t s = (hipStream_t)stream;
+        hipError_t e = hipMemcpyAsync(flat, W, sizeof(float) * AW_TOTAL, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { err = hip_err("hipMemcpyAsync", e); return -1; }
+        hipLaunchKernelGGL(k_actor_pack, dim3(1), dim3(256), 0, s, W, packed);
+        return check_launch(err);
+    }
+    template <typename OBS_T>
+    static void launch_actor_t(const float *W, const unsigned char *packed, const OBS_T *obs, const int32_t *meta, double *actions,
+                               int n_envs, int cap, bool exact_f32, hipStream_t s)
+    {
+        // persistent workgroups of 4 waves (the parameters are staged in LDS once per workgroup): 4 per CU, one wave
         // per intersection at a time
         static const int wgs = [] { const char *g = getenv("PVE_ACTOR_GRID"); const int v = g ? atoi(g) : 0; return v > 0 ? v : 1024; }();
         const int grid = (n_envs + 3) / 4 < wgs ? (n_envs + 3) / 4 : wgs;
@@ -470,16 +550,16 @@ struct Backend {
             if (cap == 64) hipLaunchKernelGGL((k_actor_t<64, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
             else hipLaunchKernelGGL((k_actor_t<128, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
         } else {
-            if (cap == 64) hipLaunchKernelGGL((k_actor_h<64, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
-            else hipLaunchKernelGGL((k_actor_h<128, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);
+            if (cap == 64) hipLaunchKernelGGL((k_actor_h<64, OBS_T>), dim3(grid), dim3(256), 0, s, packed, obs, meta, actions, n_envs);
+            else hipLaunchKernelGGL((k_actor_h<128, OBS_T>), dim3(grid), dim3(256), 0, s, packed, obs, meta, actions, n_envs);
         }
     }
-    static int launch_actor(const float *W, const void *obs, int mode, const int32_t *meta, double *actions, int n_envs,
-                            int cap, void *stream, std::string &err)
+    static int launch_actor(const float *W, const unsigned char *packed, const void *obs, int mode, const int32_t *meta,
+                            double *actions, int n_envs, int cap, void *stream, std::string &err)
     {
         hipStream_t s = (hipStream_t)stream;
-        if (mode & 1) launch_actor_t<float>(W, (const float *)obs, meta, actions, n_envs, cap, (mode & 2) != 0, s);
-        else launch_actor_t<double>(W, (const double *)obs, meta, actions, n_envs, cap, (mode & 2) != 0, s);
+        if (mode & 1) launch_actor_t<float>(W, packed, (const float *)obs, meta, actions, n_envs, cap, (mode & 2) != 0, s);
+        else launch_actor_t<double>(W, packed, (const double *)obs, meta, actions, n_envs, cap, (mode & 2) != 0, s);
         return check_launch(err);
     }
     static int launch_probe(const Params &P, int cap, int *sink, void *stream, std::string &err)

@@ -230,4 +230,5 @@ struct pve_handle_s {
     bool has_arrivals, is_reset;
     long long ticks_since_reset;
     unsigned long long *phase_cycles;
+    bool has_actor;                   // pve_set_actor installed an actor in the workspace
 };

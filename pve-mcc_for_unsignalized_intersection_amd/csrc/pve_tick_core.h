@@ -1227,9 +1227,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // k_rollout, `still` ticks: when nobody is deleted and nobody spawns every vehicle keeps its slot, so nothing has to
     // move: no staging, no barriers A / B, no reload -- the registers simply carry over (about every second tick at the bench
     // load).  `full` (uniform) forces the staged form: the last tick of a launch, whose state FLUSH takes from the staging area.
+    // adst (k_rollout with the actor on the chip): the post-compaction slot of the dense thread's vehicle (< 0: gone) for the
+    // actor pass behind STAGE
     template <bool RES, class OutT>
     static PVE_HD void ph_final(const PVE_AS4 Const &c, const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh,
-                                Regs &r, FinCarry &fc, bool full = true)
+                                Regs &r, FinCarry &fc, bool full = true, int *adst = nullptr)
     {
         EnvHeader &gh = P.headers[env];
         const int N = sh.hd.n_alive;
@@ -1394,6 +1396,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             int ns = -1;
             if (mask_test(keep, sl)) ns = mask_below<NW>(keep, sl) + __builtin_popcount(sp & ((1u << r.dlane) - 1u));
             if (O.reward) O.reward[gd] = r.reward;
+            if (adst) *adst = ns;
             // the 6 neighbours' speed, acceleration, lane and lane start: two batches of unconditional LDS gathers on clamped
             // slots (one guarded block per neighbour = six serial round trips), shared by the neighbour ids and the row
             int xc[NNB], nln[NNB], nls[NNB]; double nv[NNB], na[NNB];

@@ -138,15 +138,20 @@ struct Params {
 // pve_step_many: action source and output addressing of a multi-tick launch (k_rollout)
 struct RolloutArgs {
     const double *pool;          // PVE_SRC_POOL: [n_pool][n_envs][cap]
-    const float *actor_w;        // PVE_SRC_ACTOR
-    const void *actor_obs;
-    int32_t n_ticks, source, n_pool, pool_tick0, trajectory, pad_;
+    const unsigned char *actor_packed;   // PVE_SRC_ACTOR: the packed actor parameters (pve_actor.h, k_actor_pack)
+    const void *actor_obs;       // PVE_SRC_ACTOR: the observation rows the first tick's actor reads
+    int32_t n_ticks, source, n_pool, pool_tick0, trajectory;
+    int32_t exact_f32;           // PVE_CFG_ACTOR_F32: the resident kernel has no exact-float32 actor (per-tick launches instead)
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// pve_set_actor keeps two images of the actor in the handle's workspace: the flat float32 weights (the exact float32
+// kernel k_actor_t reads them) and the packed split-half form (pve_actor.h: AP_BYTES_PADDED)
+constexpr size_t ACTOR_FLAT_BYTES = 25600, ACTOR_PACKED_BYTES = 26880;
+
 struct Layout {
-    size_t off_headers, off_f64[NF64], off_i32[NI32], total;
+    size_t off_headers, off_f64[NF64], off_i32[NI32], off_actor_flat, off_actor_packed, total;
 };
 
 inline Layout make_layout(int n_envs, int cap)
@@ -156,6 +161,8 @@ inline Layout make_layout(int n_envs, int cap)
     L.off_headers = o; o = align_up(o + sizeof(EnvHeader) * (size_t)n_envs, 256);
     for (int k = 0; k < NF64; k++) { L.off_f64[k] = o; o = align_up(o + 8 * (size_t)n_envs * cap, 256); }
     for (int k = 0; k < NI32; k++) { L.off_i32[k] = o; o = align_up(o + 4 * (size_t)n_envs * cap, 256); }
+    L.off_actor_flat = o; o = align_up(o + ACTOR_FLAT_BYTES, 256);
+    L.off_actor_packed = o; o = align_up(o + ACTOR_PACKED_BYTES, 256);
     L.total = o;
     return L;
 }

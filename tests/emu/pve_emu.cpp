@@ -188,8 +188,13 @@ struct Backend {
         return 0;
     }
     // the canonical float32 evaluation order of csrc/pve_actor.h (what the matrix-core kernel computes)
-    static int launch_actor(const float *W, const void *obs_v, int obs_f32, const int32_t *meta, double *actions, int n_envs,
-                            int cap, void *, std::string &)
+    static int pack_actor(const float *W, float *flat, unsigned char *, void *, std::string &)
+    {
+        memcpy(flat, W, sizeof(float) * AW_TOTAL);
+        return 0;
+    }
+    static int launch_actor(const float *W, const unsigned char *, const void *obs_v, int obs_f32, const int32_t *meta,
+                            double *actions, int n_envs, int cap, void *, std::string &)
     {
         const double *obs = (const double *)obs_v;
         const float *obsf = (const float *)obs_v;
