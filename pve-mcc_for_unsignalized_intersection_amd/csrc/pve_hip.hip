@@ -190,6 +190,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             const int mt = P.i32[I_META][(size_t)env0_ * CAP + t0_];
             const bool cc = (mt & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
             vote<CAP / 64>(sh.m_ctl, t0_, cc);
+            adsts[t0_] = 255;                            // (entries beyond the controlled count: no vehicle)
             lds_barrier();
             if (cc) adsts[mask_rank<CAP / 64>(sh.m_ctl, t0_)] = (uint8_t)t0_;
             const int nc = mask_count<CAP / 64>(sh.m_ctl);

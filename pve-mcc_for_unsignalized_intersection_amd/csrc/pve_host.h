@@ -22,6 +22,7 @@ inline Const make_const(const pve_config &cfg)
     c.deltaT = cfg.deltaT; c.dt2 = pow(cfg.deltaT, 2);
     c.vm = cfg.vm; c.vM = cfg.vM; c.am = cfg.am; c.aM = cfg.aM; c.v0 = cfg.v0;
     c.abs_am = fabs(cfg.am); c.two_abs_am = 2 * fabs(cfg.am);
+    c.inv_abs_am = 1.0 / c.abs_am; c.inv_two_abs_am = 1.0 / c.two_abs_am;
     c.aM_minus_am = cfg.aM - cfg.am;
     c.inv_dt = 1.0 / cfg.deltaT; c.inv_span = 1.0 / (cfg.aM - cfg.am);
     c.collision_thr = cfg.collision_thr; c.lock_mean_thr = cfg.collision_thr + 3;

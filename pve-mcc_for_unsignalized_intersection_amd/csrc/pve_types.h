@@ -38,6 +38,7 @@ struct Const {
     double deltaT, dt2;            // dt2 = pow(deltaT, 2) (ref :1529)
     double vm, vM, am, aM, v0;
     double abs_am, two_abs_am;     // |am|, 2*|am| (ref :1513-1514)
+    double inv_abs_am, inv_two_abs_am;   // their correctly rounded reciprocals (div_const: exact division by a constant)
     double aM_minus_am;            // float(aM - am) (ref :319)
     double inv_dt, inv_span;       // 1/deltaT, 1/(aM - am): reward-only terms use a multiplication (float output, ~1 ulp)
     double collision_thr, lock_mean_thr;   // thr, thr + 3 (ref :1471, 1495)
