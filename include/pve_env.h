@@ -50,7 +50,7 @@ enum {
 #define PVE_CFG_OBS_F32      0x2   /* flags: pve_outputs.obs_post and the actor's obs input hold float32 [n_envs][cap][28]
                                       (the type the actor consumes, model_agent_maddpg.py:15; SURVEY.md 8d "FP32 observation
                                       output": 268 instead of 380 algorithmic bytes per slot-step).  Fused ticks only:
-                                      obs_pre / state_pre / pve_compact(obs) stay float64 and are refused with this flag. */
+                                      obs_pre / state_pre follow (lane_num 12; refused for lane_num 4 / 8); pve_compact(obs) is refused. */
 #define PVE_CFG_GEO_SCAN     0x4   /* flags (diagnostics): the general-geometry kernel finds list members by scanning every controlled
                                       vehicle (its fallback when an intersection's lists overflow the LDS entry pool) instead of reading
                                       the per-route lists; results are identical (tested) */
@@ -79,8 +79,9 @@ typedef struct pve_config {
 typedef struct pve_outputs {
     double  *obs_post;      /* [n_envs][cap][28]  (float32 rows with PVE_CFG_OBS_F32) row 0 of the state (ref :1336) of the vehicle now in
                                each slot; zeros for vehicles spawned this tick (ref :380,420) */
-    double  *obs_pre;       /* [n_envs][cap][28]  same rows, pre-compaction indexing (`re_state[k][0]`) */
-    double  *state_pre;     /* [n_envs][cap][7][28] full state incl. neighbour rows (ref :1325-1337);
+    double  *obs_pre;       /* [n_envs][cap][28]  same rows, pre-compaction indexing (`re_state[k][0]`); float32 like obs_post with
+                               PVE_CFG_OBS_F32 (lane_num 12) */
+    double  *state_pre;     /* [n_envs][cap][7][28] full state incl. neighbour rows (ref :1325-1337), same element type;
                                needs obs_prev_post and obs_pre */
     const double *obs_prev_post; /* obs_post buffer written by the previous tick (stale neighbour rows, ref :1332) */
     double  *reward;        /* [n_envs][cap]  pre; 0 for uncontrolled slots (ref :311-320, 346, 357) */
@@ -220,7 +221,10 @@ int pve_step_all_actor(pve_handle h, const float *weights, const void *obs_in, d
  * from C.
  * trajectory = 0: every tick overwrites the `out` buffers (the last tick's outputs remain; metrics accumulate in the
  * handle as usual); trajectory = 1: every non-NULL `out` buffer holds n_ticks consecutive per-tick blocks
- * ([n_ticks][n_envs][cap]...), the roll-out a trainer consumes.  obs_pre / state_pre are not available here. */
+ * ([n_ticks][n_envs][cap]...), the roll-out a trainer consumes.  The training outputs (lane_num 12): obs_pre may be
+ * requested in either form; state_pre needs trajectory = 1 (tick k reads the stale neighbour rows from block k - 1 of
+ * obs_post, tick 0 from out->obs_prev_post = the rows stored before this call), i.e. a MADDPG trainer gets `re_state` and the
+ * 7-action vectors (column 2 of the 7 rows, ref :290) of every tick of the roll-out without leaving the resident kernel. */
 enum { PVE_SRC_ZERO = 0, PVE_SRC_POOL = 1, PVE_SRC_ACTOR = 2 };
 typedef struct pve_rollout {
     int32_t n_ticks;

@@ -100,7 +100,9 @@ class BatchedIntersections:
             self._obs = [torch.zeros(E, K, 28, dtype=obs_dtype, device=dev)
                          for _ in range(2 if "state_pre" in names else 1)]
             self._obs_cur = 0
-        shapes = dict(obs_pre=((E, K, 28), torch.float64), state_pre=((E, K, 7, 28), torch.float64),
+        if obs_dtype == torch.float32 and self.lane_num != 12 and ("obs_pre" in names or "state_pre" in names):
+            raise PveError("obs_pre / state_pre with float32 rows need lane_num = 12")
+        shapes = dict(obs_pre=((E, K, 28), obs_dtype), state_pre=((E, K, 7, 28), obs_dtype),
                       reward=((E, K), torch.float64), flags=((E, K), torch.int32), lanej=((E, K), torch.int32),
                       nbr=((E, K, 6), torch.int32), new_slot=((E, K), torch.int32), env_out=((E, 8), torch.int32))
         for n in names:
@@ -338,8 +340,8 @@ class BatchedIntersections:
             ro.source = _capi.SRC_ZERO
         else:
             raise PveError("unknown action source %r" % (source,))
-        if "obs_pre" in self.out or "state_pre" in self.out:
-            raise PveError("step_many: obs_pre / state_pre are single-tick outputs (use step())")
+        if "state_pre" in self.out and not trajectory:
+            raise PveError("step_many: state_pre needs a trajectory roll-out (every tick reads the rows the previous one stored)")
         if not trajectory:
             o = self._outputs_struct(flip_obs=False)
             check(self.lib, self.lib.pve_step_many(self._h, C.byref(ro), C.byref(o)), "pve_step_many")
@@ -359,6 +361,10 @@ class BatchedIntersections:
                 traj = self.alloc_trajectory(n_ticks)
             for n, tns in traj.items():
                 setattr(o, n, tns.data_ptr())
+            if "state_pre" in self.out:      # the stale neighbour rows of the first tick: what the previous tick stored
+                o.obs_prev_post = self._obs[self._obs_cur].data_ptr()
+                if not update_views:
+                    raise PveError("step_many with state_pre reads the handle's observation view: update_views must stay True")
             check(self.lib, self.lib.pve_step_many(self._h, C.byref(ro), C.byref(o)), "pve_step_many")
             self.ticks += n_ticks
             if n_ticks > 0 and update_views:     # the handle's single-tick views keep showing the latest tick

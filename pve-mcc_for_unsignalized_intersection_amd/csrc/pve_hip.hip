@@ -145,7 +145,9 @@ __device__ __forceinline__ void rollout_actor(const unsigned char *packed, const
 // (pve_actor.h: actor_wave, the same function the stand-alone k_actor_h calls), A operands streamed from L1 / L2, the
 // float parameters in 2 KB of LDS, and deposits next tick's actions where RELOAD looks for them (act_next).  No new
 // barrier; still ticks are staged like the others.  The first tick of a launch takes its rows from HBM.
-template <int CAP, int WPE, bool PROF = false, bool ACT = false>
+// TRAIN: the training outputs (obs_pre, state_pre: SURVEY 8 f3) are written per tick; a variant of its own so that the
+// default kernel keeps its register allocation (123 VGPR, no scratch).
+template <int CAP, int WPE, bool PROF = false, bool ACT = false, bool TRAIN = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout(const Const c_arg, const Params P_arg,
                                                                                                const RolloutArgs R_arg)
 {
@@ -251,18 +253,19 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         lds_barrier();                                // (also what orders the previous tick's output stores before this tick's)
         PVE_PHASE_MARK(8)
         if constexpr (!ACT) T::ph_park_action(t, sh, r);
-        const Outputs O = T::tick_outputs(P, R, k);
+        const Outputs O = T::template tick_outputs<TRAIN>(P, R, k);
         if constexpr (ACT) {
             adst = -1;
             T::template ph_final<true>(c, P, O, env, t, sh, r, fc, true, &adst);
             adsts[t] = (uint8_t)(adst < 0 ? 255 : adst);  // (dense thread t; threads >= n_ctl: 255)
-        } else T::template ph_final<true>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks);
+        } else T::template ph_final<true>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
         PVE_PHASE_MARK(9)
         if (fc.still) {                               // (uniform) nobody moves: the registers carry over
             T::ph_stage_header(t, sh, fc);
             T::ph_carry_over(t, sh, r, fc);
         } else {
             lds_barrier();                            // A: nobody reads the tick's work arrays any more
+            if (TRAIN && O.state_pre) T::ph_state(P, O, env, t, sh, r);   // (uniform; barrier A also orders the obs_pre rows of this tick)
             T::ph_stage(c, t, sh, r, fc);
             if constexpr (ACT) {
                 // next tick's actions: the vehicle lane t spawns gets the action of an all-zero row (ref :380, :420), the
@@ -488,9 +491,16 @@ struct Backend {
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
         static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
+        const bool train = P.out.obs_pre || P.out.state_pre;
         if (R.source == 2) {
-            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
+            if (train) {
+                if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
+                else hipLaunchKernelGGL((k_rollout<128, 4, false, true, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
+            } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
             else hipLaunchKernelGGL((k_rollout<128, 4, false, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
+        } else if (train) {
+            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
+            else hipLaunchKernelGGL((k_rollout<128, 4, false, false, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         } else if (P.phase_cycles) {
             if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
             else hipLaunchKernelGGL((k_rollout<128, 4, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);

@@ -1441,9 +1441,15 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                     row[6 + 4 * k] = has ? na[k] : 0.0; row[7 + 4 * k] = has ? (double)nln[k] : 0.0;
                 }
                 if (O.obs_pre) {
-                    double *o = O.obs_pre + gd * OBSW;
+                    if (P.obs_f32) {                    // (12-lane kernels: obs_pre / state_pre follow the row type)
+                        float *o = (float *)O.obs_pre + gd * OBSW;
 #pragma unroll
-                    for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                        for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
+                    } else {
+                        double *o = O.obs_pre + gd * OBSW;
+#pragma unroll
+                        for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                    }
                 }
                 if (O.obs_post && ns >= 0) {
                     if (P.obs_f32) {                    // uniform: float32 rows (half the bytes of the largest output)
@@ -1471,6 +1477,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // and FLUSH after the last tick.  Only the per-tick outputs (and the prefetched actions / arrival times) touch HBM.
     //
     // this tick's block of the output buffers (trajectory roll-outs: block k; else the same buffers every tick)
+    template <bool TRAIN = true>
     static PVE_HD Outputs tick_outputs(const PVE_AS4 Params &P, const PVE_AS4 RolloutArgs &R, int k)
     {
         // (all pointers are loaded in one go and shifted with arithmetic: a null test + branch per pointer is a serial chain
@@ -1479,8 +1486,16 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         const long long s = R.trajectory ? (long long)k * P.n_envs * CAP : 0;
         const long long se = R.trajectory ? (long long)k * P.n_envs * 8 : 0;
         const long long f32 = P.obs_f32 ? 1 : 0;
-        o.obs_post = (double *)((char *)P.out.obs_post + (P.out.obs_post ? s * OBSW * (f32 ? 4 : 8) : 0));
-        o.obs_pre = nullptr; o.state_pre = nullptr; o.obs_prev_post = nullptr;
+        const long long rowb = OBSW * (f32 ? 4 : 8);
+        o.obs_post = (double *)((char *)P.out.obs_post + (P.out.obs_post ? s * rowb : 0));
+        // training outputs: this tick's rows with pre-compaction indexing and the 7 x 28 states; the stale
+        // neighbour rows are what the PREVIOUS tick stored: the caller's rows for the launch's first tick, then block k - 1
+        if (TRAIN) {
+            o.obs_pre = (double *)((char *)P.out.obs_pre + (P.out.obs_pre ? s * rowb : 0));
+            o.state_pre = (double *)((char *)P.out.state_pre + (P.out.state_pre ? s * rowb * (NNB + 1) : 0));
+            o.obs_prev_post = (k == 0 || !P.out.obs_post) ? (const double *)R.prev_rows
+                                                          : (const double *)((const char *)o.obs_post - (long long)P.n_envs * CAP * rowb);
+        } else { o.obs_pre = nullptr; o.state_pre = nullptr; o.obs_prev_post = nullptr; }
         o.reward = P.out.reward + (P.out.reward ? s : 0);
         o.flags = P.out.flags + (P.out.flags ? s : 0);
         o.lanej = P.out.lanej + (P.out.lanej ? s : 0);
@@ -1595,23 +1610,30 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // neighbour precedes us in (lane, j) order ("fresh", read back from obs_pre written in FIN), else
     // the row it stored last tick ("stale", obs_prev_post at the same slot); zeros when absent (ref :1335).
     // Runs after a workgroup barrier + fence so that obs_pre rows of the other threads are visible.
-    static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    template <class ROW, class OutT>
+    static PVE_HD void state_rows(const OutT &O, size_t base, const Regs &r)
     {
-        if (!P.out.state_pre || !r.dctl) return;          // (dense mapping: the rows of the vehicle in slot ds)
-        const size_t base = (size_t)env * CAP;
         const int sl = r.ds;
-        double *dst = P.out.state_pre + (base + sl) * (size_t)((NNB + 1) * OBSW);
-        const double *own = P.out.obs_pre + (base + sl) * OBSW;
+        ROW *dst = (ROW *)O.state_pre + (base + sl) * (size_t)((NNB + 1) * OBSW);
+        const ROW *pre = (const ROW *)O.obs_pre, *prev = (const ROW *)O.obs_prev_post;
+        const ROW *own = pre + (base + sl) * OBSW;
         for (int k = 0; k < OBSW; k++) dst[k] = own[k];
         for (int q = 0; q < NNB; q++) {
             const int x = r.kr[q];
-            double *row = dst + (q + 1) * OBSW;
-            if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = 0.0; continue; }
-            const double *src = (x < sl) ? (P.out.obs_pre + (base + x) * OBSW)
-                                        : (P.out.obs_prev_post + (base + x) * OBSW);
+            ROW *row = dst + (q + 1) * OBSW;
+            if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = (ROW)0; continue; }
+            const ROW *src = (x < sl) ? (pre + (base + x) * OBSW) : (prev + (base + x) * OBSW);
             for (int k = 0; k < OBSW; k++) row[k] = src[k];
         }
     }
+    template <class OutT>
+    static PVE_HD void ph_state(const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh, Regs &r)
+    {
+        if (!O.state_pre || !r.dctl) return;              // (dense mapping: the rows of the vehicle in slot ds)
+        if (P.obs_f32) state_rows<float>(O, (size_t)env * CAP, r);
+        else state_rows<double>(O, (size_t)env * CAP, r);
+    }
+    static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r) { ph_state(P, P.out, env, t, sh, r); }
 
     // ============================================================== COMPACT (delete_vehicle only)
     static PVE_HD void ph_c_load(const PVE_AS4 Params &P, int env, int t, Sh &sh, CRegs &r)

@@ -83,11 +83,13 @@ template <int CAP> static void emu_rollout(const Const &c, const Params &P, cons
             for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_park_action(t, sh, regs[t]);
             const Outputs O = T::tick_outputs(P, R, k);
-            for (int t = 0; t < CAP; t++) T::template ph_final<true>(c, P, O, env, t, sh, regs[t], fcs[t], k + 1 == R.n_ticks);
+            for (int t = 0; t < CAP; t++)
+                T::template ph_final<true>(c, P, O, env, t, sh, regs[t], fcs[t], k + 1 == R.n_ticks || O.state_pre != nullptr);
             if (fcs[0].still) {                       // (uniform) nobody moves: the registers carry over
                 for (int t = 0; t < CAP; t++) T::ph_stage_header(t, sh, fcs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_carry_over(t, sh, regs[t], fcs[t]);
             } else {
+                if (O.state_pre) for (int t = 0; t < CAP; t++) T::ph_state(P, O, env, t, sh, regs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_stage(c, t, sh, regs[t], fcs[t]);
                 if (k + 1 < R.n_ticks) for (int t = 0; t < CAP; t++) T::ph_reload(t, sh, regs[t]);
             }

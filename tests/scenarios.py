@@ -422,14 +422,26 @@ def check_obs_f32(backend, lane_num=12, n_envs=3, capacity=128, ticks=120, seed=
         assert np.array_equal(x64.astype(np.float32), x32), "tick %d: float32 rows are not float32(float64 rows)" % t
     for k in STATE_F + STATE_I:
         assert np.array_equal(_np(b64.state_field(k)), _np(b32.state_field(k))), k
-    try:
-        bad = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre"), lane_num=lane_num,
-                         intentions=ch, obs_dtype=torch.float32)
-        bad.reset()
-        bad.step(None)
-        raise AssertionError("obs_pre must be refused with float32 observations")
-    except PveError:
-        pass
+    if lane_num == 12:
+        # the training outputs follow the row type (12-lane kernels): obs_pre == float32(float64 obs_pre)
+        p64 = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "flags"))
+        p32 = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "flags"), obs_dtype=torch.float32)
+        p64.reset(); p32.reset()
+        for t in range(60):
+            a = torch.as_tensor(rng.uniform(-2, 2, size=(n_envs, capacity))).to(b64.device)
+            o64, o32 = p64.step(a), p32.step(a)
+            ctl = (_np(o64["flags"]) & 2) != 0
+            assert o32["obs_pre"].dtype == torch.float32
+            assert np.array_equal(_np(o64["obs_pre"])[ctl].astype(np.float32), _np(o32["obs_pre"])[ctl]), "tick %d: obs_pre" % t
+    else:
+        try:
+            bad = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre"), lane_num=lane_num,
+                             intentions=ch, obs_dtype=torch.float32)
+            bad.reset()
+            bad.step(None)
+            raise AssertionError("obs_pre must be refused with float32 observations for lane_num 4 / 8")
+        except PveError:
+            pass
 
 
 def check_pipelined_equals_single(backend, n_envs=7, n_sub=3, capacity=128, ticks=150, seed=61, actor=False):
@@ -533,7 +545,7 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
     assert many.step_many(0, source=source) is not None          # zero ticks: a no-op
     batches_equal(one, many, "after a zero-tick call")
     # misuse
-    bad = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "flags"))
+    bad = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "state_pre", "flags"))
     bad.reset()
     for fn in (lambda: bad.step_many(2, source="zero"), lambda: one.step_many(2, source="pool"),
                lambda: many.step_many(2, source="nope")):
@@ -542,6 +554,56 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
             raise AssertionError("misuse accepted")
         except PveError:
             pass
+
+
+def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=1100.0, calls=(40, 25, 60, 35), seed=81, n_pool=7,
+                               obs_dtype=torch.float64, chunk=0, source="pool"):
+    """Training outputs on the fast path: pve_step_many trajectory roll-outs with
+    state_pre -- the 7 x 28 states with fresh / stale neighbour rows (ref :1325-1337) and the 7-action vectors (column 2,
+    ref :290) -- compared with the oracle at EVERY tick of every env (ids, neighbours, rewards, row 0, full state), across
+    call boundaries (the first tick of a call reads the rows the previous call stored) and chunked launches.  float32
+    rows: the same within float32 round-off of the stored rows."""
+    rng = np.random.default_rng(seed)
+    total = sum(calls)
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed)
+    outs = ("obs_post", "obs_pre", "state_pre", "reward", "flags", "nbr", "lanej", "env_out", "new_slot")
+    b = make_batch(arr, n_envs, capacity, backend, outputs=outs, obs_dtype=obs_dtype)
+    b.reset()
+    pool_np = rng.uniform(-3, 3, size=(n_pool, n_envs, capacity)).astype(np.float32).astype(np.float64)
+    if source == "pool":
+        b.set_action_pool(torch.as_tensor(pool_np))
+    oracles = [OracleEnv(arr[e]) for e in range(n_envs)]
+    tol = 1e-9 if obs_dtype == torch.float64 else 2e-6          # float32 rows: relative round-off of the stored values
+    t, n_ctl_total = 0, 0
+    ring = [b.alloc_trajectory(max(calls)) for _ in range(2)]
+    for ci, n in enumerate(calls):
+        traj = b.step_many(n, source=source, trajectory=ring[ci & 1] if ci else True, chunk=chunk)
+        b.synchronize()
+        host = {x: _np(traj[x][:n]) for x in ("flags", "reward", "nbr", "lanej", "obs_pre", "state_pre", "env_out")}
+        for k in range(n):
+            for e, o in enumerate(oracles):
+                _vid, ctlm, _ = o.alive_view()
+                na = o.n_alive
+                acts = np.where(ctlm != 0, pool_np[(t + k) % n_pool, e, :na], 0.0) if source == "pool" else np.zeros(na)
+                rec = o.tick(acts, want_state=True)
+                f = host["flags"][k, e, :na].astype(np.int64)
+                ctl = (f & 2) != 0
+                assert int(host["env_out"][k, e, 0]) == na and int(ctl.sum()) == len(rec["ids"]), "controlled set: tick %d env %d" % (t + k, e)
+                lj = host["lanej"][k, e, :na][ctl].astype(np.int64)
+                assert np.array_equal(np.stack([lj >> 16, lj & 0xFFFF], -1), rec["ids"]), "ids: tick %d env %d" % (t + k, e)
+                nb = host["nbr"][k, e, :na][ctl].astype(np.int64)
+                nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)
+                assert np.array_equal(nb, rec["nbr"]), "neighbours: tick %d env %d" % (t + k, e)
+                assert close(rec["reward"], host["reward"][k, e, :na][ctl], 1e-9), "reward: tick %d env %d" % (t + k, e)
+                assert close(rec["obs0"], host["obs_pre"][k, e, :na][ctl].astype(np.float64), tol), "row 0: tick %d env %d" % (t + k, e)
+                st = host["state_pre"][k, e, :na][ctl].astype(np.float64)
+                assert close(rec["state"], st, tol), "7 x 28 state: tick %d env %d" % (t + k, e)
+                assert close(rec["act7"], st[:, :, 2], tol), "7-action vector: tick %d env %d" % (t + k, e)
+                n_ctl_total += len(rec["ids"])
+        t += n
+    assert n_ctl_total > 5 * total
+    assert b.metrics()["overflow"] == 0
+    return n_ctl_total
 
 
 def check_step_many_pipelined(backend, n_envs=5, n_sub=2, capacity=128, ticks=40, seed=73):

@@ -298,6 +298,14 @@ def test_gpu_step_many_equals_single_ticks(source):
         scenarios.check_step_many(BACKEND, source, n_envs=5, capacity=64, rate=350.0, chunks=(5, 30, 90), trajectory_chunk=8)
 
 
+@pytest.mark.parametrize("dtype,chunk", [(torch.float64, 0), (torch.float64, 9), (torch.float32, 13)])
+def test_gpu_step_many_emits_full_state_rows_fresh_and_stale(dtype, chunk):
+    """test_gpu_full_state_rows_fresh_and_stale over pve_step_many trajectories (the resident kernel): 7 x 28 states and
+    7-action vectors of every tick against the oracle, across call and launch boundaries; float64 and float32 rows."""
+    n = scenarios.check_step_many_state_rows(BACKEND, n_envs=6, calls=(40, 25, 60, 35, 170), chunk=chunk, obs_dtype=dtype)
+    assert n > 20000
+
+
 def test_gpu_step_many_pipelined():
     scenarios.check_step_many_pipelined(BACKEND, n_envs=37, n_sub=3, ticks=120)
 

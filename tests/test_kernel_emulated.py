@@ -3,6 +3,7 @@
 and compared with the sequential oracle and the golden vectors. The `-m gpu` twin of this file
 (test_gpu_parity.py) runs the real kernels through libpveenv.so."""
 import pytest
+import torch
 
 from tests.hip_adapter import SplitEnv, make_batch
 from tests.parity_util import CASE_NAMES, GoldenCase, replay_case
@@ -75,3 +76,9 @@ def test_emulated_driver_launch_shape_vs_oracle():
     for traj in (False, True):
         m, _ = scenarios.check_driver_shape_vs_oracle(BACKEND, n_envs=7, n_sub=2, n_sample=7, calls=(30, 30, 5, 20), trajectory=traj)
         assert m["ctl_steps"] > 0
+
+
+def test_emulated_step_many_emits_training_states():
+    """state_pre / obs_pre / 7-action vectors over pve_step_many trajectories, every tick vs the oracle (f64 and f32 rows)."""
+    scenarios.check_step_many_state_rows(BACKEND, n_envs=2, calls=(30, 12, 25), chunk=0)
+    scenarios.check_step_many_state_rows(BACKEND, n_envs=2, calls=(20, 15), chunk=7, obs_dtype=torch.float32, seed=83)
