@@ -154,7 +154,7 @@ def binding_profile(mode, ticks_per_launch, cap, other):
     files.sort(key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)))
     j = json.load(open(files[-1]))
     t = j.get("%s%d" % (mode, ticks_per_launch)) or j.get(mode)
-    if not t or t.get("csrc_sha") != csrc_sha():
+    if not t or t.get("csrc_sha") != csrc_sha() or int(t.get("ticks_per_launch", 1)) != ticks_per_launch:
         return None, None
     return t, os.path.relpath(files[-1], ROOT)
 
@@ -290,7 +290,8 @@ def main(argv=None, env_factory=None):
                     help="float32 observation rows (PVE_CFG_OBS_F32; SURVEY 8d's FP32-output variant, 268 B algorithmic); "
                          "the headline / BASELINE metric is the float64 parity layout (380 B)")
     ap.add_argument("--actor", action="store_true",
-                    help="BASELINE config 5: close the loop on the device (actor -> tick per step) instead of the action pool")
+                    help="BASELINE config 5: close the loop on the device instead of the action pool -- rollout mode: the actor "
+                         "runs inside the resident kernel (pve_step_many(PVE_SRC_ACTOR)); step mode: actor launch + tick launch")
     args = ap.parse_args(argv)
     if args.actor and not args.obs_f64:
         args.obs_f32 = True
@@ -359,7 +360,7 @@ def main(argv=None, env_factory=None):
     # layout -- capacity 64: one wave per intersection, all 4096 resident at once (14.8 vs 20.6 us per tick); capacity 128:
     # launches of 25 ticks per sub-batch keep the chip full (30.0 vs 32.9 us); a short timed region (the driver's --steps
     # 20) takes launches of 5 ticks so that the two sub-batches still interleave (35.3 vs 36.6 us incl. fill and drain)
-    mode = args.mode or ("rollout" if (not emu and lane_num == 12 and not args.actor) else "step")
+    mode = args.mode or ("rollout" if (not emu and lane_num == 12) else "step")
     if mode == "rollout" and args.chunk == 0 and cap == 128:
         args.chunk = 25 if K >= 100 else 5
     if mode == "rollout" and not hasattr(env, "step_many"):
@@ -518,6 +519,8 @@ def main(argv=None, env_factory=None):
         kern_s = gpu_ms * 1e-3 / K                      # one tick of one sub-batch (n_envs / n_sub envs) on its stream
         per_launch = b_alg * cap * envs_per_launch / kern_s / 1e9
         kname = (("k_rollout<%d>" if mode == "rollout" else "k_tick<%d>") if lane_num == 12 else "k_tick_geo<%d>") % cap
+        if args.actor:
+            kname += " with the actor inside (ACT)" if mode == "rollout" else " + k_actor_h"
         other = args.actor or lane_num != 12 or args.obs_f32 or traj_on
         tr, traffic_src = (None, None) if (emu or not steady) else pmc_traffic(int(envs_per_launch), cap, outputs, mode, tpl, other)
         traffic = tr["hbm_bytes_per_launch"] if tr else None
@@ -597,6 +600,7 @@ def main(argv=None, env_factory=None):
         }
         if args.actor:
             line["roofline"]["note"] = "closed loop: actor + tick per step; achieved uses the tick's algorithmic bytes only"
+            line["metric"] += " (closed loop: MADDPG actor inference per controlled vehicle inside the step)"
         if peak_meas and achieved > peak_meas:
             line["roofline"]["note_above_copy_peak"] = ("algorithmic bytes exceed what a copy kernel moves in the same time: "
                                                         "empty slots are counted but not moved")

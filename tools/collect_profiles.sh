@@ -18,6 +18,9 @@ timeout 300 $B --capacity 64 2>/dev/null | tail -1 > $O/bench_cap64.json
 timeout 300 $NB --capacity 64 --mode step 2>/dev/null | tail -1 > $O/bench_cap64_step.json
 timeout 300 $NB --actor 2>/dev/null | tail -1 > $O/bench_actor.json
 timeout 300 $NB --actor --obs-f64 2>/dev/null | tail -1 > $O/bench_actor_f64.json
+timeout 300 $NB --actor --mode step 2>/dev/null | tail -1 > $O/bench_actor_step.json
+timeout 300 $NB --actor --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_actor_driver_like.json
+timeout 400 $NB --trajectory 1 2>/dev/null | tail -1 > $O/bench_trajectory.json
 timeout 300 $B --lane-num 8 --steps 300 --pipeline 3 2>/dev/null | tail -1 > $O/bench_lanes8.json
 timeout 300 $NB --lane-num 4 --capacity 64 --rate 1200 --steps 300 2>/dev/null | tail -1 > $O/bench_lanes4.json
 # ---- per-kernel durations (rocprofv3 --kernel-trace --stats), same commands
@@ -26,6 +29,7 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_step -o r -- $NB --mode
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_driver_like -o r -- $NB --steps 20 --warmup 5 > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_cap64 -o r -- $NB --capacity 64 > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_actor -o r -- $NB --actor --steps 300 > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_actor_step -o r -- $NB --actor --mode step --steps 300 > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats_lanes8 -o r -- $NB --lane-num 8 --steps 300 --pipeline 3 > /dev/null 2>&1
 # ---- HBM counters in their own passes (kernel-trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass)
 for m in rollout step; do
@@ -36,6 +40,12 @@ done
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch_rollout5 -o r -- $NB --mode rollout --chunk 5 --steps 100 > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write_rollout5 -o r -- $NB --mode rollout --chunk 5 --steps 100 > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/probe -o r -- python tools/traffic_probe.py > $O/probe.log 2>&1
+# ---- SQ counters (instruction mix, LDS conflicts, wait share): what binds the kernels (profiles/rNN_binding.json)
+bash tools/pmc_sq.sh rollout > /dev/null 2>&1
+PMC_BENCH_ARGS="--steps 20 --warmup 5" bash tools/pmc_sq.sh rollout5 > /dev/null 2>&1
+PMC_BENCH_ARGS="--mode step" bash tools/pmc_sq.sh step > /dev/null 2>&1
+PMC_BENCH_ARGS="--actor" bash tools/pmc_sq.sh actor > /dev/null 2>&1
+cp gpurun_out/pmc_sq_rollout.txt gpurun_out/pmc_sq_rollout5.txt gpurun_out/pmc_sq_step.txt gpurun_out/pmc_sq_actor.txt $O/ 2>/dev/null
 # ---- phase profiles
 python tools/phase_profile.py --ticks 100 > $O/phase_profile_step.txt 2>&1
 python tools/phase_profile.py --ticks 100 --many > $O/phase_profile_rollout.txt 2>&1

@@ -25,7 +25,8 @@ summary(os.path.join(src, "stats", "r_results.db"), prefix + "_kernel_stats.txt"
 summary(os.path.join(src, "stats_step", "r_results.db"), prefix + "_kernel_stats_step.txt", 1000)
 summary(os.path.join(src, "stats_driver_like", "r_results.db"), prefix + "_kernel_stats_driver_like.txt", 8)
 summary(os.path.join(src, "stats_cap64", "r_results.db"), prefix + "_kernel_stats_cap64.txt", 30)
-summary(os.path.join(src, "stats_actor", "r_results.db"), prefix + "_kernel_stats_actor.txt", 300)
+summary(os.path.join(src, "stats_actor", "r_results.db"), prefix + "_kernel_stats_actor.txt", 30)
+summary(os.path.join(src, "stats_actor_step", "r_results.db"), prefix + "_kernel_stats_actor_step.txt", 300)
 summary(os.path.join(src, "stats_lanes8", "r_results.db"), prefix + "_kernel_stats_lanes8.txt", 300)
 for m in ("rollout", "rollout5", "step"):
     summary(os.path.join(src, "fetch_" + m, "r_results.db"), prefix + "_pmc_fetch_%s.txt" % m, 30)
@@ -47,6 +48,58 @@ def last_avg(db, counter, kernel, n):
 
 
 import bench  # noqa: E402  (csrc fingerprint: a traffic figure only applies to the build it was measured on)
+
+
+def parse_sq(path):
+    """{kernel prefix: {counter: mean per launch}} from a tools/pmc_sq.sh summary"""
+    out, cur = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = out.setdefault(line.strip(), {})
+        elif cur is not None and "mean/launch" in line:
+            f = line.split()
+            cur[f[0]] = float(f[2])
+    return out
+
+
+def shader_clock(path, default=2.4):
+    try:
+        for line in open(path):
+            if line.startswith("shader clock during the launch"):
+                return float(line.split(":")[1].split("MHz")[0]) / 1000.0
+    except OSError:
+        pass
+    return default
+
+
+# ---- what binds the kernels: SQ instruction counts per wave and tick, LDS conflicts, wait share (bench.py: roofline.binding)
+try:
+    binding = {}
+    clk = shader_clock(os.path.join(src, "phase_profile_rollout.txt"))
+    for tag, kkey, mode, tpl, envs in (("rollout", "void k_rollout<128, 4, false, false", "rollout", 25, 2048),
+                                       ("rollout5", "void k_rollout<128, 4, false, false", "rollout5", 5, 2048),
+                                       ("step", "void k_tick<128>", "step", 1, 2048),
+                                       ("actor", "void k_rollout<128, 4, false, true", "actor_rollout", 25, 2048)):
+        f = os.path.join(src, "pmc_sq_%s.txt" % tag)
+        if not os.path.isfile(f):
+            continue
+        shutil.copyfile(f, os.path.join(prof, prefix + "_pmc_sq_%s.txt" % tag))
+        sq = parse_sq(f)
+        k = next((v for n, v in sq.items() if n.startswith(kkey)), None)
+        if not k:
+            continue
+        wt = envs * 2 * tpl                                   # waves x ticks of one launch (capacity 128: 2 waves per env)
+        binding[mode] = dict(kernel=kkey.replace("void ", "") + "...>", csrc_sha=bench.csrc_sha(), envs_per_launch=envs, ticks_per_launch=tpl,
+                             valu_per_wave_tick=k["SQ_INSTS_VALU"] / wt, salu_per_wave_tick=k["SQ_INSTS_SALU"] / wt,
+                             lds_per_wave_tick=k["SQ_INSTS_LDS"] / wt, vmem_per_wave_tick=k["SQ_INSTS_VMEM"] / wt,
+                             lds_bank_conflict_frac=k["SQ_LDS_BANK_CONFLICT"] / k["SQ_ACTIVE_INST_LDS"],
+                             wait_frac=k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"],
+                             valu_lane_utilisation=k["SQ_THREAD_CYCLES_VALU"] / (k["SQ_ACTIVE_INST_VALU"] * 64.0) if k.get("SQ_ACTIVE_INST_VALU") else None,
+                             shader_clock_ghz=clk, source=prefix + "_pmc_sq_%s.txt" % tag)
+    json.dump(binding, open(os.path.join(prof, prefix + "_binding.json"), "w"), indent=1)
+    print(json.dumps(binding, indent=1))
+except Exception as e:  # noqa
+    print("binding json not written:", e)
 try:
     probe = last_avg(os.path.join(src, "probe", "r_results.db"), "FETCH_SIZE", "k_probe", 10)
     known_kib = 4096 * 128 * 72 / 1024.0

@@ -30,9 +30,10 @@ def main():
     ap.add_argument("--lane-num", type=int, default=12, choices=(12, 8, 4), help="4 / 8: k_tick_geo (column 4 = FILL)")
     ap.add_argument("--geo-scan", action="store_true", help="k_tick_geo with the membership scan (PVE_CFG_GEO_SCAN)")
     ap.add_argument("--many", action="store_true", help="profile k_rollout (pve_step_many: all ticks in one launch)")
+    ap.add_argument("--rate", type=float, default=None, help="veh/h/lane (default: the bench rate of the layout)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    rate = {12: 1100.0 if a.capacity == 128 else 350.0, 8: 1500.0, 4: 1800.0}[a.lane_num]
+    rate = a.rate or {12: 1100.0 if a.capacity == 128 else 350.0, 8: 1500.0, 4: 1800.0}[a.lane_num]
     arr = synthetic_arrivals(a.envs, rate=rate, horizon_s=(a.ticks + a.warmup) * 0.1 + 20, lane_num=a.lane_num)
     from pve_mcc_amd.arrivals import synthetic_intentions
     ch = synthetic_intentions(a.envs, arr.shape[1], seed=1) if a.lane_num == 8 else None
