@@ -360,7 +360,7 @@ def main(argv=None, env_factory=None):
     # layout -- capacity 64: one wave per intersection, all 4096 resident at once (14.8 vs 20.6 us per tick); capacity 128:
     # launches of 25 ticks per sub-batch keep the chip full (30.0 vs 32.9 us); a short timed region (the driver's --steps
     # 20) takes launches of 5 ticks so that the two sub-batches still interleave (35.3 vs 36.6 us incl. fill and drain)
-    mode = args.mode or ("rollout" if (not emu and lane_num == 12) else "step")
+    mode = args.mode or ("rollout" if not emu else "step")
     if mode == "rollout" and args.chunk == 0 and cap == 128:
         args.chunk = 25 if K >= 100 else 5
     if mode == "rollout" and not hasattr(env, "step_many"):
@@ -518,7 +518,8 @@ def main(argv=None, env_factory=None):
         nominal = b_nom * cap * n_envs / (wall / K) / 1e9
         kern_s = gpu_ms * 1e-3 / K                      # one tick of one sub-batch (n_envs / n_sub envs) on its stream
         per_launch = b_alg * cap * envs_per_launch / kern_s / 1e9
-        kname = (("k_rollout<%d>" if mode == "rollout" else "k_tick<%d>") if lane_num == 12 else "k_tick_geo<%d>") % cap
+        kname = (("k_rollout<%d>" if mode == "rollout" else "k_tick<%d>") if lane_num == 12 else
+                 ("k_rollout_geo<%d>" if mode == "rollout" else "k_tick_geo<%d>")) % cap
         if args.actor:
             kname += " with the actor inside (ACT)" if mode == "rollout" else " + k_actor_h"
         other = args.actor or lane_num != 12 or args.obs_f32 or traj_on

@@ -371,6 +371,95 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
 }
 
+// pve_step_many for the 4- / 8-lane layouts: the phases of k_tick_geo in a loop, the state resident on the chip between the
+// ticks (TickGeo::ph_final<true> / ph_stage / ph_reload: the staging arrays overlay the list storage, which is dead by
+// FIN); the lookup tables are copied to LDS once per launch instead of once per tick, only the per-tick outputs and the
+// prefetched actions / arrival times touch HBM.  What it buys beyond the bytes: a launch of k_tick_geo lasts as long as its
+// slowest intersection (43 us against a mean of 30 for 4 lanes x 64 slots); here a slow tick of one intersection is
+// averaged over the ticks of the launch.
+template <int CAP, bool FIX4 = false>
+__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rollout_geo(const GeoConst g_arg, const Params P_arg,
+                                                                                                const RolloutArgs R_arg)
+{
+    KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t OFF_P = (sizeof(GeoConst) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
+    __shared__ SharedGeo<CAP> sh;
+    int t0_ = threadIdx.x;
+    int env0_ = blockIdx.x;
+    KernargPtr kav_ = ka0_;
+    Regs r;
+    FinCarry fc;
+    typedef TickGeo<CAP> T;
+    typedef Tick<CAP, SharedGeo<CAP>> B;
+    int pool_idx, n_ticks;
+    {
+        const PVE_AS4 GeoConst &g = *(const PVE_AS4 GeoConst *)ka0_;
+        const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
+        const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
+        pool_idx = R.pool_tick0;
+        n_ticks = R.n_ticks;
+        T::ph_load(g, P, env0_, t0_, sh, r);            // P.actions = the first tick's actions
+        lds_barrier();
+        T::ph_load_late(P, env0_, t0_, sh, r);
+    }
+    for (int k = 0; k < n_ticks; k++) {
+        // (the same opaque re-definitions as in k_rollout: nothing derived from the arguments is hoisted out of the loop)
+        asm volatile("" : "+s"(kav_), "+v"(t0_), "+s"(env0_));
+        const KernargPtr ka = kav_;
+        const int t = t0_, env = env0_;
+        const PVE_AS4 GeoConst &g = *(const PVE_AS4 GeoConst *)ka;
+        const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka + OFF_P);
+        const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka + OFF_R);
+        lds_barrier();
+        if (k > 0) T::ph_tick_init(g, t, sh, r);
+        // (ph_tick_init's list counters are read behind the next barrier; S1 counts the routes with atomics on rc: the
+        //  zeroing must precede them)
+        if (k > 0) lds_barrier();
+        T::ph_step1(g, P, env, t, sh, r);
+        lds_barrier();
+        B::ph_step2(g.base, t, sh, r);
+        T::ph_order(t, sh, r);
+        lds_barrier();
+        B::ph_step3(g.base, t, sh, r);
+        B::ph_step3_publish(t, sh, r);
+        T::ph_order2(t, sh);
+        lds_barrier();
+        T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
+        lds_barrier();
+        T::ph_pairs_exact(t, sh, P.geo_scan != 0);
+        lds_barrier();
+        T::ph_pairs_apply(t, sh);
+        lds_barrier();
+        T::ph_pairs_fill(g, t, sh);
+        lds_barrier();
+        T::ph_rank(t, sh);
+        lds_barrier();
+        T::template ph_scan<FIX4>(g, t, sh, r);
+        T::ph_reward(g, t, sh, r);
+        lds_barrier();
+        int nx = -1;
+        if (k + 1 < n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
+        B::ph_prefetch_action(P, R, env, t, nx, r);
+        T::ph_effects(g, t, sh, r);
+        lds_barrier();
+        B::ph_prefetch_arrival(P, env, t, sh, r, g.lane_num);
+        B::ph_lock_slot(g.base, t, sh, r);
+        lds_barrier();
+        B::ph_lock2_slot(t, sh, r);
+        lds_barrier();
+        const Outputs O = B::template tick_outputs<false>(P, R, k);
+        T::template ph_final<true>(g, P, O, env, t, sh, r, fc);
+        lds_barrier();                                // A: nobody reads the tick's work arrays any more
+        T::ph_stage(g, t, sh, r, fc);
+        lds_barrier();                                // B: the staging area is complete
+        if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
+    }
+    {
+        const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
+        B::ph_flush(P, env0_, t0_, sh);
+    }
+}
+
 template <int CAP>
 __global__ __launch_bounds__(64) void k_reset_geo(const GeoConst g_arg, const Params P_arg, int cap_ticks)
 {
@@ -507,6 +596,24 @@ struct Backend {
         } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
         else if (w5) hipLaunchKernelGGL((k_rollout<128, 5>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         else hipLaunchKernelGGL((k_rollout<128, 4>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
+        return check_launch(err);
+    }
+    static int launch_rollout_geo(const GeoConst &g, const Params &P_in, const RolloutArgs &R, int cap, void *stream, std::string &err)
+    {
+        static const bool off = getenv("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
+        if (off || R.source == 2 /* the actor reads 12-lane rows */ || P_in.phase_cycles || P_in.out.obs_pre || P_in.out.state_pre) return 1;
+        hipStream_t s = (hipStream_t)stream;
+        Params P = P_in;
+        RolloutArgs Rk = R;
+        if (R.source == 1) {
+            Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
+            P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
+        } else P.actions = nullptr;
+        if (g.lane_num == 4) {
+            if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, true>), dim3(P.n_envs), dim3(64), 0, s, g, P, Rk);
+            else hipLaunchKernelGGL((k_rollout_geo<128, true>), dim3(P.n_envs), dim3(128), 0, s, g, P, Rk);
+        } else if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, false>), dim3(P.n_envs), dim3(64), 0, s, g, P, Rk);
+        else hipLaunchKernelGGL((k_rollout_geo<128, false>), dim3(P.n_envs), dim3(128), 0, s, g, P, Rk);
         return check_launch(err);
     }
     static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)

@@ -297,6 +297,7 @@ struct FinCarry {
     int new_slot;                    // of the vehicle in slot t (< 0: deleted or empty)
     int ls;                          // t <= NL: lane_start[t] after re-pack + spawn
     int sp_slot, sp_id, sp_vnum;     // t < NL: slot / id / id_info[1] of the vehicle lane t spawns (sp_slot < 0: none)
+    int sp_int;                      // general-geometry kernel: its intention (ref :382-394)
     int n_post, n_sp, n_over, n_fin, n_ctl, n_lock, n_coll, n_pre;
     double sr, sj;
 };

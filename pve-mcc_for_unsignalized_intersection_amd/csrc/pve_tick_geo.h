@@ -47,9 +47,23 @@ template <int CAP> struct SharedGeo {
         double u_vd[PE];                    // entry pool; LOCK2 re-uses [0, CAP) as the dead-lock scratch (records by rank)
     };
     double s_vd[1];
-    uint16_t s_idx[PE];
-    uint8_t u_slot[PE], u_list[PE];
-    uint8_t s_slot[PE];                     // slot of the entry at every sorted position (read by the 4-lane left-turn egos)
+    alignas(8) uint16_t s_idx[PE];
+    alignas(8) uint8_t u_slot[PE], u_list[PE];
+    alignas(8) uint8_t s_slot[PE];          // slot of the entry at every sorted position (read by the 4-lane left-turn egos)
+    // k_rollout_geo keeps the state on the chip between two ticks (cf. Shared<CAP>): every persistent field of every vehicle
+    // moves to its new slot through storage that is dead by FIN -- the entry pool beyond the dead-lock records, virdis, the
+    // sorted-list arrays, cnt, ord / slot_at (EARLY, at the top of FIN); p into u_vd[0 .. CAP), v and a in place (LATE,
+    // behind barrier A)
+    enum { SF_JERK = 0, SF_JERK_SUM, SF_VIR_DIS, SF_CLOSER_P, SF_P, SF_V, SF_A };
+    template <int K> PVE_HD double *stf()
+    {
+        return K < 3 ? u_vd + (K + 1) * CAP : (K == SF_CLOSER_P ? virdis : (K == SF_P ? u_vd : (K == SF_V ? v : a)));
+    }
+    template <int K> PVE_HD int *sti()   // K = I_ID .. I_HDR
+    {
+        return K < 2 ? (int *)s_idx + K * CAP
+                     : (K == 2 ? (int *)u_slot : (K == 3 ? (int *)u_list : (K == 4 ? (int *)s_slot : (K == 5 ? cnt : (int *)ord))));
+    }
     int16_t mypos[CAP];                     // sorted position of every controlled vehicle's own entry in its route's list
     int rc[ND], rfill[ND], fill[ND], cnt2[ND], pool_ok;   // controlled vehicles per route, claimed so far; entries filed per list;
                                             // exact member counts (only when the upper bounds overflow the pool)
@@ -60,7 +74,7 @@ template <int CAP> struct SharedGeo {
     alignas(8) GeoTab tab;           // copy of GeoConst::tab
     int cnt[CAP];
     int acc_passed_steps, acc_collisions, lead_n, emu_scan, emu_scan2, emu_scan3;
-    int16_t hdr[CAP], cyc_off[CAP], ord[CAP], slot_at[CAP];
+    alignas(8) int16_t hdr[CAP], cyc_off[CAP], ord[CAP], slot_at[CAP];
     uint8_t bb[CAP], rew_ovr[CAP], lane_of[CAP], route_of[CAP], intent_of[CAP], lk_slot[CAP];
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW], m_spawn[NW];
     u64 m_int[3][NW];                // alive slots by intention
@@ -680,14 +694,19 @@ template <int CAP> struct TickGeo {
     // ============================================================== FIN: re-pack + spawn + write-back
     static PVE_HD int pack_lanej(const Sh &sh, int slot) { return Base::pack_lanej(sh, slot); }
 
-    static PVE_HD void ph_final(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    // RES = false: the tick kernel -- state and header go back to HBM (`O` = P.out).  RES = true: k_rollout_geo -- outputs
+    // only; the persistent fields and the header updates are handed to ph_stage through `fc` and stay on the chip.
+    template <bool RES, class OutT>
+    static PVE_HD void ph_final(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh,
+                                Regs &r, FinCarry &fc)
     {
         const PVE_AS4 Const &c = g.base;
         EnvHeader &gh = P.headers[env];
         const int N = sh.hd.n_alive;
         const int LN = g.lane_num;
         const size_t gpre = (size_t)env * CAP + t;
-        const bool fused = (P.mode == MODE_FUSED);
+        const bool fused = RES || (P.mode == MODE_FUSED);
+        fc.still = 0; fc.meta = 0;
         const unsigned want = (unsigned)(sh.m_spawn[0] & 0xFFFull);
         unsigned sp = 0; int room = CAP - N;
 #pragma unroll
@@ -717,11 +736,24 @@ template <int CAP> struct TickGeo {
             hdr_word = pack_lanej(sh, r.hdr);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
-                Base::store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
+                if (!RES) Base::store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
+                else {                     // EARLY staging (these registers die here)
+                    const int s = new_slot;
+                    sh.template stf<Sh::SF_JERK>()[s] = r.jerk; sh.template stf<Sh::SF_JERK_SUM>()[s] = r.jerk_sum;
+                    sh.template stf<Sh::SF_VIR_DIS>()[s] = r.vir_dis; sh.template stf<Sh::SF_CLOSER_P>()[s] = r.closer_p;
+                    sh.template sti<I_ID>()[s] = r.id; sh.template sti<I_SEQ>()[s] = r.seq; sh.template sti<I_VNUM>()[s] = r.vnum;
+                    sh.template sti<I_STEP>()[s] = r.step; sh.template sti<I_COUNT>()[s] = r.count;
+                    sh.template sti<I_META>()[s] = meta; sh.template sti<I_HDR>()[s] = hdr_word;
+                }
             }
         }
         const int n_post = mask_below<NW>(keep, sh.hd.lane_start[NL]) + __builtin_popcount(sp);
-        if (t <= NL) gh.lane_start[t] = mask_below<NW>(keep, sh.hd.lane_start[t]) + __builtin_popcount(sp & ((1u << t) - 1u));
+        fc.new_slot = new_slot;
+        fc.ls = 0; fc.sp_slot = -1; fc.sp_id = 0; fc.sp_vnum = 0; fc.sp_int = 0;
+        if (t <= NL) {
+            const int ls = mask_below<NW>(keep, sh.hd.lane_start[t]) + __builtin_popcount(sp & ((1u << t) - 1u));
+            if (RES) fc.ls = ls; else gh.lane_start[t] = ls;
+        }
         // ---- spawned vehicles (one per lane at most), ref :378-433
         if (t < LN && ((sp >> t) & 1)) {
             const int nth = __builtin_popcount(sp & ((1u << t) - 1u));               // spawns of lower lanes come first
@@ -732,29 +764,38 @@ template <int CAP> struct TickGeo {
                 const int ch = P.choice ? P.choice[(size_t)env * P.choice_env_stride + (size_t)sh.hd.veh_rec[t] * LN + t] : 0;
                 intention = (t & 1) ? (ch ? 2 : 1) : (ch ? 1 : 0);                     // ref :125-134
             } else intention = t % 3;                                                  // ref :393-394
-            Regs nv;
-            nv.p = sel3(c.spawn_p, intention); nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
-            nv.vir_dis = 100; nv.closer_p = 150;
-            nv.id = sh.hd.id_seq + nth;
-            nv.seq = sh.hd.veh_rec[t];
-            nv.vnum = sh.hd.lane_start[t + 1] - sh.hd.lane_start[t];
-            nv.step = 0; nv.count = 0;
-            Base::store_slot(P, (size_t)env * CAP + slot, nv,
-                             M_CONTROL | M_ALIVE | (LN == 12 ? 0 : (intention << M_INT_SHIFT)), -1);   // 12-lane: lane % 3, not stored
-            if (P.out.obs_post) {                                                      // ref :380, :420
-                if (P.obs_f32) { float *o = (float *)P.out.obs_post + ((size_t)env * CAP + slot) * OBSW; for (int k = 0; k < OBSW; k++) o[k] = 0.0f; }
-                else { double *o = P.out.obs_post + ((size_t)env * CAP + slot) * OBSW; for (int k = 0; k < OBSW; k++) o[k] = 0.0; }
+            if (RES) {
+                fc.sp_slot = slot; fc.sp_id = sh.hd.id_seq + nth; fc.sp_vnum = sh.hd.lane_start[t + 1] - sh.hd.lane_start[t];
+                fc.sp_int = intention;
+            } else {
+                Regs nv;
+                nv.p = sel3(c.spawn_p, intention); nv.v = c.v0; nv.a = 0; nv.jerk = 0; nv.jerk_sum = 0;
+                nv.vir_dis = 100; nv.closer_p = 150;
+                nv.id = sh.hd.id_seq + nth;
+                nv.seq = sh.hd.veh_rec[t];
+                nv.vnum = sh.hd.lane_start[t + 1] - sh.hd.lane_start[t];
+                nv.step = 0; nv.count = 0;
+                Base::store_slot(P, (size_t)env * CAP + slot, nv,
+                                 M_CONTROL | M_ALIVE | (LN == 12 ? 0 : (intention << M_INT_SHIFT)), -1);   // 12-lane: lane % 3, not stored
             }
-            const int rec1 = sh.hd.veh_rec[t] + 1;
-            gh.veh_rec[t] = rec1;
-            gh.next_arr[t] = r.next_arr;
+            if (O.obs_post) {                                                          // ref :380, :420
+                if (P.obs_f32) { float *o = (float *)O.obs_post + ((size_t)env * CAP + slot) * OBSW; for (int k = 0; k < OBSW; k++) o[k] = 0.0f; }
+                else { double *o = O.obs_post + ((size_t)env * CAP + slot) * OBSW; for (int k = 0; k < OBSW; k++) o[k] = 0.0; }
+            }
+            if (!RES) {
+                const int rec1 = sh.hd.veh_rec[t] + 1;
+                gh.veh_rec[t] = rec1;
+                gh.next_arr[t] = r.next_arr;
+            }
         }
-        if (t >= n_post && t < N) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
-        if (t < ND) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
+        if (!RES && t >= n_post && t < N) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
+        if (!RES && t < ND) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
         const int n_ctl = mask_count<NW>(sh.m_ctl);
         const int n_lock = mask_count<NW>(sh.m_lead);
         const int n_fin = mask_count<NW>(sh.m_fin);
         const int n_del = mask_count<NW>(sh.m_del);
+        fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp); fc.n_over = n_over; fc.n_fin = n_fin; fc.n_ctl = n_ctl;
+        fc.n_lock = n_lock; fc.n_coll = mask_count<NW>(sh.m_coll); fc.n_pre = N; fc.sr = 0; fc.sj = 0;
         if (t == 0) {
             double sr = 0, sj = 0;
 #if PVE_DEVICE_CODE
@@ -762,6 +803,8 @@ template <int CAP> struct TickGeo {
 #else
             sr = sh.red_reward[0]; sj = sh.red_jerk[0];
 #endif
+            fc.sr = sr; fc.sj = sj;
+          if (!RES) {
             gh.current_time = sh.hd.current_time;
             gh.n_alive = n_post;
             gh.id_seq = sh.hd.id_seq + __builtin_popcount(sp);
@@ -777,29 +820,30 @@ template <int CAP> struct TickGeo {
             gh.collided = sh.hd.collided + mask_count<NW>(sh.m_coll);
             gh.locks = sh.hd.locks + n_lock;
             gh.overflow = sh.hd.overflow + n_over;
-            if (P.out.env_out) {
-                int *eo = P.out.env_out + (size_t)env * 8;
+          }
+            if (O.env_out) {
+                int *eo = O.env_out + (size_t)env * 8;
                 eo[0] = N; eo[1] = n_ctl; eo[2] = sh.acc_collisions;
                 eo[3] = n_lock; eo[4] = n_del; eo[5] = n_fin; eo[6] = __builtin_popcount(sp); eo[7] = n_post;
             }
         }
-        if (P.out.flags) {
+        if (O.flags) {
             int f = 0;
             if (r.alive) {
                 f = 0x01 | (r.ctl ? 0x02 : 0) | ((r.meta & M_DONE) ? 0x04 : 0) | (r.del ? 0x08 : 0) |
                     (r.fin ? 0x10 : 0) | (lockf ? 0x20 : 0) | (r.intent << 6) | (r.ctl ? (r.coll_seen << 8) : 0);
             }
-            P.out.flags[gpre] = f;
+            O.flags[gpre] = f;
         }
-        if (P.out.reward && r.alive) P.out.reward[gpre] = r.ctl ? r.reward : 0.0;
-        if (P.out.lanej && r.alive) P.out.lanej[gpre] = (r.lane << 16) | r.j;
-        if (P.out.new_slot && r.alive) P.out.new_slot[gpre] = new_slot;
-        if (P.out.nbr && r.alive && r.ctl) {           // controlled vehicles only (PVE_F_CTL in flags)
-            int *nb = P.out.nbr + gpre * NNB;
+        if (O.reward && r.alive) O.reward[gpre] = r.ctl ? r.reward : 0.0;
+        if (O.lanej && r.alive) O.lanej[gpre] = (r.lane << 16) | r.j;
+        if (O.new_slot && r.alive) O.new_slot[gpre] = new_slot;
+        if (O.nbr && r.alive && r.ctl) {           // controlled vehicles only (PVE_F_CTL in flags)
+            int *nb = O.nbr + gpre * NNB;
 #pragma unroll
             for (int k = 0; k < NNB; k++) nb[k] = pack_lanej(sh, r.kr[k]);
         }
-        if (r.alive && r.ctl && (P.out.obs_pre || (P.out.obs_post && new_slot >= 0))) {
+        if (r.alive && r.ctl && (O.obs_pre || (O.obs_post && new_slot >= 0))) {
             double row[OBSW];                                                          // ref :1325-1337
             row[0] = r.p; row[1] = r.v; row[2] = r.a; row[3] = (double)r.route;
 #pragma unroll
@@ -812,23 +856,82 @@ template <int CAP> struct TickGeo {
                     row[4 + 4 * k] = 0; row[5 + 4 * k] = 0; row[6 + 4 * k] = 0; row[7 + 4 * k] = 0;
                 }
             }
-            if (P.out.obs_pre) {
-                double *o = P.out.obs_pre + gpre * OBSW;
+            if (O.obs_pre) {
+                double *o = O.obs_pre + gpre * OBSW;
 #pragma unroll
                 for (int k = 0; k < OBSW; k++) o[k] = row[k];
             }
-            if (P.out.obs_post && new_slot >= 0) {
+            if (O.obs_post && new_slot >= 0) {
                 if (P.obs_f32) {
-                    float *o = (float *)P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+                    float *o = (float *)O.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
 #pragma unroll
                     for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
                 } else {
-                    double *o = P.out.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+                    double *o = O.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
 #pragma unroll
                     for (int k = 0; k < OBSW; k++) o[k] = row[k];
                 }
             }
         }
+    }
+
+    static PVE_HD void ph_final(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    {
+        FinCarry fc;
+        ph_final<false>(g, P, P.out, env, t, sh, r, fc);
+    }
+
+    // ============================================================== k_rollout_geo: many ticks per launch (cf. Tick::ph_stage ..)
+    // next tick's action of slot t stays in a register (the slot's own thread consumes it after RELOAD)
+    static PVE_HD void ph_stage(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r, const FinCarry &fc)
+    {
+        const PVE_AS4 Const &c = g.base;
+        if (fc.new_slot >= 0) {                          // LATE staging (the rest went at the top of FIN)
+            const int s = fc.new_slot;
+            sh.template stf<Sh::SF_P>()[s] = r.p; sh.template stf<Sh::SF_V>()[s] = r.v; sh.template stf<Sh::SF_A>()[s] = r.a;
+        }
+        if (fc.sp_slot >= 0) {                           // t < lane_num: the vehicle lane t spawns (ref :395-433)
+            const int s = fc.sp_slot;
+            sh.template stf<Sh::SF_P>()[s] = sel3(c.spawn_p, fc.sp_int); sh.template stf<Sh::SF_V>()[s] = c.v0;
+            sh.template stf<Sh::SF_A>()[s] = 0; sh.template stf<Sh::SF_JERK>()[s] = 0; sh.template stf<Sh::SF_JERK_SUM>()[s] = 0;
+            sh.template stf<Sh::SF_VIR_DIS>()[s] = 100; sh.template stf<Sh::SF_CLOSER_P>()[s] = 150;
+            sh.template sti<I_ID>()[s] = fc.sp_id; sh.template sti<I_SEQ>()[s] = sh.hd.veh_rec[t];
+            sh.template sti<I_VNUM>()[s] = fc.sp_vnum; sh.template sti<I_STEP>()[s] = 0; sh.template sti<I_COUNT>()[s] = 0;
+            sh.template sti<I_META>()[s] = M_CONTROL | M_ALIVE | (g.lane_num == 12 ? 0 : (fc.sp_int << M_INT_SHIFT));
+            sh.template sti<I_HDR>()[s] = -1;
+            sh.hd.veh_rec[t] += 1;
+            sh.hd.next_arr[t] = r.next_arr;
+        }
+        if (t <= NL) sh.hd.lane_start[t] = fc.ls;
+        if (t == 0 && g.lane_num != 12) sh.hd.intention_re += fc.n_sp;               // ref :388, :392
+        Base::ph_stage_header(t, sh, fc);
+    }
+    // RELOAD (after barrier B): slot t's vehicle from the staging arrays, its action from the prefetch register
+    static PVE_HD void ph_reload(int t, Sh &sh, Regs &r)
+    {
+        const int N = sh.hd.n_alive;
+        r.alive = t < N;
+        r.jerk = 0;
+        r.p = r.v = r.a = r.jerk_sum = r.vir_dis = r.closer_p = 0;
+        r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
+        if (t < N) {
+            r.p = sh.template stf<Sh::SF_P>()[t]; r.v = sh.template stf<Sh::SF_V>()[t]; r.a = sh.template stf<Sh::SF_A>()[t];
+            r.jerk_sum = sh.template stf<Sh::SF_JERK_SUM>()[t]; r.vir_dis = sh.template stf<Sh::SF_VIR_DIS>()[t];
+            r.closer_p = sh.template stf<Sh::SF_CLOSER_P>()[t];
+            r.id = sh.template sti<I_ID>()[t]; r.seq = sh.template sti<I_SEQ>()[t]; r.vnum = sh.template sti<I_VNUM>()[t];
+            r.step = sh.template sti<I_STEP>()[t]; r.count = sh.template sti<I_COUNT>()[t]; r.meta = sh.template sti<I_META>()[t];
+        }
+        r.act = r.act_nx;
+    }
+    // work-array initialisation of a resident tick (what LOAD does besides loading), after the barrier behind RELOAD
+    static PVE_HD void ph_tick_init(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
+    {
+        sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
+        if (t == 0) {
+            sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0;
+            sh.hd.current_time = sh.hd.current_time + g.base.deltaT;                  // ref :223 (repeated +=)
+        }
+        if (t < ND) { sh.rc[t] = 0; sh.rfill[t] = 0; sh.fill[t] = 0; sh.cnt2[t] = 0; }
     }
 
     // ============================================================== STATE: 7x28; a neighbour's row is this tick's

@@ -134,6 +134,59 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
     delete shp;
 }
 
+// k_rollout_geo: the resident multi-tick form of the general-geometry tick, phase by phase as the kernel orders them
+template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &P, const RolloutArgs &R)
+{
+    typedef TickGeo<CAP> T;
+    typedef Tick<CAP, SharedGeo<CAP>> B;
+    std::vector<Regs> regs(CAP);
+    std::vector<FinCarry> fcs(CAP);
+    SharedGeo<CAP> *shp = new SharedGeo<CAP>();
+    const bool fix4 = g.lane_num == 4;
+    for (int env = 0; env < P.n_envs; env++) {
+        SharedGeo<CAP> &sh = *shp;
+        memset(&sh, 0, sizeof(sh));
+        int pool_idx = R.pool_tick0;
+        for (int t = 0; t < CAP; t++) T::ph_load(g, P, env, t, sh, regs[t]);
+        for (int t = 0; t < CAP; t++) T::ph_load_late(P, env, t, sh, regs[t]);
+        for (int k = 0; k < R.n_ticks; k++) {
+            for (int w = 0; w < CAP / 64; w++) {     // the emulator's vote() ORs bits: start every tick from empty masks
+                sh.m_alive[w] = sh.m_ctl[w] = sh.m_del[w] = sh.m_fin[w] = sh.m_ctlnow[w] = sh.m_coll[w] = sh.m_lead[w] = sh.m_spawn[w] = 0;
+                sh.m_keep[w] = sh.m_ctl_ord[w] = sh.m_int[0][w] = sh.m_int[1][w] = sh.m_int[2][w] = 0;
+            }
+            sh.red_reward[0] = 0; sh.red_jerk[0] = 0;
+            if (k > 0) for (int t = 0; t < CAP; t++) T::ph_tick_init(g, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_step1(g, P, env, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) B::ph_step2(g.base, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_order(t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) B::ph_step3(g.base, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) B::ph_step3_publish(t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_order2(t, sh);
+            for (int t = 0; t < CAP; t++) T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
+            for (int t = 0; t < CAP; t++) T::ph_pairs_exact(t, sh, P.geo_scan != 0);
+            for (int t = 0; t < CAP; t++) T::ph_pairs_apply(t, sh);
+            for (int t = 0; t < CAP; t++) T::ph_pairs_fill(g, t, sh);
+            for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
+            if (fix4) for (int t = 0; t < CAP; t++) T::template ph_scan<true>(g, t, sh, regs[t]);
+            else for (int t = 0; t < CAP; t++) T::template ph_scan<false>(g, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_reward(g, t, sh, regs[t]);
+            int nx = -1;
+            if (k + 1 < R.n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
+            for (int t = 0; t < CAP; t++) B::ph_prefetch_action(P, R, env, t, nx, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_effects(g, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) B::ph_prefetch_arrival(P, env, t, sh, regs[t], g.lane_num);
+            for (int t = 0; t < CAP; t++) B::ph_lock_slot(g.base, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) B::ph_lock2_slot(t, sh, regs[t]);
+            const Outputs O = B::template tick_outputs<false>(P, R, k);
+            for (int t = 0; t < CAP; t++) T::template ph_final<true>(g, P, O, env, t, sh, regs[t], fcs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_stage(g, t, sh, regs[t], fcs[t]);
+            if (k + 1 < R.n_ticks) for (int t = 0; t < CAP; t++) T::ph_reload(t, sh, regs[t]);
+        }
+        for (int t = 0; t < CAP; t++) B::ph_flush(P, env, t, sh);
+    }
+    delete shp;
+}
+
 template <int CAP> static void emu_compact(const Params &P)
 {
     std::vector<CRegs> regs(CAP);
@@ -170,6 +223,18 @@ struct Backend {
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
         if (cap == 64) emu_rollout<64>(c, P, Rk); else emu_rollout<128>(c, P, Rk);
+        return 0;
+    }
+    static int launch_rollout_geo(const GeoConst &g, const Params &P_in, const RolloutArgs &R, int cap, void *, std::string &)
+    {
+        if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2 || P_in.out.obs_pre || P_in.out.state_pre) return 1;
+        Params P = P_in;
+        RolloutArgs Rk = R;
+        if (R.source == 1) {
+            Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
+            P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
+        } else P.actions = nullptr;
+        if (cap == 64) emu_rollout_geo<64>(g, P, Rk); else emu_rollout_geo<128>(g, P, Rk);
         return 0;
     }
     static int launch_compact(const Params &P, int cap, void *, std::string &)

@@ -556,6 +556,71 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
             pass
 
 
+def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chunks=(1, 7, 40, 3, 60), rate=None,
+                        trajectory_chunk=12, quantize=None):
+    """pve_step_many for the 4- / 8-lane layouts (k_rollout_geo: the general-geometry tick resident on the chip) == single
+    pve_step_all ticks of k_tick_geo, bit for bit: persistent state, headers (incl. the spawn counter intention_re and
+    the stale list heads), observation rows, last-tick outputs and, in trajectory mode, every tick's outputs."""
+    from pve_mcc_amd.arrivals import synthetic_intentions
+    n_pool = 5
+    rng = np.random.default_rng(seed)
+    rate = rate or {12: 1100.0, 8: 1500.0, 4: (1800.0 if capacity == 128 else 1200.0)}[lane_num]
+    total = sum(chunks) + trajectory_chunk
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed, lane_num=lane_num)
+    ch = synthetic_intentions(n_envs, arr.shape[1], seed=seed, lane_num=lane_num) if lane_num == 8 else None
+    outs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out", "lanej")
+    kw = dict(lane_num=lane_num, intentions=ch, outputs=outs)
+    if lane_num == 12:
+        kw["general_path"] = True
+    one = make_batch(arr, n_envs, capacity, backend, **kw)
+    many = make_batch(arr, n_envs, capacity, backend, **kw)
+    one.reset(); many.reset()
+    acts = rng.uniform(-3, 3, size=(n_pool, n_envs, capacity))
+    if quantize:
+        acts = np.round(acts / quantize) * quantize
+    pool = torch.as_tensor(acts).to(one.device)
+    many.set_action_pool(pool)
+
+    def same_outputs(o1, o2, what):
+        f = _np(o1["flags"])
+        assert np.array_equal(f, _np(o2["flags"])), what + ": flags"
+        alive, ctl = (f & 1) != 0, (f & 2) != 0
+        for k in ("reward", "new_slot", "lanej"):
+            assert np.array_equal(_np(o1[k])[alive], _np(o2[k])[alive]), what + ": " + k
+        assert np.array_equal(_np(o1["nbr"])[ctl], _np(o2["nbr"])[ctl]), what + ": nbr"
+        assert np.array_equal(_np(o1["env_out"]), _np(o2["env_out"])), what + ": env_out"
+
+    def same_headers(what):
+        for e in range(n_envs):
+            i1, i2 = one.read_env(e), many.read_env(e)
+            for f in ("current_time", "n_alive", "id_seq", "passed_veh", "passed_veh_step_total", "overflow", "intention_re"):
+                assert getattr(i1, f) == getattr(i2, f), "%s: header %s of env %d" % (what, f, e)
+            for f in ("lane_count", "veh_rec", "head_valid", "head_lane", "head_j"):
+                assert list(getattr(i1, f)) == list(getattr(i2, f)), "%s: header %s of env %d" % (what, f, e)
+
+    for n in chunks:
+        for _ in range(n):
+            o1 = one.step(pool[one.ticks % n_pool])
+        o2 = many.step_many(n, source="pool", chunk=(0 if n < 6 else (n // 3 + 1)))
+        one.synchronize(); many.synchronize()
+        batches_equal(one, many, "lane_num %d, chunk of %d" % (lane_num, n))
+        same_outputs(o1, o2, "lane_num %d, chunk of %d" % (lane_num, n))
+        same_headers("lane_num %d, chunk of %d" % (lane_num, n))
+    traj = many.step_many(trajectory_chunk, source="pool", trajectory=True, chunk=trajectory_chunk // 2 + 1)
+    for k in range(trajectory_chunk):
+        o1 = one.step(pool[one.ticks % n_pool])
+        same_outputs(o1, {n: traj[n][k] for n in traj}, "trajectory tick %d" % k)
+        post_ctl = (_np(one.state_field("meta")) & 1) != 0
+        assert np.array_equal(_np(one.obs)[post_ctl], _np(traj["obs_post"][k])[post_ctl]), "trajectory obs, tick %d" % k
+    batches_equal(one, many, "after the trajectory chunk")
+    same_headers("after the trajectory chunk")
+    m1, m2 = one.metrics(), many.metrics()
+    for k in m1:
+        assert m1[k] == m2[k], (k, m1[k], m2[k])
+    assert m1["ctl_steps"] > 0
+    return m1
+
+
 def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=1100.0, calls=(40, 25, 60, 35), seed=81, n_pool=7,
                                obs_dtype=torch.float64, chunk=0, source="pool"):
     """Training outputs on the fast path: pve_step_many trajectory roll-outs with

@@ -62,3 +62,10 @@ def test_geo_overflow_empty_exhausted(lane_num):
 def test_geo_list_path_equals_scan_fallback(lane_num, rate, quant):
     m = scenarios.check_geo_lists_equal_scan("emu", lane_num, n_envs=3, ticks=200, rate=rate, quantize=quant)
     assert m["ctl_steps"] > 2000
+
+
+def test_emulated_step_many_geo_equals_single_ticks():
+    """k_rollout_geo's staging sequence (emulated) == one k_tick_geo per tick, 4 and 8 lanes, both capacities."""
+    scenarios.check_step_many_geo(BACKEND, 8, n_envs=3, chunks=(1, 7, 30, 3), trajectory_chunk=8)
+    scenarios.check_step_many_geo(BACKEND, 4, n_envs=3, capacity=64, chunks=(1, 7, 40, 3), trajectory_chunk=8, quantize=1.0)
+    scenarios.check_step_many_geo(BACKEND, 4, n_envs=2, capacity=128, chunks=(25, 30), trajectory_chunk=6)

@@ -306,6 +306,16 @@ def test_gpu_step_many_emits_full_state_rows_fresh_and_stale(dtype, chunk):
     assert n > 20000
 
 
+@pytest.mark.parametrize("lane_num,cap,quant", [(8, 128, None), (4, 64, 1.0), (4, 128, None), (8, 64, 1.0), (12, 128, None)])
+def test_gpu_step_many_geo_equals_single_ticks(lane_num, cap, quant):
+    """k_rollout_geo (4- / 8-lane layouts resident on the chip; lane_num 12 through the general path as a cross-check) ==
+    one k_tick_geo launch per tick, bit for bit, incl. chunked launches and trajectory outputs."""
+    rate = {(8, 64): 700.0, (4, 64): 1200.0}.get((lane_num, cap))
+    m = scenarios.check_step_many_geo(BACKEND, lane_num, n_envs=12, capacity=cap, chunks=(1, 7, 40, 3, 60, 150), rate=rate,
+                                      trajectory_chunk=12, quantize=quant)
+    assert m["overflow"] == 0 and m["ctl_steps"] > 5000
+
+
 def test_gpu_step_many_pipelined():
     scenarios.check_step_many_pipelined(BACKEND, n_envs=37, n_sub=3, ticks=120)
 
