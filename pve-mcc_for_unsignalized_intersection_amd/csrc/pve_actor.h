@@ -357,10 +357,30 @@ __device__ __forceinline__ float actor_xsum2(float s)
     const pve_v2u r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0] = [lo | lo], r[1] = [hi | hi]
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// x = hi + lo in half precision: hi = half(x) (v_cvt_pk_f16_f32, two values per instruction), lo = half(x - hi) with the
+// mixed-precision FMA (v_fma_mixlo / mixhi_f16: fma(x, 1.0, -hi) evaluated in float32 -- exact, x - hi has <= 13 significant
+// bits -- and rounded once to half, straight into its half of the packed register): 1.5 instructions per value instead of
+// 3.5 (convert back, subtract, convert).  Same values as `lo = (_Float16)(x - (float)hi)`.
+// HAZARD: the compiler does not know that these inline-asm statements are vector instructions, so its hazard recognizer
+// inserts no wait states between them and a matrix instruction that reads their result (gfx90a+: 2 wait states between a
+// vector write of a register and an MFMA reading it) -- without the closing `s_nop 1`, which is tied to the results as
+// operands and therefore sits between the last write and the first matrix read, the two kernels that inline this function
+// returned schedule-dependent (different) values.
+typedef _Float16 pve_v2h __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void actor_split8(const float *x, pve_v8h &hi, pve_v8h &lo)
 {
+    typedef unsigned pve_v4u __attribute__((ext_vector_type(4)));
+    pve_v4u hq, lq;
 #pragma unroll
-    for (int e = 0; e < 8; e++) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+    for (int e = 0; e < 8; e += 2) {
+        unsigned hp, lp;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(x[e]), "v"(x[e + 1]));
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lp) : "v"(x[e]), "v"(hp));
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lp) : "v"(x[e + 1]), "v"(hp));
+        hq[e >> 1] = hp; lq[e >> 1] = lp;
+    }
+    asm("s_nop 1" : "+v"(hq), "+v"(lq));
+    hi = __builtin_bit_cast(pve_v8h, hq); lo = __builtin_bit_cast(pve_v8h, lq);
 }
 // 3 tanh(z): exp(2 z) overflows to +inf -> 3, underflows to 0 -> -3
 __device__ __forceinline__ float actor_tanh3(float z)
@@ -414,19 +434,22 @@ __device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *
     float s0 = ((((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) +
                 (((x[8] + x[9]) + (x[10] + x[11])) + ((x[12] + x[13]) + (x[14] + x[15]))));
     const float mean = actor_xsum2(s0) * (1.0f / (float)ACT_IN);
-    float d[16], var = 0.f;
+    pve_v16f d;
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-        d[c] = (c >= 12 && hf) ? 0.f : x[c] - mean;            // features 28..31 do not exist
-        var = fmaf(d[c], d[c], var);
-    }
+    for (int c = 0; c < 16; c++) d[c] = x[c];
+    d = d - mean;
+    if (hf) { d[12] = 0.f; d[13] = 0.f; d[14] = 0.f; d[15] = 0.f; }   // features 28..31 do not exist
+    const pve_v16f e0 = d * d;
+    const float var = ((((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e0[4] + e0[5]) + (e0[6] + e0[7]))) +
+                       (((e0[8] + e0[9]) + (e0[10] + e0[11])) + ((e0[12] + e0[13]) + (e0[14] + e0[15]))));
     const float rstd0 = __builtin_amdgcn_rsqf(actor_xsum2(var) * (1.0f / (float)ACT_IN) + 1e-12f);
     pve_v8h bh[4], bl[4];                                     // B operands of the current layer: K-blocks as half pairs
     {
         const pve_v16f ga = *(const pve_v16f *)(prm + PV_LN0G + 16 * hf), be = *(const pve_v16f *)(prm + PV_LN0B + 16 * hf);
+        const pve_v16f yv = __builtin_elementwise_fma(d, ga * rstd0, be);
         float y[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) y[c] = fmaf(d[c], ga[c] * rstd0, be[c]);
+        for (int c = 0; c < 16; c++) y[c] = yv[c];
         actor_split8(y, bh[0], bl[0]);
         actor_split8(y + 8, bh[1], bl[1]);
     }
@@ -457,13 +480,10 @@ __device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *
     }
     actor_ln_relu32(g, prm + PV_G2 + hf * 32, prm + PV_BE2 + hf * 32);
     // ---- dense 64 -> 1, 3 tanh
-    float part = 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const pve_v16f w3 = *(const pve_v16f *)(prm + PV_W3 + (hf * 2 + m) * 16);
-#pragma unroll
-        for (int r = 0; r < 16; r++) part = fmaf(g[m][r], w3[r], part);
-    }
+    pve_v16f pv = g[0] * *(const pve_v16f *)(prm + PV_W3 + (hf * 2 + 0) * 16);
+    pv = __builtin_elementwise_fma(g[1], *(const pve_v16f *)(prm + PV_W3 + (hf * 2 + 1) * 16), pv);
+    const float part = ((((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
+                        (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15]))));
     return actor_tanh3(actor_xsum2(part) + prm[PV_B3]);
 }
 

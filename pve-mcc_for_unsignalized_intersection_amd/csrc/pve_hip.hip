@@ -377,8 +377,8 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // prefetched actions / arrival times touch HBM.  What it buys beyond the bytes: a launch of k_tick_geo lasts as long as its
 // slowest intersection (43 us against a mean of 30 for 4 lanes x 64 slots); here a slow tick of one intersection is
 // averaged over the ticks of the launch.
-template <int CAP, bool FIX4 = false>
-__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rollout_geo(const GeoConst g_arg, const Params P_arg,
+template <int CAP, bool FIX4 = false, int WPE = 4>
+__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout_geo(const GeoConst g_arg, const Params P_arg,
                                                                                                 const RolloutArgs R_arg)
 {
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -613,7 +613,11 @@ struct Backend {
             if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, true>), dim3(P.n_envs), dim3(64), 0, s, g, P, Rk);
             else hipLaunchKernelGGL((k_rollout_geo<128, true>), dim3(P.n_envs), dim3(128), 0, s, g, P, Rk);
         } else if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, false>), dim3(P.n_envs), dim3(64), 0, s, g, P, Rk);
-        else hipLaunchKernelGGL((k_rollout_geo<128, false>), dim3(P.n_envs), dim3(128), 0, s, g, P, Rk);
+        else {
+            static const bool w5 = getenv("PVE_ROLLOUT_GEO_WPE5") != nullptr;     // A/B knob: 96-VGPR build, 10 workgroups per CU
+            if (w5) hipLaunchKernelGGL((k_rollout_geo<128, false, 5>), dim3(P.n_envs), dim3(128), 0, s, g, P, Rk);
+            else hipLaunchKernelGGL((k_rollout_geo<128, false>), dim3(P.n_envs), dim3(128), 0, s, g, P, Rk);
+        }
         return check_launch(err);
     }
     static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)
