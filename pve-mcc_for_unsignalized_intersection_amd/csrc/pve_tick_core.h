@@ -561,7 +561,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     {
         r.ctl = 0; r.lane = 0; r.j = 0; r.a0 = r.a1 = 0;
         if (r.alive) {
-            const int lane = slot_lane(sh.hd, t);
+            const int lane = (r.meta >> M_LANE_SHIFT) & M_LANE_MASK;    // (== slot_lane(sh.hd, t): slots are sorted by lane)
             r.lane = lane; r.j = t - sh.hd.lane_start[lane];
             sh.lane_of[t] = (uint8_t)lane;
             r.ctl = (r.meta & M_CONTROL) ? 1 : 0;
@@ -1270,7 +1270,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (r.alive) {
             r.v = sh.v[t]; r.a = sh.a[t];                  // back from LDS (S3 published them; dead in registers since then)
             int coll = r.coll_fin > M_COLL_MASK ? M_COLL_MASK : r.coll_fin;
-            meta = (r.meta & (M_CONTROL | M_FINISH | M_DONE)) | M_ALIVE | (coll << M_COLL_SHIFT);
+            meta = (r.meta & (M_CONTROL | M_FINISH | M_DONE | (M_LANE_MASK << M_LANE_SHIFT))) | M_ALIVE | (coll << M_COLL_SHIFT);
             if (r.cyc & 1) {
                 // every member evaluates its cycle's verdict itself: records sorted by rank, python's left-to-right
                 // sum(), tightest record first (ref :1493-1497); +1 for the tightest vehicle, -1 for its header
@@ -1331,7 +1331,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 nv.vnum = nvnum;
                 nv.step = 0; nv.count = 0;
                 size_t gs = (size_t)env * CAP + slot;
-                store_slot(P, gs, nv, M_CONTROL | M_ALIVE, -1);
+                store_slot(P, gs, nv, M_CONTROL | M_ALIVE | (t << M_LANE_SHIFT), -1);
                 const int rec1 = sh.hd.veh_rec[t] + 1;
                 gh.veh_rec[t] = rec1;
                 gh.next_arr[t] = r.next_arr;
@@ -1529,7 +1529,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             sh.template stf<Sh::SF_VIR_DIS>()[s] = 100; sh.template stf<Sh::SF_CLOSER_P>()[s] = 150;
             sh.template sti<I_ID>()[s] = fc.sp_id; sh.template sti<I_SEQ>()[s] = sh.hd.veh_rec[t];
             sh.template sti<I_VNUM>()[s] = fc.sp_vnum; sh.template sti<I_STEP>()[s] = 0; sh.template sti<I_COUNT>()[s] = 0;
-            sh.template sti<I_META>()[s] = M_CONTROL | M_ALIVE; sh.template sti<I_HDR>()[s] = -1;
+            sh.template sti<I_META>()[s] = M_CONTROL | M_ALIVE | (t << M_LANE_SHIFT); sh.template sti<I_HDR>()[s] = -1;
             sh.hd.veh_rec[t] += 1;
             sh.hd.next_arr[t] = r.next_arr;
         }
@@ -1715,7 +1715,7 @@ PVE_HD void reset_env(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, 
             P.f64[F_P][g] = c.spawn_p[l % 3]; P.f64[F_V][g] = c.v0; P.f64[F_A][g] = 0; P.f64[F_JERK][g] = 0;
             P.f64[F_JERK_SUM][g] = 0; P.f64[F_VIR_DIS][g] = 100; P.f64[F_CLOSER_P][g] = 150;
             P.i32[I_ID][g] = s; P.i32[I_SEQ][g] = 0; P.i32[I_VNUM][g] = 0; P.i32[I_STEP][g] = 0;
-            P.i32[I_COUNT][g] = 0; P.i32[I_META][g] = M_CONTROL | M_ALIVE; P.i32[I_HDR][g] = -1;
+            P.i32[I_COUNT][g] = 0; P.i32[I_META][g] = M_CONTROL | M_ALIVE | (l << M_LANE_SHIFT); P.i32[I_HDR][g] = -1;
         } else {
             P.f64[F_P][g] = 0; P.f64[F_V][g] = 0; P.f64[F_A][g] = 0; P.f64[F_JERK][g] = 0;
             P.f64[F_JERK_SUM][g] = 0; P.f64[F_VIR_DIS][g] = 0; P.f64[F_CLOSER_P][g] = 0;

@@ -718,7 +718,8 @@ template <int CAP> struct TickGeo {
         int meta = 0, hdr_word = -1, new_slot = -1, lockf = 0;
         if (r.alive) {
             int coll = r.coll_fin > M_COLL_MASK ? M_COLL_MASK : r.coll_fin;
-            meta = (r.meta & (M_CONTROL | M_FINISH | M_DONE | (M_INT_MASK << M_INT_SHIFT))) | M_ALIVE | (coll << M_COLL_SHIFT);
+            meta = (r.meta & (M_CONTROL | M_FINISH | M_DONE | (M_INT_MASK << M_INT_SHIFT) | (M_LANE_MASK << M_LANE_SHIFT))) | M_ALIVE |
+                   (coll << M_COLL_SHIFT);
             if (r.cyc & 1) {                                                           // ref :1493-1497
                 const int len = (r.cyc >> 1) & 15, off = sh.cyc_off[r.cyc >> 9];
                 double sum = 0;
@@ -776,7 +777,7 @@ template <int CAP> struct TickGeo {
                 nv.vnum = sh.hd.lane_start[t + 1] - sh.hd.lane_start[t];
                 nv.step = 0; nv.count = 0;
                 Base::store_slot(P, (size_t)env * CAP + slot, nv,
-                                 M_CONTROL | M_ALIVE | (LN == 12 ? 0 : (intention << M_INT_SHIFT)), -1);   // 12-lane: lane % 3, not stored
+                                 M_CONTROL | M_ALIVE | (t << M_LANE_SHIFT) | (LN == 12 ? 0 : (intention << M_INT_SHIFT)), -1);   // 12-lane: lane % 3, not stored
             }
             if (O.obs_post) {                                                          // ref :380, :420
                 if (P.obs_f32) { float *o = (float *)O.obs_post + ((size_t)env * CAP + slot) * OBSW; for (int k = 0; k < OBSW; k++) o[k] = 0.0f; }
@@ -897,7 +898,7 @@ template <int CAP> struct TickGeo {
             sh.template stf<Sh::SF_VIR_DIS>()[s] = 100; sh.template stf<Sh::SF_CLOSER_P>()[s] = 150;
             sh.template sti<I_ID>()[s] = fc.sp_id; sh.template sti<I_SEQ>()[s] = sh.hd.veh_rec[t];
             sh.template sti<I_VNUM>()[s] = fc.sp_vnum; sh.template sti<I_STEP>()[s] = 0; sh.template sti<I_COUNT>()[s] = 0;
-            sh.template sti<I_META>()[s] = M_CONTROL | M_ALIVE | (g.lane_num == 12 ? 0 : (fc.sp_int << M_INT_SHIFT));
+            sh.template sti<I_META>()[s] = M_CONTROL | M_ALIVE | (t << M_LANE_SHIFT) | (g.lane_num == 12 ? 0 : (fc.sp_int << M_INT_SHIFT));
             sh.template sti<I_HDR>()[s] = -1;
             sh.hd.veh_rec[t] += 1;
             sh.hd.next_arr[t] = r.next_arr;
@@ -993,7 +994,7 @@ PVE_HD void reset_env_geo(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, in
             P.f64[F_JERK_SUM][gi] = 0; P.f64[F_VIR_DIS][gi] = 100; P.f64[F_CLOSER_P][gi] = 150;
             P.i32[I_ID][gi] = s; P.i32[I_SEQ][gi] = 0; P.i32[I_VNUM][gi] = 0; P.i32[I_STEP][gi] = 0;
             P.i32[I_COUNT][gi] = 0; P.i32[I_HDR][gi] = -1;
-            P.i32[I_META][gi] = M_CONTROL | M_ALIVE | (LN == 12 ? 0 : (int_of[s] << M_INT_SHIFT));
+            P.i32[I_META][gi] = M_CONTROL | M_ALIVE | (lane_of[s] << M_LANE_SHIFT) | (LN == 12 ? 0 : (int_of[s] << M_INT_SHIFT));
         } else {
             P.f64[F_P][gi] = 0; P.f64[F_V][gi] = 0; P.f64[F_A][gi] = 0; P.f64[F_JERK][gi] = 0;
             P.f64[F_JERK_SUM][gi] = 0; P.f64[F_VIR_DIS][gi] = 0; P.f64[F_CLOSER_P][gi] = 0;

@@ -26,6 +26,8 @@ constexpr int M_DEL = 0x40;                             // in delete_veh, awaiti
 constexpr int M_ALIVE = 0x80;
 constexpr int M_COLL_SHIFT = 8, M_COLL_MASK = 0xFFFF;   // veh["collision"] (ref :333-334)
 constexpr int M_INT_SHIFT = 24, M_INT_MASK = 0x3;       // veh["intention"] (ref :382-394); 12-lane: lane % 3, not stored
+constexpr int M_LANE_SHIFT = 26, M_LANE_MASK = 0xF;     // veh["lane"]: set at the spawn, never changes -- step() reads it from here
+                                                        // instead of comparing the slot with the 12 lane starts
 
 // launch modes
 constexpr int MODE_FUSED = 0;     // step* + scene_update + delete_vehicle
