@@ -328,14 +328,17 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     B::ph_step3(g.base, t, sh, r);
     B::ph_step3_publish(t, sh, r);
     T::ph_order2(t, sh);
+    T::ph_pairs_mode(t, sh, P.geo_scan != 0);
     lds_barrier();
     PVE_PHASE_MARK(3)
-    T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
-    lds_barrier();
-    T::ph_pairs_exact(t, sh, P.geo_scan != 0);
-    lds_barrier();
-    T::ph_pairs_apply(t, sh);
-    lds_barrier();
+    if (T::pairs_over(sh, P.geo_scan != 0)) {         // (uniform, rare: the capacity upper bounds overflow the entry pool)
+        T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
+        lds_barrier();
+        T::ph_pairs_exact(t, sh, P.geo_scan != 0);
+        lds_barrier();
+        T::ph_pairs_apply(t, sh);
+        lds_barrier();
+    }
     T::ph_pairs_fill(g, t, sh);
     lds_barrier();
     PVE_PHASE_MARK(4)
@@ -423,13 +426,16 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         B::ph_step3(g.base, t, sh, r);
         B::ph_step3_publish(t, sh, r);
         T::ph_order2(t, sh);
+        T::ph_pairs_mode(t, sh, P.geo_scan != 0);
         lds_barrier();
-        T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
-        lds_barrier();
-        T::ph_pairs_exact(t, sh, P.geo_scan != 0);
-        lds_barrier();
-        T::ph_pairs_apply(t, sh);
-        lds_barrier();
+        if (T::pairs_over(sh, P.geo_scan != 0)) {     // (uniform, rare)
+            T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
+            lds_barrier();
+            T::ph_pairs_exact(t, sh, P.geo_scan != 0);
+            lds_barrier();
+            T::ph_pairs_apply(t, sh);
+            lds_barrier();
+        }
         T::ph_pairs_fill(g, t, sh);
         lds_barrier();
         T::ph_rank(t, sh);

@@ -288,6 +288,14 @@ template <int CAP> struct TickGeo {
             sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)x; sh.u_list[e] = (uint8_t)d;
         }
     }
+    // The common case -- the capacity upper bounds fit the entry pool -- needs neither the counting pass nor the two
+    // phases that pack the segments: pairs_over() (uniform: an LDS value) lets the kernels branch around COUNT / EXACT /
+    // APPLY and their three barriers; ph_pairs_mode (same phase as ORDER2, lbase is complete there) sets pool_ok for it.
+    static PVE_HD bool pairs_over(const Sh &sh, bool force_scan) { return !force_scan && sh.lbase[ND] > Sh::PE; }
+    static PVE_HD void ph_pairs_mode(int t, Sh &sh, bool force_scan)
+    {
+        if (t == 0) sh.pool_ok = force_scan ? 0 : (sh.lbase[ND] > Sh::PE ? 2 : 1);
+    }
     static PVE_HD void ph_pairs_count(const PVE_AS4 GeoConst &g, int t, Sh &sh, bool force_scan)
     {
         if (force_scan || sh.lbase[ND] <= Sh::PE) return;       // the upper bounds fit (or the scan is forced): nothing to count

@@ -115,9 +115,12 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
         for (int t = 0; t < CAP; t++) B::ph_step3(g.base, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_step3_publish(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_order2(t, sh);
-        for (int t = 0; t < CAP; t++) T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
-        for (int t = 0; t < CAP; t++) T::ph_pairs_exact(t, sh, P.geo_scan != 0);
-        for (int t = 0; t < CAP; t++) T::ph_pairs_apply(t, sh);
+        for (int t = 0; t < CAP; t++) T::ph_pairs_mode(t, sh, P.geo_scan != 0);
+        if (T::pairs_over(sh, P.geo_scan != 0)) {
+            for (int t = 0; t < CAP; t++) T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
+            for (int t = 0; t < CAP; t++) T::ph_pairs_exact(t, sh, P.geo_scan != 0);
+            for (int t = 0; t < CAP; t++) T::ph_pairs_apply(t, sh);
+        }
         for (int t = 0; t < CAP; t++) T::ph_pairs_fill(g, t, sh);
         for (int t = 0; t < CAP; t++) T::ph_load_late(P, env, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
@@ -162,9 +165,12 @@ template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &
             for (int t = 0; t < CAP; t++) B::ph_step3(g.base, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) B::ph_step3_publish(t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_order2(t, sh);
-            for (int t = 0; t < CAP; t++) T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
-            for (int t = 0; t < CAP; t++) T::ph_pairs_exact(t, sh, P.geo_scan != 0);
-            for (int t = 0; t < CAP; t++) T::ph_pairs_apply(t, sh);
+            for (int t = 0; t < CAP; t++) T::ph_pairs_mode(t, sh, P.geo_scan != 0);
+            if (T::pairs_over(sh, P.geo_scan != 0)) {
+                for (int t = 0; t < CAP; t++) T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
+                for (int t = 0; t < CAP; t++) T::ph_pairs_exact(t, sh, P.geo_scan != 0);
+                for (int t = 0; t < CAP; t++) T::ph_pairs_apply(t, sh);
+            }
             for (int t = 0; t < CAP; t++) T::ph_pairs_fill(g, t, sh);
             for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
             if (fix4) for (int t = 0; t < CAP; t++) T::template ph_scan<true>(g, t, sh, regs[t]);
