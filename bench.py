@@ -281,6 +281,8 @@ def main(argv=None, env_factory=None):
                     help="rollout mode: 1 = every tick's outputs are RETAINED (trajectory roll-outs into a ring of two "
                          "chunk buffers per sub-batch, what a trainer consumes, main.py:397-441); 0 = each tick overwrites "
                          "the previous tick's outputs")
+    ap.add_argument("--no-companion", action="store_true",
+                    help="skip the second timed region (per-tick outputs retained) behind the headline roll-out")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle replay of %d sampled envs after the timed region" % VERIFY_ENVS)
     ap.add_argument("--obs-f64", action="store_true",
@@ -494,6 +496,27 @@ def main(argv=None, env_factory=None):
             verify = verify_against_oracle(locate, last_outputs, arr, pool_np, tick[0], lane_num, choice)
         else:
             verify = dict(verified=None, reason="needs the flags, reward and env_out outputs")
+    # ---- companion figure: the headline roll-out overwrites each tick's outputs with the next tick's; the same K
+    # ticks with every tick's outputs RETAINED (trajectory roll-outs into a ring of two chunk buffers per sub-batch: what a
+    # trainer consumes) are timed right behind it, outside the headline region
+    companion = None
+    if mode == "rollout" and not traj_on and not args.actor and not emu and world == 1 and not args.no_companion:
+        tl = args.chunk if args.chunk > 0 else 25
+        ring2 = [env.alloc_trajectory(tl) for _ in range(2)]
+        def traj_ticks(n):
+            for i, c0 in enumerate(range(0, n, tl)):
+                env.step_many(min(tl, n - c0), trajectory=ring2[i & 1], update_views=False)
+        traj_ticks(2 * tl)
+        sync()
+        tc0 = time.perf_counter()
+        traj_ticks(K)
+        sync()
+        tc = time.perf_counter() - tc0
+        tick[0] += 2 * tl + K
+        companion = {"what": "the same workload with every tick's outputs retained (pve_step_many trajectory = 1, launches of %d "
+                             "ticks into a ring of two buffers per sub-batch)" % tl,
+                     "ms_per_step": tc / K * 1e3, "value": float(cap) * n_envs * K / tc, "unit": "env-steps/s", "steps": K}
+        del ring2
     ok_flag = 0.0 if verify["verified"] is False else 1.0
     if world > 1:
         tv = torch.tensor([ok_flag], dtype=torch.float64, device=dev)
@@ -553,6 +576,7 @@ def main(argv=None, env_factory=None):
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "synthetic (injected test environment: timings meaningless)",
             "verified": verify["verified"], "verification": verify,
+            "retained_outputs": companion,
             "config": {"workload": "%d parallel %d-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"

@@ -15,7 +15,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM
            "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_INT32" \
            "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS_ATOMIC"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $grp --kernel-trace -d "$OUT/p$i" -o p$i --output-format csv -- python3 "$REPO/bench.py" --steps 100 --warmup 300 --no-cpu-baseline --no-copy-peak --no-verify ${PMC_BENCH_ARGS:-} > "$OUT/p$i.log" 2>&1
+  timeout 150 rocprofv3 --pmc $grp --kernel-trace -d "$OUT/p$i" -o p$i --output-format csv -- python3 "$REPO/bench.py" --steps 100 --warmup 300 --no-cpu-baseline --no-copy-peak --no-verify --no-companion ${PMC_BENCH_ARGS:-} > "$OUT/p$i.log" 2>&1
 done
 python3 - "$OUT" <<'PY' > "$REPO/gpurun_out/pmc_sq_$TAG.txt"
 import sys, glob, csv, collections
