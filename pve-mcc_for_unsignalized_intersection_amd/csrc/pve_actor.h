@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //    3.6e-7 absolute on the action), divisions by the layer widths are multiplications;
 //  * every weight is centered, split and laid out in A-operand order ONCE (k_actor_pack, pve_set_actor) instead of by
 //    every workgroup of every launch.
-// The same device function (`actor_wave`) is called by the stand-alone kernel k_actor_h (weights staged in LDS by persistent
+// The same device function (`actor_tile32`) is called by the stand-alone kernel k_actor_h (weights staged in LDS by persistent
 // workgroups) and from inside k_rollout (pve_step_many(PVE_SRC_ACTOR): the closed loop resident on the chip, A operands
 // streamed from L1 / L2), so the two paths are bit-identical by construction.
 // Not bit-identical to the float32 chain of k_actor_t (actor_canonical); the action parity bar is 5e-4
@@ -487,33 +487,15 @@ __device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *
     return actor_tanh3(actor_xsum2(part) + prm[PV_B3]);
 }
 
-// Every lane of the wave brings ONE vehicle's observation row (row[28], float32; `valid` = it has one) and gets that
-// vehicle's action back.  The two tiles of the wave are formed in registers: tile A = the vehicles of lanes 0..31, tile B =
-// those of lanes 32..63; one v_permlane32_swap per feature pair hands each lane the half row it contracts
-// (swap(F0, F1): a' = [F0.lo | F1.lo] = tile A, b' = [F0.hi | F1.hi] = tile B).  A tile without a valid lane is skipped
-// (wave-uniform).
-__device__ __forceinline__ float actor_wave(const pve_v8h *A1, const pve_v8h *A2, const float *prm, const float (&row)[ACT_IN],
-                                            bool valid, int lane)
+// The <= 16 raw features lane (j, hf) contracts, straight from the observation row of `slot` (float32 or float64 rows):
+// features 8 hf .. 8 hf + 7 and 16 + 8 hf .. 16 + 8 hf + 7 (28 .. 31 do not exist: zeros) -- four 16-byte loads per lane
+// for float32 rows, every row read by exactly two lanes
+template <typename OBS_T>
+__device__ __forceinline__ void actor_fetch(const OBS_T *rows, size_t row, int hf, float (&x)[16])
 {
-    const unsigned long long vm = __ballot(valid);
-    float xa[16], xb[16];
+    const OBS_T *src = rows + row * OBSW + 8 * hf;
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-        const int f0 = 16 * (c >> 3) + (c & 7), f1 = f0 + 8;
-        const unsigned a = __float_as_uint(row[f0]), b = f1 < ACT_IN ? __float_as_uint(row[f1]) : 0u;
-        const pve_v2u r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-        xa[c] = __uint_as_float(r[0]); xb[c] = __uint_as_float(r[1]);
-    }
-    float act = 0.f;
-    if ((unsigned)vm != 0u) {                                  // tile A (uniform)
-        const float a = actor_tile32(A1, A2, prm, xa, lane);
-        act = lane < 32 ? a : act;
-    }
-    if ((unsigned)(vm >> 32) != 0u) {                          // tile B (uniform)
-        const float a = actor_tile32(A1, A2, prm, xb, lane);
-        act = lane >= 32 ? a : act;
-    }
-    return act;
+    for (int c = 0; c < 16; c++) x[c] = (c < 12 || !hf) ? (float)src[actor_feature(c, 0)] : 0.f;
 }
 
 // pve_set_actor: flat float32 weights -> the packed buffer (one workgroup of 256 threads)
@@ -571,7 +553,7 @@ __global__ __launch_bounds__(256) void k_actor_pack(const float *__restrict__ W,
 
 // Stand-alone actor pass (pve_actor_forward / pve_step_all_actor): persistent workgroups of 4 waves sharing ONE copy of the
 // packed parameters in LDS; every wave is on its own: it loops over intersections, compacts the controlled vehicles of its
-// intersection with ballots (dense lanes), every lane loads ONE vehicle's row, and actor_wave runs the <= 2 tiles.
+// intersection with ballots and runs their tiles of 32 (lane (j, hf) fetches the half row it contracts).
 template <int CAP, typename OBS_T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_actor_h(const unsigned char *__restrict__ packed, const OBS_T *__restrict__ obs,
                                                  const int32_t *__restrict__ meta, double *__restrict__ actions,
@@ -608,19 +590,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int sub = 0; sub < CAP / 64; sub++) mt[sub] = en < n_envs ? meta[(size_t)en * CAP + sub * 64 + lane] : 0;
         }
-        for (int v0 = 0; v0 < nctl; v0 += 64) {              // 64 vehicles per pass (one per lane)
+        for (int v0 = 0; v0 < nctl; v0 += 32) {              // one tile = 32 vehicles, two lanes each
             int wo = 0;
-            asm volatile("" : "+v"(wo));                      // (keeps the A-operand reads inside the loop)
-            const bool valid = v0 + lane < nctl;
-            const int slot = slot_of[valid ? v0 + lane : 0];
-            float row[ACT_IN];
-            {
-                const OBS_T *src = obs + (base + slot) * OBSW;
-#pragma unroll
-                for (int k = 0; k < ACT_IN; k++) row[k] = valid ? (float)src[k] : 0.f;
-            }
-            const float a = actor_wave(A1, A2, prm + wo, row, valid, lane);
-            if (valid) actions[base + slot] = (double)a;
+            asm volatile("" : "+v"(wo));                      // (keeps the parameter reads inside the loop)
+            const int j = lane & 31, hf = lane >> 5;
+            const bool valid = v0 + j < nctl;
+            const int slot = slot_of[valid ? v0 + j : 0];
+            float x[16];
+            actor_fetch(obs, base + slot, hf, x);
+            const float a = actor_tile32(A1, A2, prm + wo, x, lane);
+            if (valid && hf == 0) actions[base + slot] = (double)a;
         }
     }
 }

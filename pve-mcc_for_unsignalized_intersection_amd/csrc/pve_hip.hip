@@ -117,17 +117,10 @@ __device__ __forceinline__ void rollout_actor(const unsigned char *packed, const
     const int lane = t & 63, hf = lane >> 5, j = lane & 31;
     for (int tile = t >> 6; 32 * tile < n_ctl; tile += CAP / 64) {          // (uniform per wave)
         const int slot = adsts[32 * tile + j];
-        const size_t g = (base + (slot == 255 ? 0 : slot)) * OBSW + 8 * hf;
+        const size_t row = base + (slot == 255 ? 0 : slot);
         float x[16];
-        if (obs_f32) {
-            const float *src = (const float *)rows + g;
-#pragma unroll
-            for (int c = 0; c < 16; c++) x[c] = (c < 12 || !hf) ? src[actor_feature(c, 0)] : 0.f;
-        } else {
-            const double *src = (const double *)rows + g;
-#pragma unroll
-            for (int c = 0; c < 16; c++) x[c] = (c < 12 || !hf) ? (float)src[actor_feature(c, 0)] : 0.f;
-        }
+        if (obs_f32) actor_fetch((const float *)rows, row, hf, x);
+        else actor_fetch((const double *)rows, row, hf, x);
         const float a = actor_tile32(A1, A2, aprm, x, lane);
         if (lane < 32 && slot != 255) act[slot] = (double)a;
     }
@@ -142,7 +135,7 @@ __device__ __forceinline__ void rollout_actor(const unsigned char *packed, const
 // ACT: pve_step_many(PVE_SRC_ACTOR) -- the closed loop of main.py:398-441 resident on the chip.  The dense thread of every
 // controlled vehicle keeps the float32 observation row it has just built in FIN; behind STAGE (the carried state lives in
 // the staging arrays by then, the registers are free) the wave runs the actor on its <= 2 tiles of 32 vehicles
-// (pve_actor.h: actor_wave, the same function the stand-alone k_actor_h calls), A operands streamed from L1 / L2, the
+// (pve_actor.h: actor_tile32, the same function the stand-alone k_actor_h calls), A operands streamed from L1 / L2, the
 // float parameters in 2 KB of LDS, and deposits next tick's actions where RELOAD looks for them (act_next).  No new
 // barrier; still ticks are staged like the others.  The first tick of a launch takes its rows from HBM.
 // TRAIN: the training outputs (obs_pre, state_pre: SURVEY 8 f3) are written per tick; a variant of its own so that the

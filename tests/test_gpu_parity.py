@@ -282,6 +282,15 @@ def test_gpu_closed_loop_on_float32_observations_is_bit_identical():
     A.check_closed_loop_f32_obs_equals_f64("hip", ticks=400, n_envs=16)
 
 
+def test_gpu_split_actor_long_horizon_drift_is_bounded():
+    """Default (split-half) actor vs the exact float32 chain over a 1000-tick closed loop on 16 intersections: actions on
+    identical states within 1e-4, no collision in either, every aggregate of the evaluation protocol within 1-2 %."""
+    from tests import actor_scenarios as A
+    first, worst_a, rel = A.check_split_actor_long_horizon("hip", ticks=1000, n_envs=16)
+    print("split vs exact actor: first differing tick %s, max |da| on identical states %.2e, relative aggregate differences %s"
+          % (first, worst_a, {k: round(v, 5) for k, v in rel.items()}))
+
+
 def test_gpu_pipelined_sub_batches_equal_one_batch():
     """Two / three free-running sub-batches on their own HIP streams == one launch over all envs, bit for bit."""
     scenarios.check_pipelined_equals_single(BACKEND, n_envs=64, n_sub=2, ticks=300)
