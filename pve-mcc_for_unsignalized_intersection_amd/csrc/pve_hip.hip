@@ -333,6 +333,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         lds_barrier();
     }
     T::ph_pairs_fill(g, t, sh);
+    if (FIX4) T::ph_fix_table(g, t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(4)
     T::ph_load_late(P, env, t, sh, r);
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             lds_barrier();
         }
         T::ph_pairs_fill(g, t, sh);
+        if (FIX4) T::ph_fix_table(g, t, sh, r);
         lds_barrier();
         T::ph_rank(t, sh);
         lds_barrier();

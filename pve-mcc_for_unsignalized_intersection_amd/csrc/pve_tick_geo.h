@@ -71,6 +71,14 @@ template <int CAP> struct SharedGeo {
     int16_t lbase[ND + 1];                  // list d owns [lbase[d], lbase[d] + fill[d]) (capacity: the next lbase)
     int16_t rbase[ND + 1], pbase[ND + 1];   // prefix of rc (route-sorted controlled vehicles) and of rc * nl (pairs)
     uint8_t ctl_by_route[CAP];
+    // 4-lane far-conflict fix-up (ref :1301-1319) as a TABLE: row = a controlled vehicle x of a left-turn route (rk[x] = its
+    // rank among the controlled vehicles of its route), column i = the value of x's entry in the opposing left-turn route's
+    // list after the first i + 1 egos of that route have re-written it (the adjustments compound, ref :286-287).  Computed
+    // once per (entry, ego) by the entry's own thread instead of being replayed by every ego for every member it looks at;
+    // lives in the unused tail of the entry pool, u_vd[tstart ..) (fix_ok = 0: no room, the egos replay as before)
+    uint8_t rk[CAP];
+    int16_t tbase[5], tstart;
+    int fix_ok;
     alignas(8) GeoTab tab;           // copy of GeoConst::tab
     int cnt[CAP];
     int acc_passed_steps, acc_collisions, lead_n, emu_scan, emu_scan2, emu_scan3;
@@ -246,7 +254,9 @@ template <int CAP> struct TickGeo {
             int rb = 0;
 #pragma unroll
             for (int rt = 0; rt < ND; rt++) rb += (rt < r.route) ? sh.rc[rt] : 0;
-            sh.ctl_by_route[rb + lds_claim(&sh.rfill[r.route], 1)] = (uint8_t)t;
+            const int rkk = lds_claim(&sh.rfill[r.route], 1);
+            sh.ctl_by_route[rb + rkk] = (uint8_t)t;
+            sh.rk[t] = (uint8_t)rkk;
         }
         if (r.alive) {
             const int ls = sh.hd.lane_start[r.lane], le = sh.hd.lane_start[r.lane + 1];
@@ -295,6 +305,47 @@ template <int CAP> struct TickGeo {
     static PVE_HD void ph_pairs_mode(int t, Sh &sh, bool force_scan)
     {
         if (t == 0) sh.pool_ok = force_scan ? 0 : (sh.lbase[ND] > Sh::PE ? 2 : 1);
+        if (t == 1) {
+            // far-conflict table of the 4-lane layout: one block per left-turn route d = 3 q: rc[opp[d]] rows x rc[d] columns,
+            // behind the entry pool's capacity bound (no room, or no lists: the egos replay the adjustments themselves)
+            int o = 0;
+            for (int q = 0; q < 4; q++) { sh.tbase[q] = (int16_t)o; o += sh.rc[sh.tab.opp[3 * q] < 0 ? 0 : sh.tab.opp[3 * q]] * sh.rc[3 * q]; }
+            sh.tbase[4] = (int16_t)o;
+            const int start = sh.lbase[ND];
+            sh.tstart = (int16_t)(start > 32767 ? 32767 : start);
+            sh.fix_ok = (!force_scan && start + o <= Sh::PE) ? 1 : 0;
+        }
+    }
+    // one thread per controlled vehicle x of a left-turn route (4-lane layout): the value of x's entry in the list of the
+    // OPPOSING left-turn route d after each of d's egos, in slot order (ref :1301-1319).  Same phase as FILL (reads only
+    // positions, counts and masks; writes beyond the capacity bound of the entry pool).
+    static PVE_HD void ph_fix_table(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
+    {
+        if (g.lane_num != 4 || !sh.fix_ok) return;
+        if (!(r.alive && r.ctl) || r.route % 3 != 0) return;
+        const int d = sh.tab.opp[r.route];                    // (the relation is symmetric: opp[opp[d]] = d)
+        if (d < 0) return;
+        const int li = sh.tab.dir_lane[d], m = sh.tab.dir_index[d];
+        double vc;
+        if (!member(g, sh, d, li, m, t, vc)) return;          // not in list d: its row is never read
+        const int ls = sh.hd.lane_start[li], le = sh.hd.lane_start[li + 1];
+        double *row = sh.u_vd + sh.tstart + sh.tbase[d / 3] + (int)sh.rk[t] * sh.rc[d];
+        int i = 0;
+        for (int w2 = 0; w2 < NW; w2++) {
+            u64 eb = sh.m_ctl[w2] & sh.m_int[m][w2] & below_sel(le - w2 * 64) & ~below_sel(ls - w2 * 64);
+            for (; eb; eb &= eb - 1) {
+                const double pe = sh.p[w2 * 64 + __builtin_ctzll(eb)];
+                const double ori = vc + g.fix_d;                                       // ref :1304
+                if (pe < ori) {                                                        // ref :1305-1312
+                    const double r2 = ori - g.fix_hi + g.fix_lo;
+                    vc = (r2 < pe) ? pe + 1 : r2;
+                } else {                                                               // ref :1313-1319
+                    const double r2 = ori + g.fix_hi - g.fix_lo;
+                    vc = (r2 > pe) ? pe - 1 : r2;
+                }
+                row[i++] = vc;
+            }
+        }
     }
     static PVE_HD void ph_pairs_count(const PVE_AS4 GeoConst &g, int t, Sh &sh, bool force_scan)
     {
@@ -453,6 +504,18 @@ template <int CAP> struct TickGeo {
         const int opp = sh.tab.opp[d];
         const int ls = sh.hd.lane_start[li], le = sh.hd.lane_start[li + 1];
         const unsigned mroutes = sh.tab.mroutes[d];                  // routes that can appear in list d (cheap early reject)
+        // current value of member x's entry (build-time value vo) as this ego sees it: table lookup, or the replay
+        const bool tabf = fix && sh.fix_ok != 0;
+        int tcol = 0;
+        if (tabf) {                                           // this ego's column: its index among the egos of its route
+            for (int w2 = 0; w2 < NW; w2++)
+                tcol += __builtin_popcountll(sh.m_ctl[w2] & sh.m_int[m][w2] & below_sel(t - w2 * 64) & ~below_sel(ls - w2 * 64));
+            tcol += sh.tstart + sh.tbase[d / 3];
+        }
+        const int tcols = sh.rc[d];
+        auto adj = [&](int x, double vo) -> double {
+            return tabf ? sh.u_vd[tcol + (int)sh.rk[x] * tcols] : adjusted(g, sh, m, ls, le, t, vo);
+        };
         double bvo = -INFINITY, bvc = 0; int bslot = -1;
         // the 6 nearest so far, sorted by |vd - vd_self|: only (distance, slot) travel through the insertion chain;
         // the build-time / current distances of the 6 winners are re-derived at the end, and the rare exact
@@ -462,7 +525,7 @@ template <int CAP> struct TickGeo {
 #pragma unroll
         for (int k = 0; k < NNB; k++) { kd[k] = INFINITY; ks[k] = -1; }
         auto consider = [&](int x, double vo) {
-            const double vc = (fix && sh.route_of[x] == opp) ? adjusted(g, sh, m, ls, le, t, vo) : vo;
+            const double vc = (fix && sh.route_of[x] == opp) ? adj(x, vo) : vo;
             // predecessor in list order = stable sort by the build-time distance (ref :271, :1353)
             const bool before = vo < me || (vo == me && x < t);
             if (before && (vo > bvo || (vo == bvo && x > bslot))) { bvo = vo; bslot = x; bvc = vc; }
@@ -537,7 +600,7 @@ template <int CAP> struct TickGeo {
                         const int i = i0 + k;
                         const bool valid = (i < n) & (i != mp);
                         double vc = vos[k];
-                        if (valid && rts[k] == opp) vc = adjusted(g, sh, m, ls, le, t, vc);
+                        if (valid && rts[k] == opp) vc = adj(xs[k], vc);
                         const unsigned key = valid ? ((Base::f32_bits((float)fabs(vc - me)) & ~127u) | (unsigned)i) : ~0u;
                         unsigned c = key;                     // insertion into the sorted 7: one min / max pair per place
 #pragma unroll
@@ -553,7 +616,7 @@ template <int CAP> struct TickGeo {
                     const int i = has ? (int)(k7[k] & 127u) : 0;
                     const int x = sh.s_slot[base + i];
                     double vc = sh.u_vd[sh.s_idx[base + i]];
-                    if (has && sh.route_of[x] == opp) vc = adjusted(g, sh, m, ls, le, t, vc);
+                    if (has && sh.route_of[x] == opp) vc = adj(x, vc);
                     wx[k] = has ? x : -1; wp[k] = i; wv[k] = has ? vc : 0.0; wd[k] = has ? fabs(vc - me) : INFINITY;
                 }
 #pragma unroll
@@ -567,7 +630,7 @@ template <int CAP> struct TickGeo {
                     if (mp > 0) {
                         bs = sh.s_slot[base + mp - 1];
                         bv = sh.u_vd[sh.s_idx[base + mp - 1]];
-                        if (sh.route_of[bs] == opp) bv = adjusted(g, sh, m, ls, le, t, bv);
+                        if (sh.route_of[bs] == opp) bv = adj(bs, bv);
                     }
                     r.hdr = bs;                                                             // ref :1348-1354
                     r.vir_dis = (bs >= 0) ? (me - bv) : 100.0;
@@ -598,7 +661,7 @@ template <int CAP> struct TickGeo {
             const int x = ks[k];
             if (x >= 0) {
                 member(g, sh, d, li, m, x, vo);
-                if (fix && sh.route_of[x] == opp) vo = adjusted(g, sh, m, ls, le, t, vo);
+                if (fix && sh.route_of[x] == opp) vo = adj(x, vo);
             }
             r.kr[k] = x; r.kv[k] = vo;
         }

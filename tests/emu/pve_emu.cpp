@@ -122,6 +122,7 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
             for (int t = 0; t < CAP; t++) T::ph_pairs_apply(t, sh);
         }
         for (int t = 0; t < CAP; t++) T::ph_pairs_fill(g, t, sh);
+        for (int t = 0; t < CAP; t++) T::ph_fix_table(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_load_late(P, env, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
         for (int t = 0; t < CAP; t++) T::ph_scan(g, t, sh, regs[t]);
@@ -172,6 +173,7 @@ template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &
                 for (int t = 0; t < CAP; t++) T::ph_pairs_apply(t, sh);
             }
             for (int t = 0; t < CAP; t++) T::ph_pairs_fill(g, t, sh);
+            for (int t = 0; t < CAP; t++) T::ph_fix_table(g, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
             if (fix4) for (int t = 0; t < CAP; t++) T::template ph_scan<true>(g, t, sh, regs[t]);
             else for (int t = 0; t < CAP; t++) T::template ph_scan<false>(g, t, sh, regs[t]);
