@@ -51,17 +51,39 @@ for k in range(a.runs):
 print("%d runs: %d green, %d ended at a deferred spawn, 0 differences" % (a.runs, ok, stopped))
 # pve_step_many (k_rollout: still ticks, staged ticks, chunked launches, trajectory outputs) == single ticks, bit for bit
 for k in range(a.many):
-    cap = int(rng.choice([64, 128, 128]))
-    lo, hi = RATES[(12, cap)]
-    rate = float(rng.uniform(lo * 0.3, hi * 1.15))          # (deferred spawns are deterministic: both paths agree on them too)
-    n_envs = int(rng.choice([3, 8, 17]))
-    chunks = tuple(int(x) for x in rng.integers(1, 90, size=int(rng.integers(2, 6))))
-    src = str(rng.choice(["pool", "pool", "zero"]))
+    kind = str(rng.choice(["k_rollout", "k_rollout", "actor", "geo", "geo", "state"]))
     seed = int(rng.integers(1, 1 << 30))
     t0 = time.time()
-    scenarios.check_step_many(a.backend, src, n_envs=n_envs, capacity=cap, rate=rate, prefill=int(rng.choice([0, 150, 320])),
-                              chunks=chunks, trajectory_chunk=int(rng.integers(2, 30)), seed=seed)
-    print("many %2d: cap %3d rate %6.0f %s chunks %s x %2d envs seed %d OK %.0f s" % (k, cap, rate, src, chunks, n_envs, seed,
-                                                                                time.time() - t0), flush=True)
+    if kind in ("k_rollout", "actor"):
+        cap = int(rng.choice([64, 128, 128]))
+        lo, hi = RATES[(12, cap)]
+        rate = float(rng.uniform(lo * 0.3, hi * 1.15))          # (deferred spawns are deterministic: both paths agree on them too)
+        n_envs = int(rng.choice([3, 8, 17]))
+        chunks = tuple(int(x) for x in rng.integers(1, 90, size=int(rng.integers(2, 6))))
+        src = "actor" if kind == "actor" else str(rng.choice(["pool", "pool", "zero"]))
+        if src == "actor":
+            rate = min(rate, hi * 0.85)                         # (the pretrained policy keeps more vehicles in the box)
+        scenarios.check_step_many(a.backend, src, n_envs=n_envs, capacity=cap, rate=rate, prefill=int(rng.choice([0, 150, 320])),
+                                  chunks=chunks, trajectory_chunk=int(rng.integers(2, 30)), seed=seed)
+        what = "cap %3d rate %6.0f %s chunks %s x %2d envs" % (cap, rate, src, chunks, n_envs)
+    elif kind == "geo":                                         # k_rollout_geo == k_tick_geo ticks
+        ln = int(rng.choice([4, 8]))
+        cap = int(rng.choice([64, 128]))
+        lo, hi = RATES[(ln, cap)]
+        rate = float(rng.uniform(lo, hi * 0.9))
+        chunks = tuple(int(x) for x in rng.integers(1, 70, size=int(rng.integers(2, 5))))
+        quant = rng.choice([0.0, 0.5, 1.0])
+        scenarios.check_step_many_geo(a.backend, ln, n_envs=int(rng.choice([3, 8, 12])), capacity=cap, chunks=chunks, rate=rate,
+                                      trajectory_chunk=int(rng.integers(2, 20)), seed=seed, quantize=None if quant == 0.0 else float(quant))
+        what = "%d lanes cap %3d rate %6.0f chunks %s quant %s" % (ln, cap, rate, chunks, quant)
+    else:                                                       # training outputs of pve_step_many vs the oracle, every tick
+        import torch
+        dt = torch.float32 if rng.random() < 0.5 else torch.float64
+        calls = tuple(int(x) for x in rng.integers(5, 60, size=int(rng.integers(2, 5))))
+        rate = float(rng.uniform(400.0, 1200.0))
+        scenarios.check_step_many_state_rows(a.backend, n_envs=int(rng.choice([2, 5])), calls=calls, rate=rate, seed=seed,
+                                             obs_dtype=dt, chunk=int(rng.choice([0, 7, 16])), source=str(rng.choice(["pool", "zero"])))
+        what = "state rows %s calls %s rate %6.0f" % (str(dt).split(".")[-1], calls, rate)
+    print("many %2d [%s]: %s seed %d OK %.0f s" % (k, kind, what, seed, time.time() - t0), flush=True)
 if a.many:
-    print("%d pve_step_many runs: all bit-identical to single ticks" % a.many)
+    print("%d pve_step_many runs (12-lane pool / zero / actor, 4- / 8-lane, training outputs): all bit-identical to single ticks / equal to the oracle" % a.many)
