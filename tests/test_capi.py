@@ -90,3 +90,50 @@ def test_argument_validation_and_call_order():
     assert lib.pve_state_field(h, b"nope", C.byref(p), C.byref(eb)) == -1
     assert lib.pve_state_field(h, b"meta", C.byref(p), C.byref(eb)) == 0 and eb.value == 4
     assert lib.pve_destroy(h) == 0
+
+
+def test_actor_and_rollout_argument_validation():
+    """Round-3 entry points through the emulator build of the C ABI: pve_set_actor / NULL weights, and what pve_step_many
+    accepts for the training outputs."""
+    lib = emulator_lib()
+    arr = np.full((40, 12), np.inf)
+    arr[0, :] = 0.05
+    b = BatchedIntersections(2, 64, arr, device="cpu", outputs=("obs_post", "reward", "flags"), _lib=lib)
+    b.reset()
+    obs = torch.zeros(2, 64, 28, dtype=torch.float64)
+    act = torch.zeros(2, 64, dtype=torch.float64)
+    # no actor installed: NULL weights are refused (PVE_ERR_STATE), explicit weights install them
+    assert lib.pve_actor_forward(b._h, None, C.c_void_p(obs.data_ptr()), C.c_void_p(act.data_ptr())) == -3
+    assert b"pve_set_actor" in lib.pve_last_error()
+    assert lib.pve_set_actor(b._h, None) == -1
+    ro = _capi.PveRollout()
+    ro.n_ticks, ro.source = 3, _capi.SRC_ACTOR
+    ro.actor_obs, ro.actor_actions = obs.data_ptr(), act.data_ptr()
+    o = _capi.PveOutputs()
+    o.obs_post = obs.data_ptr()
+    assert lib.pve_step_many(b._h, C.byref(ro), C.byref(o)) == -3          # still no actor
+    w = torch.zeros(_capi.PVE_ACTOR_N_WEIGHTS, dtype=torch.float32)
+    assert lib.pve_actor_forward(b._h, C.c_void_p(w.data_ptr()), C.c_void_p(obs.data_ptr()), C.c_void_p(act.data_ptr())) == 0
+    assert lib.pve_actor_forward(b._h, None, C.c_void_p(obs.data_ptr()), C.c_void_p(act.data_ptr())) == 0     # installed now
+    assert lib.pve_step_many(b._h, C.byref(ro), C.byref(o)) == 0
+    # state_pre needs a trajectory roll-out (and obs_pre + the previous rows)
+    sp = torch.zeros(3, 2, 64, 7, 28, dtype=torch.float64)
+    op = torch.zeros(3, 2, 64, 28, dtype=torch.float64)
+    o.state_pre, o.obs_pre, o.obs_prev_post = sp.data_ptr(), op.data_ptr(), torch.zeros(2, 64, 28, dtype=torch.float64).data_ptr()
+    ro.source, ro.trajectory = _capi.SRC_ZERO, 0
+    assert lib.pve_step_many(b._h, C.byref(ro), C.byref(o)) == -1 and b"trajectory" in lib.pve_last_error()
+    # the 4- / 8-lane layouts keep obs_pre / state_pre for single ticks
+    arr8 = np.full((40, 8), np.inf)
+    g = BatchedIntersections(2, 64, arr8, device="cpu", outputs=("obs_post", "obs_pre", "flags"), lane_num=8, _lib=lib)
+    g.reset()
+    with pytest.raises(_capi.PveError):
+        g.step_many(2, source="zero")
+    g.step(None)
+    with pytest.raises(_capi.PveError):
+        BatchedIntersections(2, 64, arr8, device="cpu", outputs=("obs_post", "obs_pre"), lane_num=8, _lib=lib, obs_dtype=torch.float32)
+    # |am| outside the range the reciprocal division of the brake test covers
+    cfg = _capi.PveConfig()
+    lib.pve_default_config(C.byref(cfg))
+    cfg.am = -1e-9
+    h = C.c_void_p()
+    assert lib.pve_create(C.byref(cfg), 2, 64, 0, None, None, C.byref(h)) == -1 and b"|am|" in lib.pve_last_error()

@@ -325,6 +325,14 @@ def test_gpu_step_many_geo_equals_single_ticks(lane_num, cap, quant):
     assert m["overflow"] == 0 and m["ctl_steps"] > 5000
 
 
+def test_gpu_step_many_actor_in_dense_traffic():
+    """The closed loop inside k_rollout with more than 64 controlled vehicles per intersection (tiles 2 and 3: the second
+    wave re-reads the rows of its own dense threads) and with one-wave workgroups (capacity 64: one wave runs every tile):
+    bit-identical to actor launch + tick launch per tick."""
+    scenarios.check_step_many(BACKEND, "actor", n_envs=8, rate=1450.0, prefill=260, chunks=(30, 7, 45), trajectory_chunk=10, seed=19)
+    scenarios.check_step_many(BACKEND, "actor", n_envs=9, capacity=64, rate=420.0, prefill=200, chunks=(25, 3, 40), trajectory_chunk=9, seed=23)
+
+
 def test_gpu_step_many_pipelined():
     scenarios.check_step_many_pipelined(BACKEND, n_envs=37, n_sub=3, ticks=120)
 
