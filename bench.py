@@ -14,6 +14,12 @@ UN-TIMED prefill (>= 300 ticks, continued until the mean population moves < 1 % 
 says; then W un-timed warm-up steps, then EXACTLY K timed steps between barrier + synchronize pairs.  A "step" =
 one fused tick (all step() calls + scene_update() + delete_vehicle()) of every env of the rank.  Inputs (arrival
 streams, action pool) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+After the timed region (outside it) the line certifies itself: 8 of the envs this rank timed are replayed from reset by
+the CPU oracle and compared (final state + the last tick's outputs): "verified": true / false, exit code != 0 on false.
+`roofline` carries three HBM fractions (bytes the measured mode must move / SURVEY 8d's nominal 380 B / PMC counter bytes)
+and `binding`, the roofline that actually limits the kernel (vector-instruction issue, from the SQ counter passes of the
+same build); `retained_outputs` is the same workload with every tick's outputs kept (second timed region).
 """
 import argparse
 import hashlib
