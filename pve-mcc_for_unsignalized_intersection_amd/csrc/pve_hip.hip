@@ -287,8 +287,12 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
 // General-geometry tick (lane_num 4 / 8): same workgroup-per-intersection structure, phases of
 // pve_tick_geo.h (per-route sorted lists: PAIRS -> RANK -> WALK; the membership scan only as the overflow fallback).
+// Registers: 5 waves per SIMD (<= 96 VGPR) for CAP = 128 = 10 workgroups per CU.  CAP = 64 is one wave per workgroup and its
+// 9.4 KB of LDS admit 16 workgroups per CU = 4 waves per SIMD whatever the registers: 128 VGPR there (the 4-lane variant,
+// which carries both the far-conflict table and its replay fallback, spilled 35 registers at 96).  The 4-lane variant takes
+// 128 at CAP = 128 too (8 workgroups per CU instead of 10, no scratch; its fast path is k_rollout_geo anyway).
 template <int CAP, bool PROF = false, bool FIX4 = false>
-__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tick_geo(const GeoConst g_arg, const Params P_arg)
+__global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu((CAP == 64 || FIX4) ? 4 : 5, (CAP == 64 || FIX4) ? 4 : 5))) void k_tick_geo(const GeoConst g_arg, const Params P_arg)
 {
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const PVE_AS4 GeoConst &g = *(const PVE_AS4 GeoConst *)ka0_;

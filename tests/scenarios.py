@@ -622,7 +622,7 @@ def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chun
 
 
 def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=1100.0, calls=(40, 25, 60, 35), seed=81, n_pool=7,
-                               obs_dtype=torch.float64, chunk=0, source="pool"):
+                               obs_dtype=torch.float64, chunk=0, source="pool", min_ctl_per_tick=5):
     """Training outputs on the fast path: pve_step_many trajectory roll-outs with
     state_pre -- the 7 x 28 states with fresh / stale neighbour rows (ref :1325-1337) and the 7-action vectors (column 2,
     ref :290) -- compared with the oracle at EVERY tick of every env (ids, neighbours, rewards, row 0, full state), across
@@ -666,7 +666,7 @@ def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=1100.0, cal
                 assert close(rec["act7"], st[:, :, 2], tol), "7-action vector: tick %d env %d" % (t + k, e)
                 n_ctl_total += len(rec["ids"])
         t += n
-    assert n_ctl_total > 5 * total
+    assert n_ctl_total >= min_ctl_per_tick * total            # (the scenario did exercise controlled vehicles)
     assert b.metrics()["overflow"] == 0
     return n_ctl_total
 

@@ -82,7 +82,8 @@ for k in range(a.many):
         calls = tuple(int(x) for x in rng.integers(5, 60, size=int(rng.integers(2, 5))))
         rate = float(rng.uniform(400.0, 1200.0))
         scenarios.check_step_many_state_rows(a.backend, n_envs=int(rng.choice([2, 5])), calls=calls, rate=rate, seed=seed,
-                                             obs_dtype=dt, chunk=int(rng.choice([0, 7, 16])), source=str(rng.choice(["pool", "zero"])))
+                                             obs_dtype=dt, chunk=int(rng.choice([0, 7, 16])), source=str(rng.choice(["pool", "zero"])),
+                                             min_ctl_per_tick=0)
         what = "state rows %s calls %s rate %6.0f" % (str(dt).split(".")[-1], calls, rate)
     print("many %2d [%s]: %s seed %d OK %.0f s" % (k, kind, what, seed, time.time() - t0), flush=True)
 if a.many:
