@@ -393,9 +393,18 @@ def main(argv=None, env_factory=None):
     ring = [env.alloc_trajectory(traj_len) for _ in range(2)] if traj_on else None
     ring_pos = [0, None, 0]                              # next buffer, (buffer, ticks) of the last call
 
+    prepared = {}
+
     def run_ticks(n):
         """n ticks of every env of this rank, enqueued (not synchronised)."""
         if n <= 0:
+            return
+        if mode == "rollout" and not traj_on and not args.actor and hasattr(env, "prepare_step_many"):
+            # prepared calls: the host side of the timed region is one ctypes call per sub-batch
+            if n not in prepared:
+                prepared[n] = env.prepare_step_many(n, chunk=args.chunk)
+            prepared[n]()
+            tick[0] += n
             return
         if traj_on:
             for c0 in range(0, n, traj_len):
@@ -436,6 +445,8 @@ def main(argv=None, env_factory=None):
     steady = prefill >= PREFILL_MIN and drift is not None and drift < 0.01
 
     run_ticks(W)
+    if mode == "rollout" and not traj_on and not args.actor and hasattr(env, "prepare_step_many") and K > 0 and K not in prepared:
+        prepared[K] = env.prepare_step_many(K, chunk=args.chunk)      # (built outside the timed region)
     sync()
     if world > 1:
         dist.barrier()

@@ -374,6 +374,38 @@ class BatchedIntersections:
                     tns.copy_(traj[n][n_ticks - 1])
         return traj
 
+    def prepare_step_many(self, n_ticks, source=None, chunk=0):
+        """A prepared pve_step_many call (trajectory=False): everything the call needs is built once; the returned callable
+        re-issues it (only the position in the action pool advances) at the cost of one ctypes call -- for loops whose host
+        side is measured in microseconds (RL inner loops, bench.py's timed region)."""
+        n_ticks = int(n_ticks)
+        if source is None:
+            source = "pool" if getattr(self, "_pool", None) is not None else "zero"
+        if source == "actor" or "state_pre" in self.out:
+            raise PveError("prepare_step_many: pool / zero sources without state_pre (use step_many)")
+        ro = PveRollout()
+        ro.n_ticks, ro.trajectory, ro.chunk_ticks = n_ticks, 0, int(chunk)
+        if source == "pool":
+            if getattr(self, "_pool", None) is None:
+                raise PveError("prepare_step_many(source='pool'): call set_action_pool first")
+            ro.source, ro.pool, ro.n_pool = _capi.SRC_POOL, self._pool.data_ptr(), self._pool.shape[0]
+        elif source == "zero":
+            ro.source = _capi.SRC_ZERO
+        else:
+            raise PveError("unknown action source %r" % (source,))
+        self._bind_stream()
+        o = self._outputs_struct(flip_obs=False)
+        fn, h, pro, po, n_pool = self.lib.pve_step_many, self._h, C.byref(ro), C.byref(o), max(1, int(ro.n_pool))
+
+        def call():
+            ro.pool_tick0 = self.ticks % n_pool
+            rc = fn(h, pro, po)
+            if rc != 0:
+                check(self.lib, rc, "pve_step_many")
+            self.ticks += n_ticks
+        call._keep = (ro, o)
+        return call
+
     def scene_update(self, actions=None):
         """Split protocol, part 1: all step() calls + scene_update(); Done vehicles stay in place."""
         a = self._zero_actions if actions is None else actions
@@ -526,6 +558,15 @@ class PipelinedIntersections:
         tr = trajectory if isinstance(trajectory, (list, tuple)) else [trajectory] * self.n_sub
         return [sub.step_many(n_ticks, actor=actor, source=source, trajectory=tr[k], chunk=chunk, update_views=update_views)
                 for k, sub in enumerate(self.subs)]
+
+    def prepare_step_many(self, n_ticks, source=None, chunk=0):
+        """One prepared call per sub-batch (BatchedIntersections.prepare_step_many); the returned callable issues them all."""
+        calls = [sub.prepare_step_many(n_ticks, source=source, chunk=chunk) for sub in self.subs]
+
+        def call():
+            for c in calls:
+                c()
+        return call
 
     def synchronize(self):
         for sub in self.subs:

@@ -82,3 +82,29 @@ def test_emulated_step_many_emits_training_states():
     """state_pre / obs_pre / 7-action vectors over pve_step_many trajectories, every tick vs the oracle (f64 and f32 rows)."""
     scenarios.check_step_many_state_rows(BACKEND, n_envs=2, calls=(30, 12, 25), chunk=0)
     scenarios.check_step_many_state_rows(BACKEND, n_envs=2, calls=(20, 15), chunk=7, obs_dtype=torch.float32, seed=83)
+
+
+def test_emulated_prepared_step_many_equals_step_many():
+    """prepare_step_many (one ctypes call per re-issue) == step_many, incl. the position in the action pool and pipelined
+    sub-batches."""
+    import numpy as np
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    from pve_mcc_amd.batched import PipelinedIntersections
+    from tests.hip_adapter import emulator_lib
+    arr = synthetic_arrivals(5, rate=900.0, horizon_s=40.0, seed=4)
+    outs = ("obs_post", "reward", "flags", "env_out", "new_slot", "nbr")
+    a = make_batch(arr, 5, 128, BACKEND, outputs=outs)
+    b = PipelinedIntersections(5, 128, arr, n_sub=2, outputs=outs, device="cpu", _lib=emulator_lib())
+    pool = torch.as_tensor(np.random.default_rng(1).uniform(-2, 2, size=(5, 5, 128)))
+    a.reset(); b.reset()
+    a.set_action_pool(pool); b.set_action_pool(pool)
+    f = b.prepare_step_many(7, chunk=3)
+    for _ in range(6):
+        a.step_many(7, chunk=3)
+        f()
+    for k in scenarios.STATE_F + scenarios.STATE_I:
+        x = a.state_field(k).numpy()
+        y = np.concatenate([sub.state_field(k).numpy() for sub in b.subs], 0)
+        live = a.state_field("meta").numpy() != 0
+        assert np.array_equal(x[live], y[live]), k
+    assert a.ticks == 42 and all(sub.ticks == 42 for sub in b.subs)
