@@ -68,7 +68,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(arr, pool, cap, lane_num=12, choice=None):
+def cpu_baseline(arr, pool, cap, lane_num=12, choice=None, id_sin=False):
     """The CPU oracle (oracle/pve_oracle.c, a plain-C port of the reference algorithm) timed on this host's cores on a
     BOUNDED sample of the same workload: the first n envs of the same arrival tensor with the same action pool, 300
     warm-up ticks (steady population) + 200 timed ticks each, independent of --steps / --warmup.  Two figures: every
@@ -88,7 +88,7 @@ def cpu_baseline(arr, pool, cap, lane_num=12, choice=None):
 
         def worker(k, nt, t0):
             for i in range(k, len(envs), n_threads):
-                res[i] = envs[i][1].run_pool(nt, pool[:, envs[i][0], :], t0)
+                res[i] = envs[i][1].run(nt, 1, 1.0, t0) if id_sin else envs[i][1].run_pool(nt, pool[:, envs[i][0], :], t0)
 
         def run(nt, t0):
             ths = [threading.Thread(target=worker, args=(k, nt, t0)) for k in range(n_threads)]
@@ -165,7 +165,7 @@ def binding_profile(mode, ticks_per_launch, cap, other):
     return t, os.path.relpath(files[-1], ROOT)
 
 
-def verify_against_oracle(locate, last_outputs, arr, pool_np, total_ticks, lane_num, choice, n_sample=VERIFY_ENVS):
+def verify_against_oracle(locate, last_outputs, arr, pool_np, total_ticks, lane_num, choice, n_sample=VERIFY_ENVS, table_np=None):
     """Outside the timed region: `n_sample` of the envs this rank just timed are replayed from reset by the CPU oracle
     (the checker; oracle/README.md) on the same arrival stream and the same action pool for the same number of ticks;
     the final persistent state (ints exact, floats 1e-9) and the last tick's outputs (controlled set, rewards, collision /
@@ -187,11 +187,19 @@ def verify_against_oracle(locate, last_outputs, arr, pool_np, total_ticks, lane_
             else:
                 from oracle.oracle_geo import OracleGeoEnv
                 o = OracleGeoEnv(arr[e], lane_num, choice=None if choice is None else choice[e])
-            if total_ticks > 1:
-                o.run_pool(total_ticks - 1, pool_np[:, e, :], 0)
-            vi = o.vehicles()[0]
-            n = vi.shape[0]
-            acts = np.where(vi[:, 5] != 0, pool_np[(total_ticks - 1) % N_POOL, e, :n], 0.0)
+            if table_np is not None:                           # actions by (tick, vehicle id): the same table the device gathers from
+                for tk in range(total_ticks - 1):
+                    vi = o.vehicles()[0]
+                    o.tick(np.where(vi[:, 5] != 0, table_np[tk % table_np.shape[0], np.minimum(vi[:, 2], table_np.shape[1] - 1)], 0.0))
+                vi = o.vehicles()[0]
+                n = vi.shape[0]
+                acts = np.where(vi[:, 5] != 0, table_np[(total_ticks - 1) % table_np.shape[0], np.minimum(vi[:, 2], table_np.shape[1] - 1)], 0.0)
+            else:
+                if total_ticks > 1:
+                    o.run_pool(total_ticks - 1, pool_np[:, e, :], 0)
+                vi = o.vehicles()[0]
+                n = vi.shape[0]
+                acts = np.where(vi[:, 5] != 0, pool_np[(total_ticks - 1) % N_POOL, e, :n], 0.0)
             rec = o.tick(acts)
             slot_of = {(int(l), int(j)): k for k, (l, j) in enumerate(vi[:, :2])}
             batch, le = locate(e)
@@ -287,6 +295,11 @@ def main(argv=None, env_factory=None):
                     help="rollout mode: 1 = every tick's outputs are RETAINED (trajectory roll-outs into a ring of two "
                          "chunk buffers per sub-batch, what a trainer consumes, main.py:397-441); 0 = each tick overwrites "
                          "the previous tick's outputs")
+    ap.add_argument("--tape", default="pool", choices=("id-sin", "pool"),
+                    help="id-sin: BASELINE.md 3's tape a = float32(sin(0.37 id + 0.05 tick)) by VEHICLE id, gathered on the device "
+                         "from a [tick][id] table (pve_step_many(PVE_SRC_TABLE), lane_num 12, rollout mode); pool: 16 slot-indexed "
+                         "sin entries (any layout / mode; what rounds 1-2 measured, the default; the default line also times K ticks "
+                         "of the id-sin tape behind the headline region: `tape_id_sin`)")
     ap.add_argument("--no-companion", action="store_true",
                     help="skip the second timed region (per-tick outputs retained) behind the headline roll-out")
     ap.add_argument("--no-verify", action="store_true",
@@ -350,6 +363,15 @@ def main(argv=None, env_factory=None):
     arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=horizon, seed=20250213 + rank * n_envs, lane_num=lane_num)
     choice = synthetic_intentions(n_envs, arr.shape[1], seed=20250213 + rank * n_envs) if lane_num == 8 else None
     pool_np = action_pool(n_envs, cap, seed=99 + rank)
+    # BASELINE.md 3's tape, by vehicle id: one row per tick of the whole run (incl. the companion region), one column per id a
+    # lane can hand out in that time (headways >= 1 s)
+    id_sin = (args.tape == "id-sin") and lane_num == 12 and not args.actor and not emu
+    table_np = None
+    if id_sin:
+        rows_t = prefill_cap + W + 2 * K + 128
+        cols_t = int(12 * (rows_t * 0.1 + 4)) + 64
+        table_np = np.sin(0.37 * np.arange(cols_t, dtype=np.float64)[None, :] + 0.05 * np.arange(rows_t, dtype=np.float64)[:, None])
+        table_np = table_np.astype(np.float32).astype(np.float64)
     outputs = tuple(x for x in args.outputs.split(",") if x)
     n_sub = max(1, min(args.pipeline, n_envs))
     obs_dtype = torch.float32 if args.obs_f32 else torch.float64
@@ -369,6 +391,9 @@ def main(argv=None, env_factory=None):
     # launches of 25 ticks per sub-batch keep the chip full (30.0 vs 32.9 us); a short timed region (the driver's --steps
     # 20) takes launches of 5 ticks so that the two sub-batches still interleave (35.3 vs 36.6 us incl. fill and drain)
     mode = args.mode or ("rollout" if not emu else "step")
+    if id_sin and mode != "rollout":
+        id_sin, table_np = False, None                   # (one launch per tick: the slot-indexed pool)
+    src = "table" if id_sin else None
     if mode == "rollout" and args.chunk == 0 and cap == 128:
         args.chunk = 25 if K >= 100 else 5
     if mode == "rollout" and not hasattr(env, "step_many"):
@@ -385,7 +410,10 @@ def main(argv=None, env_factory=None):
         z = np.load(wpath)
         env.set_actor({k: z[k] for k in z.files})       # the reference's pretrained actor (model_data/baseline/66.cptk)
     if mode == "rollout" and not args.actor:
-        env.set_action_pool(pool)
+        if id_sin:
+            env.set_action_table(torch.as_tensor(table_np))
+        else:
+            env.set_action_pool(pool)
     tick = [0]
     step_kw = {"wait": False} if sub_streams else {}     # the pool upload was synchronised above
     # retained per-tick outputs: a ring of two chunk buffers per sub-batch (the consumer reads one while the next fills)
@@ -402,18 +430,18 @@ def main(argv=None, env_factory=None):
         if mode == "rollout" and not traj_on and not args.actor and hasattr(env, "prepare_step_many"):
             # prepared calls: the host side of the timed region is one ctypes call per sub-batch
             if n not in prepared:
-                prepared[n] = env.prepare_step_many(n, chunk=args.chunk)
+                prepared[n] = env.prepare_step_many(n, source=src, chunk=args.chunk)
             prepared[n]()
             tick[0] += n
             return
         if traj_on:
             for c0 in range(0, n, traj_len):
                 m = min(traj_len, n - c0)
-                env.step_many(m, trajectory=ring[ring_pos[0]], update_views=False)
+                env.step_many(m, source=src, trajectory=ring[ring_pos[0]], update_views=False)
                 ring_pos[1], ring_pos[2] = ring_pos[0], m
                 ring_pos[0] ^= 1
         elif mode == "rollout":
-            env.step_many(n, actor=args.actor, chunk=args.chunk)
+            env.step_many(n, actor=args.actor, source=src, chunk=args.chunk)
         elif args.actor:
             for _ in range(n):
                 env.step_with_actor()
@@ -446,7 +474,7 @@ def main(argv=None, env_factory=None):
 
     run_ticks(W)
     if mode == "rollout" and not traj_on and not args.actor and hasattr(env, "prepare_step_many") and K > 0 and K not in prepared:
-        prepared[K] = env.prepare_step_many(K, chunk=args.chunk)      # (built outside the timed region)
+        prepared[K] = env.prepare_step_many(K, source=src, chunk=args.chunk)      # (built outside the timed region)
     sync()
     if world > 1:
         dist.barrier()
@@ -510,7 +538,7 @@ def main(argv=None, env_factory=None):
             return {n: b.out[n][le].cpu().numpy() for n in ("flags", "reward", "env_out")}
         if all(n in outputs for n in ("flags", "reward", "env_out")):
             sync()
-            verify = verify_against_oracle(locate, last_outputs, arr, pool_np, tick[0], lane_num, choice)
+            verify = verify_against_oracle(locate, last_outputs, arr, pool_np, tick[0], lane_num, choice, table_np=table_np)
         else:
             verify = dict(verified=None, reason="needs the flags, reward and env_out outputs")
     # ---- companion figure: the headline roll-out overwrites each tick's outputs with the next tick's; the same K
@@ -522,7 +550,7 @@ def main(argv=None, env_factory=None):
         ring2 = [env.alloc_trajectory(tl) for _ in range(2)]
         def traj_ticks(n):
             for i, c0 in enumerate(range(0, n, tl)):
-                env.step_many(min(tl, n - c0), trajectory=ring2[i & 1], update_views=False)
+                env.step_many(min(tl, n - c0), source=src, trajectory=ring2[i & 1], update_views=False)
         traj_ticks(2 * tl)
         sync()
         tc0 = time.perf_counter()
@@ -534,6 +562,26 @@ def main(argv=None, env_factory=None):
                              "ticks into a ring of two buffers per sub-batch)" % tl,
                      "ms_per_step": tc / K * 1e3, "value": float(cap) * n_envs * K / tc, "unit": "env-steps/s", "steps": K}
         del ring2
+    # ---- BASELINE.md 3's own tape beside the slot-indexed pool: K more ticks with a = float32(sin(0.37 id +
+    # 0.05 tick)) by vehicle id, gathered on the device (PVE_SRC_TABLE); `--tape id-sin` makes it the headline (and verifies it)
+    tape_id_sin = None
+    if mode == "rollout" and not id_sin and not traj_on and not args.actor and not emu and world == 1 and lane_num == 12 \
+            and not args.no_companion:
+        rows_t = tick[0] + 2 * K + 64
+        cols_t = int(12 * (rows_t * 0.1 + 4)) + 64
+        tab = np.sin(0.37 * np.arange(cols_t, dtype=np.float64)[None, :] + 0.05 * np.arange(rows_t, dtype=np.float64)[:, None])
+        env.set_action_table(torch.as_tensor(tab.astype(np.float32).astype(np.float64)))
+        call = env.prepare_step_many(K, source="table", chunk=args.chunk)
+        warm = env.prepare_step_many(min(K, 50), source="table", chunk=args.chunk)
+        warm(); sync()
+        ti0 = time.perf_counter()
+        call()
+        sync()
+        ti = time.perf_counter() - ti0
+        tick[0] += K + min(K, 50)
+        tape_id_sin = {"what": "the same envs continued for %d ticks under BASELINE.md 3's tape a = float32(sin(0.37 id + 0.05 tick)) by "
+                               "vehicle id (pve_step_many(PVE_SRC_TABLE)); not part of the verified region" % K,
+                       "ms_per_step": ti / K * 1e3, "value": float(cap) * n_envs * K / ti, "unit": "env-steps/s", "steps": K}
     ok_flag = 0.0 if verify["verified"] is False else 1.0
     if world > 1:
         tv = torch.tensor([ok_flag], dtype=torch.float64, device=dev)
@@ -584,7 +632,8 @@ def main(argv=None, env_factory=None):
                                      "shader clock) / measured time per tick: the share of the tick during which the vector "
                                      "pipes HAVE to be busy; lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS; "
                                      "wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
-        pool_desc = ("sin action pool indexed by SLOT, pool[k][env][slot] = float32(sin(phase_env + 0.37 slot + 0.35 k)), 16 "
+        pool_desc = ("sin action tape by VEHICLE id, a = float32(sin(0.37 id + 0.05 tick)) (BASELINE.md 3), gathered on the device "
+                     "from a [tick][id] table (pve_step_many(PVE_SRC_TABLE))") if id_sin else ("sin action pool indexed by SLOT, pool[k][env][slot] = float32(sin(phase_env + 0.37 slot + 0.35 k)), 16 "
                      "entries (BASELINE.md 3 indexes its sin tape by vehicle id: sin(0.37 id + 0.05 tick); a slot-indexed "
                      "tape needs no feedback from the device and costs the same per tick)")
         line = {
@@ -593,7 +642,7 @@ def main(argv=None, env_factory=None):
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "synthetic (injected test environment: timings meaningless)",
             "verified": verify["verified"], "verification": verify,
-            "retained_outputs": companion,
+            "retained_outputs": companion, "tape_id_sin": tape_id_sin,
             "config": {"workload": "%d parallel %d-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
@@ -647,7 +696,7 @@ def main(argv=None, env_factory=None):
             line["roofline"]["note_above_copy_peak"] = ("algorithmic bytes exceed what a copy kernel moves in the same time: "
                                                         "empty slots are counted but not moved")
         if not args.no_cpu_baseline and not args.actor and world == 1:      # reported at N=1 only
-            line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, lane_num, choice)
+            line["cpu_baseline"] = cpu_baseline(arr, pool_np, cap, lane_num, choice, id_sin=id_sin)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()                # every rank leaves together (rank 0 may still be timing the CPU baseline)

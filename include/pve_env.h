@@ -210,6 +210,10 @@ int pve_step_all_actor(pve_handle h, const float *weights, const void *obs_in, d
  * pve_step_all() with
  *   PVE_SRC_ZERO   actions = 0 (the zero policy of SURVEY.md 8d)
  *   PVE_SRC_POOL   actions = pool[(pool_tick0 + k) % n_pool], pool = DEVICE float64 [n_pool][n_envs][capacity]
+ *   PVE_SRC_TABLE  actions[slot] = table[(pool_tick0 + k) % n_pool][min(id of the vehicle in the slot, table_ids - 1)], table =
+ *                  DEVICE float64 [n_pool][table_ids] passed in `pool`: a policy that is a function of (tick, vehicle id), e.g.
+ *                  the sin tape of SURVEY.md 8c-ii / BASELINE.md 3, `a = sin(0.37 id + 0.05 tick)`; the vehicle's own thread
+ *                  gathers its action (lane_num 12, resident kernel only)
  *   PVE_SRC_ACTOR  actions = pve_actor_forward(actor_weights, observation rows the previous tick stored), i.e. the closed
  *                  loop of main.py:398-441 with the actor of model_agent_maddpg.py:23-49; the first tick reads
  *                  `actor_obs` (zeros after pve_reset, ref :380), later ticks the rows written through out->obs_post,
@@ -225,7 +229,7 @@ int pve_step_all_actor(pve_handle h, const float *weights, const void *obs_in, d
  * requested in either form; state_pre needs trajectory = 1 (tick k reads the stale neighbour rows from block k - 1 of
  * obs_post, tick 0 from out->obs_prev_post = the rows stored before this call), i.e. a MADDPG trainer gets `re_state` and the
  * 7-action vectors (column 2 of the 7 rows, ref :290) of every tick of the roll-out without leaving the resident kernel. */
-enum { PVE_SRC_ZERO = 0, PVE_SRC_POOL = 1, PVE_SRC_ACTOR = 2 };
+enum { PVE_SRC_ZERO = 0, PVE_SRC_POOL = 1, PVE_SRC_ACTOR = 2, PVE_SRC_TABLE = 3 };
 typedef struct pve_rollout {
     int32_t n_ticks;
     int32_t source;               /* PVE_SRC_* */
@@ -236,6 +240,7 @@ typedef struct pve_rollout {
     double *actor_actions;        /* PVE_SRC_ACTOR: DEVICE scratch float64 [n_envs][capacity] (per-tick launches only: the resident
                                      kernel keeps the actions on the chip and does not touch it) */
     int32_t trajectory;
+    int32_t table_ids;            /* PVE_SRC_TABLE: columns of the table (vehicle ids beyond it use the last column) */
     int32_t chunk_ticks;          /* 0: all n_ticks in one launch; > 0: launches of at most chunk_ticks ticks each (same results).
                                      Every workgroup of a launch runs its intersection for all the ticks of the launch, so a
                                      launch lasts as long as its slowest intersection: with several handles stepped on their

@@ -291,6 +291,22 @@ class BatchedIntersections:
             raise PveError("action pool must be [n_pool, %d, %d]" % (self.n_envs, self.capacity))
         self._pool = p
 
+    def set_action_table(self, table):
+        """A policy that is a function of (tick, vehicle id), resident on the device: float64 [n_rows, n_ids]; at tick
+        number k since reset() the vehicle with id v gets table[k % n_rows, min(v, n_ids - 1)] (controlled vehicles; the
+        others 0, main.py:401) -- e.g. the sin tape of BASELINE.md 3, float32(sin(0.37 id + 0.05 tick)).
+        step_many(source="table") gathers it inside the resident kernel; actions_from_table() gives the same per tick."""
+        t = torch.as_tensor(table, dtype=torch.float64).contiguous().to(self.device)
+        if t.dim() != 2:
+            raise PveError("action table must be [n_rows, n_ids]")
+        self._table = t
+
+    def actions_from_table(self):
+        """[n_envs, capacity] actions of the CURRENT tick from the table (what step_many(source="table") applies next)."""
+        tab = self._table
+        ids = self.state_field("id").long().clamp(0, tab.shape[1] - 1)
+        return tab[self.ticks % tab.shape[0]][ids].contiguous()
+
     _TRAJ_SHAPES = dict(reward=(), flags=(), lanej=(), new_slot=(), nbr=(6,))
 
     def alloc_trajectory(self, n_ticks):
@@ -338,6 +354,11 @@ class BatchedIntersections:
                 raise PveError("step_many(source='actor') reads the handle's observation view: update_views must stay True")
         elif source == "zero":
             ro.source = _capi.SRC_ZERO
+        elif source == "table":
+            if getattr(self, "_table", None) is None:
+                raise PveError("step_many(source='table'): call set_action_table first")
+            ro.source, ro.pool, ro.n_pool = _capi.SRC_TABLE, self._table.data_ptr(), self._table.shape[0]
+            ro.table_ids, ro.pool_tick0 = self._table.shape[1], self.ticks % self._table.shape[0]
         else:
             raise PveError("unknown action source %r" % (source,))
         if "state_pre" in self.out and not trajectory:
@@ -391,6 +412,11 @@ class BatchedIntersections:
             ro.source, ro.pool, ro.n_pool = _capi.SRC_POOL, self._pool.data_ptr(), self._pool.shape[0]
         elif source == "zero":
             ro.source = _capi.SRC_ZERO
+        elif source == "table":
+            if getattr(self, "_table", None) is None:
+                raise PveError("prepare_step_many(source='table'): call set_action_table first")
+            ro.source, ro.pool, ro.n_pool = _capi.SRC_TABLE, self._table.data_ptr(), self._table.shape[0]
+            ro.table_ids = self._table.shape[1]
         else:
             raise PveError("unknown action source %r" % (source,))
         self._bind_stream()
@@ -538,6 +564,13 @@ class PipelinedIntersections:
 
     def step_with_actor(self):
         return [sub.step_with_actor() for sub in self.subs]
+
+    def set_action_table(self, table):
+        for k, sub in enumerate(self.subs):
+            with self._on(k):
+                sub.set_action_table(table)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     def set_action_pool(self, pool):
         pool = torch.as_tensor(pool, dtype=torch.float64)

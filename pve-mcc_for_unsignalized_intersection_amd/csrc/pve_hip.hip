@@ -140,7 +140,10 @@ __device__ __forceinline__ void rollout_actor(const unsigned char *packed, const
 // barrier; still ticks are staged like the others.  The first tick of a launch takes its rows from HBM.
 // TRAIN: the training outputs (obs_pre, state_pre: SURVEY 8 f3) are written per tick; a variant of its own so that the
 // default kernel keeps its register allocation (123 VGPR, no scratch).
-template <int CAP, int WPE, bool PROF = false, bool ACT = false, bool TRAIN = false>
+// IDT: PVE_SRC_TABLE -- the action is a function of (tick, vehicle id) given as a table: every vehicle's own thread gathers
+// its next action under FX (the id travels with the vehicle), the lanes that spawn gather theirs right behind FIN (in flight
+// under barrier A and STAGE), and the values are parked at the vehicles' NEW slots (act_next) where RELOAD looks for them.
+template <int CAP, int WPE, bool PROF = false, bool ACT = false, bool TRAIN = false, bool IDT = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout(const Const c_arg, const Params P_arg,
                                                                                                const RolloutArgs R_arg)
 {
@@ -195,7 +198,12 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         }
         T::ph_load(c, P, env0_, t0_, sh, r);            // P.actions = the first tick's actions
         if constexpr (ACT) r.act = sh.act_next[t0_];    // (uncontrolled slots: whatever is there, masked in S1)
+        if constexpr (IDT) {                            // the first tick's action of the vehicle in this slot: table[row][id]
+            const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
+            r.act = r.alive ? R.pool[(size_t)pool_idx * (size_t)R.table_ids + idc] : 0.0;
+        }
     }
+    double sp_act = 0;                                  // IDT: the action of the vehicle this lane spawns
     for (int k = 0; k < n_ticks; k++) {
         // The loop body is one tick of the single-tick kernel.  Without the two opaque copies below the compiler's
         // loop-invariant code motion hoists every kernel-argument load and every per-thread address out of the loop
@@ -235,7 +243,10 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         PVE_PHASE_MARK(6)
         int nx = -1;
         if (k + 1 < n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
-        T::ph_prefetch_action(P, R, env, t, nx, r);
+        if constexpr (IDT) {
+            const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
+            r.act_nx = (nx >= 0 && r.alive) ? R.pool[(size_t)nx * (size_t)R.table_ids + idc] : 0.0;
+        } else T::ph_prefetch_action(P, R, env, t, nx, r);
         T::ph_effects(c, t, sh, r);
         lds_barrier();
         PVE_PHASE_MARK(7)
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         T::ph_lock2(t, sh, r);
         lds_barrier();                                // (also what orders the previous tick's output stores before this tick's)
         PVE_PHASE_MARK(8)
-        if constexpr (!ACT) T::ph_park_action(t, sh, r);
+        if constexpr (!ACT && !IDT) T::ph_park_action(t, sh, r);
         const Outputs O = T::template tick_outputs<TRAIN>(P, R, k);
         if constexpr (ACT) {
             adst = -1;
@@ -253,6 +264,15 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             adsts[t] = (uint8_t)(adst < 0 ? 255 : adst);  // (dense thread t; threads >= n_ctl: 255)
         } else T::template ph_final<true>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
         PVE_PHASE_MARK(9)
+        if constexpr (IDT) {
+            if (fc.new_slot >= 0) sh.act_next[fc.new_slot] = r.act_nx;   // (act_next = xy32: dead since REWARD)
+            // the vehicle this lane spawns (id known since FIN): its first action, in flight under barrier A and STAGE
+            sp_act = 0;
+            if (fc.sp_slot >= 0 && nx >= 0) {
+                const int idc = fc.sp_id < R.table_ids ? fc.sp_id : R.table_ids - 1;
+                sp_act = R.pool[(size_t)nx * (size_t)R.table_ids + idc];
+            }
+        }
         if (fc.still) {                               // (uniform) nobody moves: the registers carry over
             T::ph_stage_header(t, sh, fc);
             T::ph_carry_over(t, sh, r, fc);
@@ -260,6 +280,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             lds_barrier();                            // A: nobody reads the tick's work arrays any more
             if (TRAIN && O.state_pre) T::ph_state(P, O, env, t, sh, r);   // (uniform; barrier A also orders the obs_pre rows of this tick)
             T::ph_stage(c, t, sh, r, fc);
+            if constexpr (IDT) { if (fc.sp_slot >= 0) sh.act_next[fc.sp_slot] = sp_act; }
             if constexpr (ACT) {
                 // next tick's actions: the vehicle lane t spawns gets the action of an all-zero row (ref :380, :420), the
                 // controlled vehicles that stay get actor(row)
@@ -584,9 +605,14 @@ struct Backend {
             Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
+        if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
         static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
         const bool train = P.out.obs_pre || P.out.state_pre;
-        if (R.source == 2) {
+        if (R.source == 3) {                                                  // PVE_SRC_TABLE
+            if (train || P.phase_cycles) return 1;
+            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
+            else hipLaunchKernelGGL((k_rollout<128, 4, false, false, false, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
+        } else if (R.source == 2) {
             if (train) {
                 if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
                 else hipLaunchKernelGGL((k_rollout<128, 4, false, true, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);

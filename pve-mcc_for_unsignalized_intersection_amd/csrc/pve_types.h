@@ -145,6 +145,7 @@ struct RolloutArgs {
     const void *actor_obs;       // PVE_SRC_ACTOR: the observation rows the first tick's actor reads
     const void *prev_rows;       // state_pre: the rows the tick before this launch stored (stale neighbour rows of its first tick)
     int32_t n_ticks, source, n_pool, pool_tick0, trajectory;
+    int32_t table_ids;           // PVE_SRC_TABLE: `pool` is [n_pool][table_ids], indexed by (tick, vehicle id)
     int32_t exact_f32;           // PVE_CFG_ACTOR_F32: the resident kernel has no exact-float32 actor (per-tick launches instead)
 };
 

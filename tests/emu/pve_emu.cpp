@@ -58,7 +58,11 @@ template <int CAP> static void emu_rollout(const Const &c, const Params &P, cons
         Shared<CAP> &sh = *shp;
         memset(&sh, 0, sizeof(sh));
         int pool_idx = R.pool_tick0;
+        const bool idt = R.source == 3;                      // PVE_SRC_TABLE: actions by (tick, vehicle id)
+        auto tab = [&](int row, int id) { return R.pool[(size_t)row * (size_t)R.table_ids + (id < 0 ? 0 : (id < R.table_ids ? id : R.table_ids - 1))]; };
+        std::vector<double> sp_act(CAP, 0.0);
         for (int t = 0; t < CAP; t++) T::ph_load(c, P, env, t, sh, regs[t]);
+        if (idt) for (int t = 0; t < CAP; t++) regs[t].act = regs[t].alive ? tab(pool_idx, regs[t].id) : 0.0;
         for (int k = 0; k < R.n_ticks; k++) {
             for (int w = 0; w < CAP / 64; w++)      // the emulator's vote() ORs bits: start every tick from empty masks
                 sh.m_alive[w] = sh.m_ctl[w] = sh.m_del[w] = sh.m_fin[w] = sh.m_ctlnow[w] = sh.m_coll[w] = sh.m_lead[w] = sh.m_spawn[w] = 0;
@@ -76,21 +80,31 @@ template <int CAP> static void emu_rollout(const Const &c, const Params &P, cons
             for (int t = 0; t < CAP; t++) T::ph_reward(c, t, sh, regs[t]);
             int nx = -1;
             if (k + 1 < R.n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
-            for (int t = 0; t < CAP; t++) T::ph_prefetch_action(P, R, env, t, nx, regs[t]);
+            if (idt) for (int t = 0; t < CAP; t++) regs[t].act_nx = (nx >= 0 && regs[t].alive) ? tab(nx, regs[t].id) : 0.0;
+            else for (int t = 0; t < CAP; t++) T::ph_prefetch_action(P, R, env, t, nx, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_effects(c, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_prefetch_arrival(P, env, t, sh, regs[t], NL);
+            if (idt) {                               // first action of the vehicles spawned at the end of this tick
+                const unsigned want = (unsigned)(sh.m_spawn[0] & 0xFFFull);
+                unsigned sp = 0; int room = CAP - sh.hd.n_alive;
+                for (int l = 0; l < NL; l++) if ((want >> l) & 1) { if (room > 0) { sp |= 1u << l; room--; } }
+                for (int t = 0; t < NL; t++)
+                    sp_act[t] = (((sp >> t) & 1) && nx >= 0) ? tab(nx, sh.hd.id_seq + __builtin_popcount(sp & ((1u << t) - 1u))) : 0.0;
+            }
             for (int t = 0; t < CAP; t++) T::ph_lock(c, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t]);
-            for (int t = 0; t < CAP; t++) T::ph_park_action(t, sh, regs[t]);
+            if (!idt) for (int t = 0; t < CAP; t++) T::ph_park_action(t, sh, regs[t]);
             const Outputs O = T::tick_outputs(P, R, k);
             for (int t = 0; t < CAP; t++)
                 T::template ph_final<true>(c, P, O, env, t, sh, regs[t], fcs[t], k + 1 == R.n_ticks || O.state_pre != nullptr);
+            if (idt) for (int t = 0; t < CAP; t++) if (fcs[t].new_slot >= 0) sh.act_next[fcs[t].new_slot] = regs[t].act_nx;
             if (fcs[0].still) {                       // (uniform) nobody moves: the registers carry over
                 for (int t = 0; t < CAP; t++) T::ph_stage_header(t, sh, fcs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_carry_over(t, sh, regs[t], fcs[t]);
             } else {
                 if (O.state_pre) for (int t = 0; t < CAP; t++) T::ph_state(P, O, env, t, sh, regs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_stage(c, t, sh, regs[t], fcs[t]);
+                if (idt) for (int t = 0; t < NL; t++) if (fcs[t].sp_slot >= 0) sh.act_next[fcs[t].sp_slot] = sp_act[t];
                 if (k + 1 < R.n_ticks) for (int t = 0; t < CAP; t++) T::ph_reload(t, sh, regs[t]);
             }
         }
@@ -230,6 +244,7 @@ struct Backend {
             Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
+        if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
         if (cap == 64) emu_rollout<64>(c, P, Rk); else emu_rollout<128>(c, P, Rk);
         return 0;
     }

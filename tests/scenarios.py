@@ -499,8 +499,13 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
         from oracle.actor_np import flat_weights, load_weights
         w = flat_weights(load_weights())
         one.set_actor(w); many.set_actor(w)
+    if source == "table":                                   # actions by (tick, vehicle id); few columns: ids beyond them share the last
+        table = torch.as_tensor(rng.uniform(-3, 3, size=(23, 150)))
+        one.set_action_table(table); many.set_action_table(table)
 
     def single():
+        if source == "table":
+            return one.step(one.actions_from_table())
         if source == "pool":
             return one.step(pool[one.ticks % n_pool])
         if source == "actor":

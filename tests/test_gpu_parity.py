@@ -297,11 +297,13 @@ def test_gpu_pipelined_sub_batches_equal_one_batch():
     scenarios.check_pipelined_equals_single(BACKEND, n_envs=37, n_sub=3, ticks=200, actor=True)
 
 
-@pytest.mark.parametrize("source", ["pool", "zero", "actor"])
+@pytest.mark.parametrize("source", ["pool", "zero", "actor", "table"])
 def test_gpu_step_many_equals_single_ticks(source):
     """pve_step_many (many ticks per call, action source on the device) == single pve_step_all ticks, bit for bit,
     from a cold start, and again from a filled population (prefill)."""
     scenarios.check_step_many(BACKEND, source, n_envs=6, chunks=(1, 7, 40, 3, 60), trajectory_chunk=12)
+    if source == "table":
+        scenarios.check_step_many(BACKEND, source, n_envs=9, capacity=64, rate=350.0, prefill=200, chunks=(5, 30, 90), trajectory_chunk=8, seed=6)
     if source == "pool":
         scenarios.check_step_many(BACKEND, source, n_envs=4, prefill=320, chunks=(25,), trajectory_chunk=10, seed=5)
         scenarios.check_step_many(BACKEND, source, n_envs=5, capacity=64, rate=350.0, chunks=(5, 30, 90), trajectory_chunk=8)

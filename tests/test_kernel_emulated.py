@@ -108,3 +108,10 @@ def test_emulated_prepared_step_many_equals_step_many():
         live = a.state_field("meta").numpy() != 0
         assert np.array_equal(x[live], y[live]), k
     assert a.ticks == 42 and all(sub.ticks == 42 for sub in b.subs)
+
+
+def test_emulated_step_many_table_source_equals_single_ticks():
+    """PVE_SRC_TABLE (actions by (tick, vehicle id), gathered by the vehicle's own thread inside the resident loop; the
+    spawned vehicles' first actions; still ticks) == single ticks with the same table applied on the host side."""
+    scenarios.check_step_many(BACKEND, "table", n_envs=4, chunks=(1, 7, 40, 3, 60), trajectory_chunk=12)
+    scenarios.check_step_many(BACKEND, "table", n_envs=3, capacity=64, rate=350.0, chunks=(5, 30, 50), trajectory_chunk=8, seed=7)

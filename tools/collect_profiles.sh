@@ -21,6 +21,8 @@ timeout 300 $NB --actor --obs-f64 2>/dev/null | tail -1 > $O/bench_actor_f64.jso
 timeout 300 $NB --actor --mode step 2>/dev/null | tail -1 > $O/bench_actor_step.json
 timeout 300 $NB --actor --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_actor_driver_like.json
 timeout 400 $NB --trajectory 1 2>/dev/null | tail -1 > $O/bench_trajectory.json
+timeout 400 $NB --tape id-sin 2>/dev/null | tail -1 > $O/bench_id_sin.json
+timeout 400 $NB --tape id-sin --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_id_sin_driver_like.json
 timeout 300 $B --lane-num 8 --steps 300 2>/dev/null | tail -1 > $O/bench_lanes8.json
 timeout 300 $NB --lane-num 8 --steps 300 --pipeline 3 --mode step 2>/dev/null | tail -1 > $O/bench_lanes8_step.json
 timeout 300 $B --lane-num 4 --capacity 64 --rate 1200 --steps 300 2>/dev/null | tail -1 > $O/bench_lanes4.json
