@@ -617,8 +617,11 @@ def main(argv=None, env_factory=None):
         peak_meas = None if (emu or args.no_copy_peak) else measured_copy_peak(torch, dev)
         mean_alive = tot["alive_steps"] / (K * n_envs * world)
         # ---- what binds: VALU issue (SQ counters of this build), not bandwidth
-        bp, bind_src = (None, None) if emu else binding_profile(mode, tpl, cap, other or tuple(outputs) != (
-            "obs_post", "reward", "flags", "nbr", "new_slot", "env_out"))
+        std_out = tuple(outputs) == ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
+        if args.actor and mode == "rollout" and lane_num == 12 and args.obs_f32 and not traj_on:
+            bp, bind_src = (None, None) if emu else binding_profile("actor_rollout", tpl, cap, not std_out)   # the closed loop's own SQ pass
+        else:
+            bp, bind_src = (None, None) if emu else binding_profile(mode, tpl, cap, other or not std_out)
         binding = None
         if bp:
             waves_per_tick = n_envs * cap / 64.0
