@@ -121,25 +121,6 @@ __device__ __forceinline__ float actor_xsum(float s)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// LayerNorm + ReLU over the 64 hidden units of a vehicle: 16 of them in this lane (units 16 m + 4 q + r), the rest in the
-// lanes 16 / 32 / 48 further on
-__device__ __forceinline__ void actor_ln_relu16(pve_v4f (&v)[4], const float *__restrict__ gamma, const float *__restrict__ beta, int q)
-{   // float4 arithmetic = packed f32 instructions (v_pk_add / v_pk_mul / v_pk_fma): half the VALU issue of scalar code
-    const pve_v4f a4 = (v[0] + v[1]) + (v[2] + v[3]);
-    const float mean = actor_xsum((a4[0] + a4[1]) + (a4[2] + a4[3])) / (float)ACT_H;
-    pve_v4f e4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int m = 0; m < 4; m++) { const pve_v4f d = v[m] - mean; e4 = __builtin_elementwise_fma(d, d, e4); }
-    const float rstd = 1.0f / sqrtf(actor_xsum((e4[0] + e4[1]) + (e4[2] + e4[3])) / (float)ACT_H + 1e-12f);
-    const pve_v4f zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const pve_v4f ga = *(const pve_v4f *)(gamma + 16 * m + 4 * q), be = *(const pve_v4f *)(beta + 16 * m + 4 * q);
-        const pve_v4f inv = ga * rstd;
-        v[m] = __builtin_elementwise_max(__builtin_elementwise_fma(v[m], inv, be - inv * mean), zero);
-    }
-}
-
 // Workgroup = 4 waves sharing ONE copy of the two dense kernels in LDS (rows padded to 68 floats: the four lane groups of
 // an A-operand read hit disjoint banks).  Every wave is on its own: it loops over intersections (persistent), compacts
 // the controlled vehicles of its intersection with ballots and runs their 16-vehicle tiles one after the other -- no
