@@ -393,11 +393,12 @@ __device__ __forceinline__ void actor_ln_relu32(pve_v16f (&v)[2], const float *g
 // One tile: x[16] = this lane's raw observation features (layout above) -> the action of vehicle j (in both of its lanes).
 // A1 / A2: the packed A operands (LDS or global memory), prm: the packed float parameters (LDS).
 // The 12 product blocks (layer 1: unit tile m x K-block kb; layer 2: m2 x kb) run as one software pipeline: the operand pair
-// (hi, lo) of block s + 2 is requested while block s multiplies (three matrix instructions, ~100 cycles), which covers an
-// L1 / L2 round trip when the operands stream from global memory (k_rollout) and keeps at most three pairs (24 registers)
-// in flight.  The opaque offset `o` pins every request to its place: without it the compiler hoists all 24 operand loads
-// to the top (96 registers) and spills.  Unit tiles are processed one after the other (one 16-register accumulator live),
-// all K-blocks of the input are split into half pairs up front.
+// (hi, lo) of block s + 1 is requested while block s multiplies (three matrix instructions, ~100 cycles -- about an L1 round
+// trip when the operands stream from global memory in k_rollout); two pairs (16 registers) in flight.  A ring of three
+// (request s + 2) covered an L2 round trip too but cost 8 more registers: inside k_rollout that was 34 instead of 12 spilled
+// registers and 38.1 instead of 36.6 us per closed-loop step.  The opaque offset `o` pins every request to its place:
+// without it the compiler hoists all 24 operand loads to the top (96 registers) and spills.  Unit tiles are processed one
+// after the other, all K-blocks of the input are split into half pairs up front.
 __device__ __forceinline__ pve_v8h actor_a_operand(const pve_v8h *A1, const pve_v8h *A2, int s, int hl, int idx)
 {   // block s: 0..3 = layer 1 (m = s >> 1, kb = s & 1), 4..11 = layer 2 (m2 = (s - 4) >> 2, kb = (s - 4) & 3)
     return s < 4 ? A1[((hl * 2 + (s >> 1)) * 2 + (s & 1)) * 64 + idx] : A2[((hl * 2 + ((s - 4) >> 2)) * 4 + ((s - 4) & 3)) * 64 + idx];
@@ -408,9 +409,8 @@ __device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *
     const int hf = lane >> 5;
     int o = lane;
     asm volatile("" : "+v"(o));
-    pve_v8h ah[3], al[3];                                     // operand ring
+    pve_v8h ah[2], al[2];                                     // operand ring
     ah[0] = actor_a_operand(A1, A2, 0, 0, o); al[0] = actor_a_operand(A1, A2, 0, 1, o);
-    ah[1] = actor_a_operand(A1, A2, 1, 0, o); al[1] = actor_a_operand(A1, A2, 1, 1, o);
     // ---- LayerNorm over the 28 inputs (14 + 14 of them in the two lanes; the padding entries are zeros)
     float s0 = ((((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) +
                 (((x[8] + x[9]) + (x[10] + x[11])) + ((x[12] + x[13]) + (x[14] + x[15]))));
@@ -437,9 +437,9 @@ __device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *
     pve_v16f h[2], g[2];
 #pragma unroll
     for (int s = 0; s < 12; s++) {
-        if (s + 2 < 12) {                                     // request block s + 2
+        if (s + 1 < 12) {                                     // request block s + 1
             asm volatile("" : "+v"(o));
-            ah[(s + 2) % 3] = actor_a_operand(A1, A2, s + 2, 0, o); al[(s + 2) % 3] = actor_a_operand(A1, A2, s + 2, 1, o);
+            ah[(s + 1) % 2] = actor_a_operand(A1, A2, s + 1, 0, o); al[(s + 1) % 2] = actor_a_operand(A1, A2, s + 1, 1, o);
         }
         if (s == 4) {
             // ---- LayerNorm_1 + ReLU; K-block kb = 2 m + g of the next layer is exactly registers 8 g .. 8 g + 7 of h[m]
@@ -455,9 +455,9 @@ __device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *
         const int layer2 = s >= 4, m = layer2 ? (s - 4) >> 2 : s >> 1, kb = layer2 ? (s - 4) & 3 : s & 1;
         pve_v16f &acc = layer2 ? g[m] : h[m];
         if (kb == 0) acc = *(const pve_v16f *)(prm + (layer2 ? PV_B2 : PV_B1) + (hf * 2 + m) * 16);   // centered bias
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 3], bh[kb], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 3], bl[kb], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % 3], bh[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 2], bh[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 2], bl[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % 2], bh[kb], acc, 0, 0, 0);
     }
     actor_ln_relu32(g, prm + PV_G2 + hf * 32, prm + PV_BE2 + hf * 32);
     // ---- dense 64 -> 1, 3 tanh
