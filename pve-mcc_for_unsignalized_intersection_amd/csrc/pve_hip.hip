@@ -70,7 +70,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(CAP == 64 ?
     T::ph_build(c, t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(4)
-    T::ph_rank(t, sh);
+    T::ph_rank(t, sh, env);
     lds_barrier();
     PVE_PHASE_MARK(5)
     T::ph_scan(c, t, sh, r);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu((CAP == 64 
     lds_barrier();
     PVE_PHASE_MARK(4)
     T::ph_load_late(P, env, t, sh, r);
-    T::ph_rank(t, sh);
+    T::ph_rank(t, sh, env);
     lds_barrier();
     PVE_PHASE_MARK(5)
     T::template ph_scan<FIX4>(g, t, sh, r);

@@ -120,6 +120,20 @@ PVE_HD int lds_claim(int *p, int n)  // reserves n consecutive units, returns th
     int o = *p; *p += n; return o;
 #endif
 }
+PVE_HD unsigned lds_xchg(unsigned *p, unsigned v)   // stores v, returns what was there
+{
+#if PVE_DEVICE_CODE
+    return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    const unsigned o = *p; *p = v; return o;
+#endif
+}
+// sorted position -> entry: the low half of a tagged word (Shared<128>, see ph_rank) or a plain 16-bit index (SharedGeo)
+template <class W> PVE_HD int sidx_at(const W *s, int i)
+{
+    if constexpr (sizeof(W) == 4) return ((const uint16_t *)s)[2 * i];
+    else return s[i];
+}
 PVE_HD void lds_or(int *p, int v)
 {
 #if PVE_DEVICE_CODE
@@ -201,7 +215,9 @@ template <int CAP> struct Shared {
     };
     double virdis[CAP];
     int cnt[CAP];                    // collision hits received: early | late << 16
-    alignas(8) uint16_t s_idx[DIRECT ? 1 : POOL];
+    // sorted position -> entry | tick tag << 16: RANK claims a position with one exchange and learns from the tag it gets
+    // back whether an entry with the SAME distance was there first (ph_rank); readers take the low half
+    alignas(8) unsigned s_idx[DIRECT ? 1 : POOL];
     double s_vd[DIRECT ? POOL : 1];
     alignas(8) uint8_t u_slot[POOL];
     // k_rollout keeps the state on the chip between two ticks: every persistent field of every vehicle moves to its
@@ -736,9 +752,19 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 
     // ============================================================== RANK: counting sort of every list by
     // (vd, slot) = the reference's stable sort of the (lane, j)-ordered list by vd (ref :271)
-    static PVE_HD void ph_rank(int t, Sh &sh)
+    //
+    // CAP = 128: the position is the number of smaller distances only (2 vector instructions per list element instead of
+    // 4 with the count of equal ones).  Entries of one list that share the same distance -- vehicles of symmetric lanes
+    // that spawned in the same tick, before their first controlled step -- compute the same position; they are found by
+    // the claim itself: s_idx[position] is taken with ONE exchange that stores entry | tag << 16, tag = this tick's (and
+    // env's) 16-bit stamp.  Whoever gets a word with the current stamp back is not the first at that position and files
+    // the whole run of equal distances in slot order (every later arrival rewrites the same values; the LDS executes
+    // the operations of a wave in order, so the last fix-up is the last write).  A stale word that happens to carry the
+    // stamp (left-over LDS contents) only sends an entry through the fix-up, which then files just itself.
+    static PVE_HD void ph_rank(int t, Sh &sh, int salt = 0)
     {
         const int M = sh.loff[NL];
+        const unsigned tag = Sh::DIRECT ? 0u : (((unsigned)sh.hd.ticks + (unsigned)salt * 0x9E37u) << 16);
         for (int e = t; e < M; e += CAP) {
             const int d = sh.u_list[e];
             const double vd = sh.u_vd[e];
@@ -751,7 +777,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 const double w0 = sh.u_vd[f], w1 = sh.u_vd[f + 1], w2 = sh.u_vd[f + 2], w3 = sh.u_vd[f + 3];
                 const double w4 = sh.u_vd[f + 4], w5 = sh.u_vd[f + 5], w6 = sh.u_vd[f + 6], w7 = sh.u_vd[f + 7];
                 pos += (w0 < vd) + (w1 < vd) + (w2 < vd) + (w3 < vd) + (w4 < vd) + (w5 < vd) + (w6 < vd) + (w7 < vd);
-                eq += (w0 == vd) + (w1 == vd) + (w2 == vd) + (w3 == vd) + (w4 == vd) + (w5 == vd) + (w6 == vd) + (w7 == vd);
+                if (Sh::DIRECT) eq += (w0 == vd) + (w1 == vd) + (w2 == vd) + (w3 == vd) + (w4 == vd) + (w5 == vd) + (w6 == vd) + (w7 == vd);
             }
             if (f < hi) {                                 // tail (< 8 entries): one more round of independent reads,
                 const int n = hi - f;                     // out-of-range lanes re-read entry f and are masked out
@@ -759,16 +785,29 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 #pragma unroll
                 for (int k = 0; k < 7; k++) w[k] = sh.u_vd[f + (k < n ? k : 0)];
 #pragma unroll
-                for (int k = 0; k < 7; k++) { pos += (k < n) & (w[k] < vd); eq += (k < n) & (w[k] == vd); }
-            }
-            if (eq > 1) {                                 // exact vd ties (rare): lower slot first
-                const int slot = sh.u_slot[e];
-                for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
+                for (int k = 0; k < 7; k++) { pos += (k < n) & (w[k] < vd); if (Sh::DIRECT) eq += (k < n) & (w[k] == vd); }
             }
             const int myslot = sh.u_slot[e];
-            if (Sh::DIRECT) { sh.s_vd[lo + pos] = vd; sh.s_slot[lo + pos] = (uint8_t)myslot; }
-            else sh.s_idx[lo + pos] = (uint16_t)e;
-            if (e - lo < sh.cstart[d + 1] - sh.cstart[d]) sh.mypos[myslot] = (uint8_t)pos;   // own-lane segment comes first
+            const int nown = sh.cstart[d + 1] - sh.cstart[d];                     // own-lane segment comes first
+            if (Sh::DIRECT) {
+                if (eq > 1)                               // exact vd ties: lower slot first
+                    for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < myslot) ? 1 : 0;
+                sh.s_vd[lo + pos] = vd; sh.s_slot[lo + pos] = (uint8_t)myslot;
+                if (e - lo < nown) sh.mypos[myslot] = (uint8_t)pos;
+            } else {
+                if (e - lo < nown) sh.mypos[myslot] = (uint8_t)pos;               // (before the claim: a fix-up comes after it)
+                const unsigned old = lds_xchg(&sh.s_idx[Sh::DIRECT ? 0 : lo + pos], tag | (unsigned)e);
+                if ((old & 0xFFFF0000u) == tag) {         // somebody with the same distance was here first (or a stale word)
+                    for (f = lo; f < hi; f++) {
+                        if (!(sh.u_vd[f] == vd)) continue;
+                        const int sf = sh.u_slot[f];
+                        int rk = 0;
+                        for (int g = lo; g < hi; g++) rk += (sh.u_vd[g] == vd && sh.u_slot[g] < sf) ? 1 : 0;
+                        sh.s_idx[Sh::DIRECT ? 0 : lo + pos + rk] = tag | (unsigned)f;
+                        if (f - lo < nown) sh.mypos[sf] = (uint8_t)(pos + rk);
+                    }
+                }
+            }
         }
     }
 
@@ -801,9 +840,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD unsigned umax(unsigned a, unsigned b) { return a < b ? b : a; }
     static PVE_HD void walk_window(Sh &sh, int base, int n, int s, double ps, Regs &r, int &pr, double &pvd)
     {
-        const uint16_t *sidx = sh.s_idx + base;      // sorted position -> entry
-#define sv(pos_) (Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base + (pos_) : 0] : sh.u_vd[sidx[pos_]])
-#define ss(pos_) (Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base + (pos_) : 0] : sh.u_slot[sidx[pos_]])
+        const auto *sidx = sh.s_idx + base;      // sorted position -> entry
+#define sv(pos_) (Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base + (pos_) : 0] : sh.u_vd[sidx_at(sidx, pos_)])
+#define ss(pos_) (Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base + (pos_) : 0] : sh.u_slot[sidx_at(sidx, pos_)])
         // All window reads are UNCONDITIONAL on clamped positions and the validity is applied to the keys afterwards: a
         // guarded LDS read is a basic block of its own (index read, wait, value read, wait) and thirteen of them in a row
         // are twenty-six serial LDS round trips; this way the 13 index reads go out back to back, then the value reads.
@@ -870,7 +909,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const int code = (int)(w[k] & 15u);
             const int pos = (code & 8) ? (s - 7 + code) : (s - 1 - code);        // = s + 1 + (code - 8) on the right
             const int pc = ((int)w[k] >= 0) ? pos : 0;                           // (the keys of absent candidates have bit 31 set)
-            ei[k] = Sh::DIRECT ? (base + pc) : (int)sidx[pc];
+            ei[k] = Sh::DIRECT ? (base + pc) : sidx_at(sidx, pc);
         }
 #pragma unroll
         for (int k = 0; k < NNB; k++) PVE_PIN(ei[k]);
@@ -908,9 +947,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // network, and for runs of equal vd on the left or equal |d| among the winners the general pointer walk.
     static PVE_HD void walk_window_exact(Sh &sh, int base, int n, int s, double ps, Regs &r)
     {
-        const uint16_t *sidx = sh.s_idx + base;
-#define sv(pos_) (Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base + (pos_) : 0] : sh.u_vd[sidx[pos_]])
-#define ss(pos_) (Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base + (pos_) : 0] : sh.u_slot[sidx[pos_]])
+        const auto *sidx = sh.s_idx + base;
+#define sv(pos_) (Sh::DIRECT ? sh.s_vd[Sh::DIRECT ? base + (pos_) : 0] : sh.u_vd[sidx_at(sidx, pos_)])
+#define ss(pos_) (Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base + (pos_) : 0] : sh.u_slot[sidx_at(sidx, pos_)])
         const int last = n - 1;
         double lv[NNB + 1], rv[NNB];
 #pragma unroll
@@ -1007,7 +1046,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             // thread d < 12: lane d is non-empty -> its list was rebuilt (ref :234); head persisted for next tick's step (ref :1517)
             const int base = sh.loff[t];
             if (sh.nfin[t] > 0) {
-                const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[sh.s_idx[base]];
+                const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[sidx_at(sh.s_idx, base)];
                 lds_or(&sh.hd.head_valid, 1 << t);
                 int hl = sh.lane_of[hr];
                 sh.hd.head_lane[t] = hl;

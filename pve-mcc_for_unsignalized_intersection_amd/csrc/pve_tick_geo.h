@@ -48,7 +48,7 @@ template <int CAP> struct SharedGeo {
         double u_vd[PE];                    // entry pool; LOCK2 re-uses [0, CAP) as the dead-lock scratch (records by rank)
     };
     double s_vd[1];
-    alignas(8) uint16_t s_idx[PE];
+    alignas(8) unsigned s_idx[PE];          // sorted position -> entry | tick tag << 16 (cf. Shared<128>, Tick::ph_rank)
     alignas(8) uint8_t u_slot[PE], u_list[PE];
     alignas(8) uint8_t s_slot[PE];          // slot of the entry at every sorted position (read by the 4-lane left-turn egos)
     // k_rollout_geo keeps the state on the chip between two ticks (cf. Shared<CAP>): every persistent field of every vehicle
@@ -381,24 +381,27 @@ template <int CAP> struct TickGeo {
     }
     // RANK: counting sort of every list by (vd, slot) = the reference's stable sort by vd of the list it builds in
     // (lane, intention, j) order (ref :271); entry-parallel, 8 independent LDS reads per round (cf. Tick::ph_rank)
-    static PVE_HD void ph_rank(int t, Sh &sh)
+    // Positions are claimed with a tagged exchange and runs of equal distances filed by whoever finds the position taken,
+    // as in Tick::ph_rank.
+    static PVE_HD void ph_rank(int t, Sh &sh, int salt = 0)
     {
         if (!sh.pool_ok) return;
         const int M = sh.lbase[ND] < Sh::PE ? sh.lbase[ND] : Sh::PE;
+        const unsigned tag = ((unsigned)sh.hd.ticks + (unsigned)salt * 0x9E37u) << 16;
         for (int e = t; e < M; e += CAP) {
             const int d = sh.u_list[e];
             if (d == 0xFF) continue;                      // capacity nobody claimed
             const double vd = sh.u_vd[e];
             const int slot = sh.u_slot[e];
             const int lo = sh.lbase[d], hi = lo + sh.fill[d];
-            int pos = 0, eq = 0;
+            int pos = 0;
             int f = lo;
             for (; f + 8 <= hi; f += 8) {
                 double w[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) w[k] = sh.u_vd[f + k];
 #pragma unroll
-                for (int k = 0; k < 8; k++) { pos += (w[k] < vd) ? 1 : 0; eq += (w[k] == vd) ? 1 : 0; }
+                for (int k = 0; k < 8; k++) pos += (w[k] < vd) ? 1 : 0;
             }
             if (f < hi) {                                 // tail (< 8 entries): one more round of independent reads
                 const int n = hi - f;
@@ -406,13 +409,22 @@ template <int CAP> struct TickGeo {
 #pragma unroll
                 for (int k = 0; k < 7; k++) w[k] = sh.u_vd[f + (k < n ? k : 0)];
 #pragma unroll
-                for (int k = 0; k < 7; k++) { pos += (k < n) & (w[k] < vd); eq += (k < n) & (w[k] == vd); }
+                for (int k = 0; k < 7; k++) pos += (k < n) & (w[k] < vd);
             }
-            if (eq > 1)                                   // exact vd ties (rare): lower slot first
-                for (f = lo; f < hi; f++) pos += (sh.u_vd[f] == vd && sh.u_slot[f] < slot) ? 1 : 0;
-            sh.s_idx[lo + pos] = (uint16_t)e;
             sh.s_slot[lo + pos] = (uint8_t)slot;
-            if (d == sh.route_of[slot]) sh.mypos[slot] = (int16_t)pos;          // the vehicle's own entry (vd = p)
+            if (d == sh.route_of[slot]) sh.mypos[slot] = (int16_t)pos;            // the vehicle's own entry (vd = p)
+            const unsigned old = lds_xchg(&sh.s_idx[lo + pos], tag | (unsigned)e);
+            if ((old & 0xFFFF0000u) == tag) {             // an entry with the same distance was here first (or a stale word)
+                for (f = lo; f < hi; f++) {
+                    if (!(sh.u_vd[f] == vd)) continue;
+                    const int sf = sh.u_slot[f];
+                    int rk = 0;
+                    for (int g = lo; g < hi; g++) rk += (sh.u_vd[g] == vd && sh.u_slot[g] < sf) ? 1 : 0;
+                    sh.s_idx[lo + pos + rk] = tag | (unsigned)f;
+                    sh.s_slot[lo + pos + rk] = (uint8_t)sf;
+                    if (d == sh.route_of[sf]) sh.mypos[sf] = (int16_t)(pos + rk);
+                }
+            }
         }
     }
 
@@ -478,7 +490,7 @@ template <int CAP> struct TickGeo {
             if (sh.hd.lane_start[li + 1] > sh.hd.lane_start[li]) {
                 double best = INFINITY; int bs = -1;
                 if (lists) {
-                    if (sh.fill[d] > 0) bs = sh.u_slot[sh.s_idx[sh.lbase[d]]];                  // sorted: the first entry
+                    if (sh.fill[d] > 0) bs = sh.u_slot[sidx_at(sh.s_idx, sh.lbase[d])];                  // sorted: the first entry
                 } else {
                     for (int w = 0; w < NW; w++)
                         for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
@@ -588,7 +600,7 @@ template <int CAP> struct TickGeo {
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         const int i = (i0 + k < n) ? i0 + k : n - 1;
-                        xs[k] = sh.s_slot[base + i]; es[k] = sh.s_idx[base + i];
+                        xs[k] = sh.s_slot[base + i]; es[k] = sidx_at(sh.s_idx, base + i);
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) { PVE_PIN(xs[k]); PVE_PIN(es[k]); }
@@ -616,7 +628,7 @@ template <int CAP> struct TickGeo {
                     const bool has = k7[k] != ~0u;
                     const int i = has ? (int)(k7[k] & 127u) : 0;
                     const int x = sh.s_slot[base + i];
-                    double vc = sh.u_vd[sh.s_idx[base + i]];
+                    double vc = sh.u_vd[sidx_at(sh.s_idx, base + i)];
                     if (has && sh.route_of[x] == opp) vc = adj(x, vc);
                     wx[k] = has ? x : -1; wp[k] = i; wv[k] = has ? vc : 0.0; wd[k] = has ? fabs(vc - me) : INFINITY;
                 }
@@ -630,7 +642,7 @@ template <int CAP> struct TickGeo {
                     int bs = -1; double bv = 0;
                     if (mp > 0) {
                         bs = sh.s_slot[base + mp - 1];
-                        bv = sh.u_vd[sh.s_idx[base + mp - 1]];
+                        bv = sh.u_vd[sidx_at(sh.s_idx, base + mp - 1)];
                         if (sh.route_of[bs] == opp) bv = adj(bs, bv);
                     }
                     r.hdr = bs;                                                             // ref :1348-1354

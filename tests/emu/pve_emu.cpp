@@ -33,7 +33,7 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_step3_publish(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_lists_b(t, sh);
         for (int t = 0; t < CAP; t++) T::ph_build(c, t, sh, regs[t]);
-        for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
+        for (int t = 0; t < CAP; t++) T::ph_rank(t, sh, env);
         for (int t = 0; t < CAP; t++) T::ph_scan(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_reward(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_effects(c, t, sh, regs[t]);
@@ -138,7 +138,7 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_pairs_fill(g, t, sh);
         for (int t = 0; t < CAP; t++) T::ph_fix_table(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_load_late(P, env, t, sh, regs[t]);
-        for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
+        for (int t = 0; t < CAP; t++) T::ph_rank(t, sh, env);
         for (int t = 0; t < CAP; t++) T::ph_scan(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_reward(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_effects(g, t, sh, regs[t]);
