@@ -154,12 +154,13 @@ PVE_HD void lds_and(int *p, int v)
 PVE_HD int wave_incl_scan(int t, int x, int *emu_acc)
 {
 #if PVE_DEVICE_CODE
-    // DPP row shifts + row broadcasts (VALU-rate data movement) instead of 6 dependent ds_bpermute round trips;
-    // lanes without a source add the `old` operand 0
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    // DPP row shifts + row broadcasts (VALU-rate data movement) instead of 6 dependent ds_bpermute round trips.  Row shifts:
+    // bound_ctrl makes the lanes without a source read 0 (no `old` operand to initialise); the row broadcasts only write
+    // the rows of their mask, the others keep old = 0
+    x += __builtin_amdgcn_mov_dpp(x, 0x111, 0xf, 0xf, true);             // row_shr:1
+    x += __builtin_amdgcn_mov_dpp(x, 0x112, 0xf, 0xf, true);             // row_shr:2
+    x += __builtin_amdgcn_mov_dpp(x, 0x114, 0xf, 0xf, true);             // row_shr:4
+    x += __builtin_amdgcn_mov_dpp(x, 0x118, 0xf, 0xf, true);             // row_shr:8
     x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
     return x;
@@ -174,9 +175,14 @@ PVE_HD int wave_incl_scan(int t, int x, int *emu_acc)
 template <int CTRL, int ROW_MASK> PVE_HD double dpp_add_f64(double x)
 {
     const int lo = __double2loint(x), hi = __double2hiint(x);
-    const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    // lanes without a valid source keep old = +0.0 (bound_ctrl off, old operand 0): adding 0 is exact
+    int slo, shi;
+    if (ROW_MASK == 0xf) {               // row shifts: bound_ctrl, lanes without a source read +0.0 (adding it is exact)
+        slo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+        shi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    } else {                             // row broadcasts: the rows outside the mask keep old = +0.0
+        slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+        shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    }
     return x + __hiloint2double(shi, slo);
 }
 #endif
@@ -195,6 +201,19 @@ PVE_HD void block_sum(double *red, int t, double x)
 #endif
 }
 
+// block_sum of a term that is zero in most waves of most ticks (jerk_sum of the vehicles that finish): a wave without a
+// single term stores +0.0, which is what the tree returns for 64 zeros
+PVE_HD void block_sum_sparse(double *red, int t, bool has, double x)
+{
+#if PVE_DEVICE_CODE
+    if (__builtin_amdgcn_ballot_w64(has) == 0) {
+        if ((t & 63) == 63) red[t >> 6] = 0.0;
+        return;
+    }
+#endif
+    block_sum(red, t, has ? x : 0.0);
+}
+
 // ------------------------------------------------------------------ shared (LDS) block of one env
 template <int CAP> struct Shared {
     static constexpr int NW = CAP / 64;
@@ -208,7 +227,9 @@ template <int CAP> struct Shared {
     static constexpr bool DIRECT = (CAP == 64);
     static constexpr bool DENSE = true;       // controlled-vehicle phases on the dense mapping (see the top of this file)
     EnvHeader hd;
-    double p[CAP], v[CAP], a[CAP];   // post-step kinematics of every slot
+    // post-step kinematics of every slot; cell CAP of v / a / lane_of / lj is a vehicle that is not there (zeros, written
+    // once per launch): FIN gathers the absent neighbours of an observation row from it instead of selecting 24 zeros
+    double p[CAP], v[CAP + 1], a[CAP + 1];
     union {                          // p1/v1 die at the barrier after S3, the lists are born after it
         struct { double p1[CAP], v1[CAP]; };   // step outcome "if braking" (S1-S3 only)
         double u_vd[POOL];           // virtual distance of every list entry (segment order)
@@ -282,9 +303,9 @@ template <int CAP> struct Shared {
         alignas(8) int16_t segoff[NL][5];                  // start of segment (own, conflict 0..3) inside list d (LISTS .. BUILD)
         struct { double red_reward[NW], red_jerk[NW]; };   // per-wave partial sums (LOCK .. FIN)
     };
-    uint8_t lane_of[CAP];            // lane of every alive slot
+    uint8_t lane_of[CAP + 1];        // lane of every alive slot
     static constexpr bool HAS_LJ = (CAP == 128);      // (CAP = 64: the block must stay <= 10 KB, see below)
-    int lj[HAS_LJ ? CAP : 1];        // lane << 16 | j of every alive slot (S1 .. FIN): the `(lane, j)` names of neighbours and virtual
+    int lj[HAS_LJ ? CAP + 1 : 1];    // lane << 16 | j of every alive slot (S1 .. FIN): the `(lane, j)` names of neighbours and virtual
                                      // headers are one gather instead of lane_of + lane_start + arithmetic
     union {
         float xy32[CAP][2];          // single-precision position of every controlled vehicle (collision pre-filter; BUILD .. REWARD)
@@ -580,7 +601,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             r.count = P.i32[I_COUNT][g];
         }
         sh.cnt[t] = 0;                                    // (rew_ovr / hdr share storage with S2-S3 arrays: BUILD)
-        if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
+        if (t == 0) {
+            sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0;
+            sh.v[CAP] = 0; sh.a[CAP] = 0; sh.lane_of[CAP] = 0;
+            if constexpr (Sh::HAS_LJ) sh.lj[CAP] = 0;
+        }
         if (t < 8) {
             sh.tabA[t >> 2][t & 3] = c.vdA[t >> 2][t & 3];
             sh.tabB[t >> 2][t & 3] = c.vdB[t >> 2][t & 3];
@@ -1192,7 +1217,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             ((double *)sh.xy32)[r.ds] = r.dcloser;        // closer_p (ref :302) back to the slot's thread; xy32 is dead after REWARD
         }
         block_sum(sh.red_reward, t, r.dctl ? r.reward : 0.0);
-        block_sum(sh.red_jerk, t, r.fin ? r.jerk_sum : 0.0);                      // ref :358
+        block_sum_sparse(sh.red_jerk, t, r.fin, r.jerk_sum);                      // ref :358
         // Dead-lock scan (ref :365-370, :1469-1499), member-parallel: every controlled vehicle follows the
         // virtual-header pointers for <= 10 hops; if the walk returns to itself it is on a cycle.  Cycles are rare:
         // the first walk only chases pointers; a member then walks its cycle again and learns the smallest slot (= the
@@ -1242,7 +1267,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     {
         if (r.alive && r.ctl && sh.rew_ovr[t]) r.reward = -10;                    // ref :346 via reward[-1]
         block_sum(sh.red_reward, t, (r.alive && r.ctl) ? r.reward : 0.0);
-        block_sum(sh.red_jerk, t, r.fin ? r.jerk_sum : 0.0);                      // ref :358
+        block_sum_sparse(sh.red_jerk, t, r.fin, r.jerk_sum);                      // ref :358
         // Dead-lock scan (ref :365-370, :1469-1499), member-parallel: every controlled vehicle follows the
         // virtual-header pointers for <= 10 hops; if the walk returns to itself it is on a cycle and has, on the
         // way, seen every other member: it knows the cycle length, the smallest slot (= the member that discovers
@@ -1321,7 +1346,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // load).  `full` (uniform) forces the staged form: the last tick of a launch, whose state FLUSH takes from the staging area.
     // adst (k_rollout with the actor on the chip): the post-compaction slot of the dense thread's vehicle (< 0: gone) for the
     // actor pass behind STAGE
-    template <bool RES, class OutT>
+    // ZROW: the fields of an absent neighbour are gathered from the zero cell instead of being selected (48 selects less;
+    // only where the longer live ranges of the gathered values do not spill: the default and actor forms of k_rollout)
+    template <bool RES, bool ZROW = false, class OutT>
     static PVE_HD void ph_final(const PVE_AS4 Const &c, const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh,
                                 Regs &r, FinCarry &fc, bool full = true, int *adst = nullptr)
     {
@@ -1494,7 +1521,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             int xc[NNB], nln[NNB], nlj[NNB]; double nv[NNB], na[NNB];
 #pragma unroll
             for (int k = 0; k < NNB; k++) {
-                xc[k] = r.kr[k] < 0 ? 0 : r.kr[k];
+                xc[k] = r.kr[k] < 0 ? (ZROW ? CAP : 0) : r.kr[k];   // (cell CAP: zeros)
                 if constexpr (Sh::HAS_LJ) nlj[k] = sh.lj[xc[k]]; else nlj[k] = (int)sh.lane_of[xc[k]];
                 nv[k] = sh.v[xc[k]]; na[k] = sh.a[xc[k]];
             }
@@ -1519,9 +1546,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 row[0] = r.dp; row[1] = myv; row[2] = mya; row[3] = (double)r.dlane;
 #pragma unroll
                 for (int k = 0; k < NNB; k++) {
+                    // absent neighbour: WALK left kv = 0, the gathers came from the zero cell
                     const bool has = r.kr[k] >= 0;
-                    row[4 + 4 * k] = has ? r.kv[k] : 0.0; row[5 + 4 * k] = has ? nv[k] : 0.0;
-                    row[6 + 4 * k] = has ? na[k] : 0.0; row[7 + 4 * k] = has ? (double)nln[k] : 0.0;
+                    row[4 + 4 * k] = (ZROW || has) ? r.kv[k] : 0.0;       // (WALK left kv = 0 for an absent neighbour)
+                    row[5 + 4 * k] = (ZROW || has) ? nv[k] : 0.0;
+                    row[6 + 4 * k] = (ZROW || has) ? na[k] : 0.0;
+                    row[7 + 4 * k] = (ZROW || has) ? (double)nln[k] : 0.0;
                 }
                 if (O.obs_pre) {
                     if (P.obs_f32) {                    // (12-lane kernels: obs_pre / state_pre follow the row type)
