@@ -423,12 +423,25 @@ def main(argv=None, env_factory=None):
 
     prepared = {}
 
+    launch_seq = {}
+    if os.environ.get("PVE_BENCH_CHUNKS") and mode == "rollout" and hasattr(env, "prepare_step_many"):
+        seq = [int(x) for x in os.environ["PVE_BENCH_CHUNKS"].split(",")]
+        launch_seq[sum(seq)] = seq
+        for m in set(seq):
+            prepared[("one", m)] = env.prepare_step_many(m, source=src, chunk=0)
+
     def run_ticks(n):
         """n ticks of every env of this rank, enqueued (not synchronised)."""
         if n <= 0:
             return
         if mode == "rollout" and not traj_on and not args.actor and hasattr(env, "prepare_step_many"):
             # prepared calls: the host side of the timed region is one ctypes call per sub-batch
+            seq = launch_seq.get(n)
+            if seq:                                       # a sequence of launches of different lengths (see below)
+                for m in seq:
+                    prepared[("one", m)]()
+                tick[0] += n
+                return
             if n not in prepared:
                 prepared[n] = env.prepare_step_many(n, source=src, chunk=args.chunk)
             prepared[n]()
@@ -485,15 +498,24 @@ def main(argv=None, env_factory=None):
     if not emu:
         ev_streams = sub_streams if sub_streams else [torch.cuda.current_stream(dev)]
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ev_streams]
-    t0 = time.perf_counter()
+    # (the start events are instrumentation, not work: recorded on the idle streams before the clock starts -- two
+    #  hipEventRecord calls are 13-25 us of host time, 2-3 % of the driver's 20-tick region)
     if not emu:
         for (e0, _), st in zip(evs, ev_streams):
             e0.record(st)
+    t0 = time.perf_counter()
+    t_rec = t0
     run_ticks(K)
+    t_enq = time.perf_counter()
     if not emu:
         for (_, e1), st in zip(evs, ev_streams):
             e1.record(st)
     sync()
+    if os.environ.get("PVE_BENCH_TIMELINE") and not emu:     # host side of the timed region, us (diagnostics, stderr)
+        t_end = time.perf_counter()
+        sys.stderr.write("timeline us: record %.1f  enqueue %.1f  wait %.1f  total %.1f | per-stream event spans %s\n" % (
+            (t_rec - t0) * 1e6, (t_enq - t_rec) * 1e6, (t_end - t_enq) * 1e6, (t_end - t0) * 1e6,
+            ["%.1f" % (e0.elapsed_time(e1) * 1e3) for e0, e1 in evs]))
     if world > 1:
         dist.barrier()
     sync()

@@ -45,11 +45,12 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(CAP == 64 ?
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka0_;
     const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + ((sizeof(Const) + 7) / 8 * 8));
-    __shared__ Shared<CAP> sh;
+    typedef Shared<CAP, false> ShT;                  // (without the lane << 16 | j words: 16 368 B, the 10th workgroup per CU)
+    __shared__ ShT sh;
     const int t = threadIdx.x;
     const int env = blockIdx.x;
     Regs r;
-    typedef Tick<CAP> T;
+    typedef Tick<CAP, ShT> T;
     unsigned long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev_ = P.phase_cycles ? wall_clock64() : 0ull;
     T::ph_load(c, P, env, t, sh, r);

@@ -215,7 +215,7 @@ PVE_HD void block_sum_sparse(double *red, int t, bool has, double x)
 }
 
 // ------------------------------------------------------------------ shared (LDS) block of one env
-template <int CAP> struct Shared {
+template <int CAP, bool LJ = (CAP == 128)> struct Shared {
     static constexpr int NW = CAP / 64;
     static constexpr bool PIN_READS = true;   // walk_window: keep the batched window reads from being sunk into guarded blocks
     static constexpr int POOL = 5 * CAP;
@@ -304,7 +304,7 @@ template <int CAP> struct Shared {
         struct { double red_reward[NW], red_jerk[NW]; };   // per-wave partial sums (LOCK .. FIN)
     };
     uint8_t lane_of[CAP + 1];        // lane of every alive slot
-    static constexpr bool HAS_LJ = (CAP == 128);      // (CAP = 64: the block must stay <= 10 KB, see below)
+    static constexpr bool HAS_LJ = LJ;                // (CAP = 64: the block must stay <= 10 KB; k_tick<128>: <= 16 KB, 10 workgroups per CU)
     int lj[HAS_LJ ? CAP + 1 : 1];    // lane << 16 | j of every alive slot (S1 .. FIN): the `(lane, j)` names of neighbours and virtual
                                      // headers are one gather instead of lane_of + lane_start + arithmetic
     union {
