@@ -165,12 +165,25 @@ def _overflow_guard(b, fn):
         raise
 
 
-def check_fuzz_vs_oracle(backend, n_envs, capacity, ticks, rate, seed, action_scale=3.0, quantize=None):
+def symmetric_arrivals(n_envs, gap_s, rows, lane_groups):
+    """Arrival streams in which the lanes of a group spawn in the SAME tick (identical arrival times): while nobody steers
+    them apart, vehicles of symmetric lanes keep identical positions, i.e. identical virtual distances in every list they
+    share -- runs of 2 .. 4 equal keys in RANK (the claim / fix-up path) in every tick."""
+    out = np.full((n_envs, rows, 12), np.inf, dtype=np.float64)
+    for e in range(n_envs):
+        for g, lanes in enumerate(lane_groups):
+            t = 1.0 + 0.3 * g + 0.7 * e + gap_s * np.arange(rows - 1)
+            for l in lanes:
+                out[e, :rows - 1, l] = t
+    return out
+
+
+def check_fuzz_vs_oracle(backend, n_envs, capacity, ticks, rate, seed, action_scale=3.0, quantize=None, arrivals=None):
     """Random action tapes (uniform in [-scale, scale], optionally quantised to provoke exact ties), every env
     compared with its own oracle every tick: controlled set, rewards, collision counters, lock counts, and the
     full persistent state at the end. Exercises vd ties, long dead-lock cycles, collisions, mid-lane deletions."""
     rng = np.random.default_rng(seed)
-    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed)
+    arr = arrivals if arrivals is not None else synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed)
     b = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "reward", "flags", "nbr",
                                                             "env_out", "new_slot", "lanej"))
     b.reset()
@@ -480,14 +493,14 @@ def check_pipelined_equals_single(backend, n_envs=7, n_sub=3, capacity=128, tick
 
 
 def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1, 7, 40, 3, 60), rate=1100.0,
-                    prefill=0, trajectory_chunk=12):
+                    prefill=0, trajectory_chunk=12, arrivals=None):
     """pve_step_many (n ticks per call, action source on the device) == n single-tick calls, bit for bit: persistent
     state, headers, observation rows, last-tick outputs and -- trajectory mode -- the outputs of every tick."""
     from pve_mcc_amd._capi import PveError
     n_pool = 5
     rng = np.random.default_rng(seed)
     total = prefill + sum(chunks) + trajectory_chunk
-    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed)
+    arr = arrivals if arrivals is not None else synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed)
     outs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out", "lanej")
     one = make_batch(arr, n_envs, capacity, backend, outputs=outs)
     many = make_batch(arr, n_envs, capacity, backend, outputs=outs)

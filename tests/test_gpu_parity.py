@@ -141,6 +141,25 @@ def test_gpu_fuzz_random_tapes(seed, rate, cap, quant):
     assert coll > 0 and lock > 0
 
 
+@pytest.mark.parametrize("groups,scale,quant", [([list(range(12))], 0.0, None),
+                                                ([[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]], 3.0, 3.0),
+                                                ([[0, 6], [3, 9], [1, 7, 4, 10], [2, 5, 8, 11]], 2.0, 1.0)])
+def test_gpu_fuzz_symmetric_lanes_equal_distances(groups, scale, quant):
+    """Lanes that spawn in the same tick: runs of 2 .. 4 equal virtual distances in every list, every tick -- the claim /
+    fix-up path of RANK (tagged exchange, entries of one run in different waves) and WALK's exact path -- 16 envs vs 16
+    oracles every tick."""
+    arr = scenarios.symmetric_arrivals(16, gap_s=3.4, rows=48, lane_groups=groups)
+    scenarios.check_fuzz_vs_oracle(BACKEND, n_envs=16, capacity=128, ticks=400, rate=0.0, seed=9, action_scale=scale,
+                                   quantize=quant, arrivals=arr)
+
+
+def test_gpu_step_many_symmetric_lanes_equal_distances():
+    """The resident kernel on the same streams (zero actions: the runs of equal distances persist until the vehicles
+    collide): pve_step_many == single ticks, bit for bit."""
+    arr = scenarios.symmetric_arrivals(6, gap_s=3.4, rows=48, lane_groups=[[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]])
+    scenarios.check_step_many(BACKEND, "zero", n_envs=6, chunks=(1, 30, 90, 7, 120), trajectory_chunk=20, arrivals=arr)
+
+
 def test_gpu_fuzz_more_than_64_controlled_vehicles():
     """Dense traffic (1400 / 1500 veh/h/lane, gentle actions): more than 64 controlled vehicles per intersection, i.e. the
     second wave takes part in the dense-mapped phases; 16 envs vs 16 oracles every tick, no deferred spawn."""

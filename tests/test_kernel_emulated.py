@@ -115,3 +115,9 @@ def test_emulated_step_many_table_source_equals_single_ticks():
     spawned vehicles' first actions; still ticks) == single ticks with the same table applied on the host side."""
     scenarios.check_step_many(BACKEND, "table", n_envs=4, chunks=(1, 7, 40, 3, 60), trajectory_chunk=12)
     scenarios.check_step_many(BACKEND, "table", n_envs=3, capacity=64, rate=350.0, chunks=(5, 30, 50), trajectory_chunk=8, seed=7)
+
+
+def test_emulated_step_many_symmetric_lanes_equal_distances():
+    """Runs of equal virtual distances (lanes that spawn in the same tick, zero actions) through the resident loop."""
+    arr = scenarios.symmetric_arrivals(2, gap_s=3.4, rows=40, lane_groups=[[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]])
+    scenarios.check_step_many(BACKEND, "zero", n_envs=2, chunks=(1, 30, 90), trajectory_chunk=10, arrivals=arr)
