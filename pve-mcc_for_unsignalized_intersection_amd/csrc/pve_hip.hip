@@ -346,7 +346,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu((CAP == 64 
     PVE_PHASE_MARK(2)
     B::ph_step3(g.base, t, sh, r);
     B::ph_step3_publish(t, sh, r);
-    T::ph_order2(t, sh);
+    T::ph_order2(t, sh, r);
     T::ph_pairs_mode(t, sh, P.geo_scan != 0);
     lds_barrier();
     PVE_PHASE_MARK(3)
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         lds_barrier();
         B::ph_step3(g.base, t, sh, r);
         B::ph_step3_publish(t, sh, r);
-        T::ph_order2(t, sh);
+        T::ph_order2(t, sh, r);
         T::ph_pairs_mode(t, sh, P.geo_scan != 0);
         lds_barrier();
         if (T::pairs_over(sh, P.geo_scan != 0)) {     // (uniform, rare)

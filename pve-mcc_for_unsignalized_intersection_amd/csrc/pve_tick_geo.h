@@ -234,7 +234,7 @@ template <int CAP> struct TickGeo {
             if (t < ND) {
                 const unsigned mr = sh.tab.mroutes[t];
 #pragma unroll
-                for (int rt = 0; rt < ND; rt++) cap += ((mr >> rt) & 1u) ? sh.rc[rt] : 0;
+                for (int rt = 0; rt < ND; rt++) cap += (int)((mr >> rt) & 1u) * sh.rc[rt];      // (bit extract + multiply-add)
                 rcv = sh.rc[t];
                 prs = rcv * sh.tab.nl[t];
             }
@@ -251,14 +251,9 @@ template <int CAP> struct TickGeo {
             }
         }
         if (t < Sh::PE / 4) ((int *)sh.u_list)[t] = -1;          // 0xFF = "no entry here" (RANK skips the gaps)
-        if (r.alive && r.ctl) {
-            int rb = 0;
-#pragma unroll
-            for (int rt = 0; rt < ND; rt++) rb += (rt < r.route) ? sh.rc[rt] : 0;
-            const int rkk = lds_claim(&sh.rfill[r.route], 1);
-            sh.ctl_by_route[rb + rkk] = (uint8_t)t;
-            sh.rk[t] = (uint8_t)rkk;
-        }
+        // rank among the controlled vehicles of its route; ORDER2 files the vehicle at rbase[route] + rank (rbase is the
+        // prefix sum written above: complete behind this phase's barrier -- no second 16-term sum per thread)
+        if (r.alive && r.ctl) sh.rk[t] = (uint8_t)lds_claim(&sh.rfill[r.route], 1);
         if (r.alive) {
             const int ls = sh.hd.lane_start[r.lane], le = sh.hd.lane_start[r.lane + 1];
             int o = ls;
@@ -271,8 +266,9 @@ template <int CAP> struct TickGeo {
             sh.slot_at[o] = (int16_t)t;
         }
     }
-    static PVE_HD void ph_order2(int t, Sh &sh)
+    static PVE_HD void ph_order2(int t, Sh &sh, const Regs &r)
     {
+        if (r.alive && r.ctl) sh.ctl_by_route[sh.rbase[r.route] + (int)sh.rk[t]] = (uint8_t)t;
         const int N = sh.hd.n_alive;
         vote<NW>(sh.m_ctl_ord, t, t < N && mask_test(sh.m_ctl, sh.slot_at[t < N ? t : 0]));
     }
@@ -285,10 +281,18 @@ template <int CAP> struct TickGeo {
     static PVE_HD void pairs_loop(const PVE_AS4 GeoConst &g, int t, Sh &sh)
     {
         const int total = sh.pbase[ND];
-        for (int q = t; q < total; q += CAP) {
-            int rt = 0;
+        // route of pair q = the largest rt with pbase[rt] <= q: the 15 inner prefix sums are read once per thread, every pair
+        // then takes 4 compares and a select tree instead of 15 compares + adds
+        int pb[ND];
 #pragma unroll
-            for (int k = 1; k < ND; k++) rt += (q >= sh.pbase[k]) ? 1 : 0;
+        for (int k = 1; k < ND; k++) pb[k] = sh.pbase[k];
+        for (int q = t; q < total; q += CAP) {
+            const bool c8 = q >= pb[8];
+            const bool c4 = q >= (c8 ? pb[12] : pb[4]);
+            const bool c2 = q >= (c8 ? (c4 ? pb[14] : pb[10]) : (c4 ? pb[6] : pb[2]));
+            const int o3 = c8 ? (c4 ? (c2 ? pb[15] : pb[13]) : (c2 ? pb[11] : pb[9]))
+                              : (c4 ? (c2 ? pb[7] : pb[5]) : (c2 ? pb[3] : pb[1]));
+            const int rt = (c8 ? 8 : 0) + (c4 ? 4 : 0) + (c2 ? 2 : 0) + ((q >= o3) ? 1 : 0);
             const int off = q - sh.pbase[rt], n = sh.tab.nl[rt];
             const int i = (off * (int)sh.tab.ninv[rt]) >> 15, k = off - i * n;          // off / n, off % n (exact: off < 2048, n <= 10)
             const int x = sh.ctl_by_route[sh.rbase[rt] + i], d = sh.tab.lst[rt][k];
@@ -923,23 +927,35 @@ template <int CAP> struct TickGeo {
         if (O.reward && r.alive) O.reward[gpre] = r.ctl ? r.reward : 0.0;
         if (O.lanej && r.alive) O.lanej[gpre] = (r.lane << 16) | r.j;
         if (O.new_slot && r.alive) O.new_slot[gpre] = new_slot;
-        if (O.nbr && r.alive && r.ctl) {           // controlled vehicles only (PVE_F_CTL in flags)
-            int *nb = O.nbr + gpre * NNB;
+        if (r.alive && r.ctl && (O.nbr || O.obs_pre || (O.obs_post && new_slot >= 0))) {
+            // the 6 neighbours' speed, acceleration, lane and route, then their lane starts: two batches of unconditional LDS
+            // gathers on clamped slots (a guarded block per neighbour is a chain of six round trips), shared by the ids and the row
+            int xc[NNB], nln[NNB], nrt[NNB], nls[NNB]; double nv[NNB], na[NNB];
 #pragma unroll
-            for (int k = 0; k < NNB; k++) nb[k] = pack_lanej(sh, r.kr[k]);
-        }
-        if (r.alive && r.ctl && (O.obs_pre || (O.obs_post && new_slot >= 0))) {
+            for (int k = 0; k < NNB; k++) {
+                xc[k] = r.kr[k] < 0 ? 0 : r.kr[k];
+                nln[k] = (int)sh.lane_of[xc[k]]; nrt[k] = (int)sh.route_of[xc[k]];
+                nv[k] = sh.v[xc[k]]; na[k] = sh.a[xc[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < NNB; k++) { PVE_PIN(nln[k]); PVE_PIN(nrt[k]); PVE_PIN(nv[k]); PVE_PIN(na[k]); }
+#pragma unroll
+            for (int k = 0; k < NNB; k++) nls[k] = sh.hd.lane_start[nln[k]];
+#pragma unroll
+            for (int k = 0; k < NNB; k++) PVE_PIN(nls[k]);
+            if (O.nbr) {                               // controlled vehicles only (PVE_F_CTL in flags)
+                int *nb = O.nbr + gpre * NNB;
+#pragma unroll
+                for (int k = 0; k < NNB; k++) nb[k] = r.kr[k] < 0 ? -1 : ((nln[k] << 16) | (xc[k] - nls[k]));
+            }
+          if (O.obs_pre || (O.obs_post && new_slot >= 0)) {
             double row[OBSW];                                                          // ref :1325-1337
             row[0] = r.p; row[1] = r.v; row[2] = r.a; row[3] = (double)r.route;
 #pragma unroll
             for (int k = 0; k < NNB; k++) {
-                const int x = r.kr[k];
-                if (x >= 0) {
-                    row[4 + 4 * k] = r.kv[k]; row[5 + 4 * k] = sh.v[x]; row[6 + 4 * k] = sh.a[x];
-                    row[7 + 4 * k] = (double)sh.route_of[x];
-                } else {
-                    row[4 + 4 * k] = 0; row[5 + 4 * k] = 0; row[6 + 4 * k] = 0; row[7 + 4 * k] = 0;
-                }
+                const bool has = r.kr[k] >= 0;
+                row[4 + 4 * k] = has ? r.kv[k] : 0.0; row[5 + 4 * k] = has ? nv[k] : 0.0;
+                row[6 + 4 * k] = has ? na[k] : 0.0; row[7 + 4 * k] = has ? (double)nrt[k] : 0.0;
             }
             if (O.obs_pre) {
                 double *o = O.obs_pre + gpre * OBSW;
@@ -957,6 +973,7 @@ template <int CAP> struct TickGeo {
                     for (int k = 0; k < OBSW; k++) o[k] = row[k];
                 }
             }
+          }
         }
     }
 

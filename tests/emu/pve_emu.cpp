@@ -128,7 +128,7 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_order(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_step3(g.base, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_step3_publish(t, sh, regs[t]);
-        for (int t = 0; t < CAP; t++) T::ph_order2(t, sh);
+        for (int t = 0; t < CAP; t++) T::ph_order2(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_pairs_mode(t, sh, P.geo_scan != 0);
         if (T::pairs_over(sh, P.geo_scan != 0)) {
             for (int t = 0; t < CAP; t++) T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
@@ -179,7 +179,7 @@ template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &
             for (int t = 0; t < CAP; t++) T::ph_order(t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) B::ph_step3(g.base, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) B::ph_step3_publish(t, sh, regs[t]);
-            for (int t = 0; t < CAP; t++) T::ph_order2(t, sh);
+            for (int t = 0; t < CAP; t++) T::ph_order2(t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_pairs_mode(t, sh, P.geo_scan != 0);
             if (T::pairs_over(sh, P.geo_scan != 0)) {
                 for (int t = 0; t < CAP; t++) T::ph_pairs_count(g, t, sh, P.geo_scan != 0);
