@@ -434,10 +434,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka + OFF_P);
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka + OFF_R);
         lds_barrier();
-        if (k > 0) T::ph_tick_init(g, t, sh, r);
-        // (ph_tick_init's list counters are read behind the next barrier; S1 counts the routes with atomics on rc: the
-        //  zeroing must precede them)
-        if (k > 0) lds_barrier();
+        if (k > 0) T::ph_tick_init(g, t, sh, r);      // (the list counters S1 adds to were cleared in the previous tick's FX phase)
         T::ph_step1(g, P, env, t, sh, r);
         lds_barrier();
         B::ph_step2(g.base, t, sh, r);
@@ -468,6 +465,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         if (k + 1 < n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
         B::ph_prefetch_action(P, R, env, t, nx, r);
         T::ph_effects(g, t, sh, r);
+        T::ph_lists_clear(t, sh);
         lds_barrier();
         B::ph_prefetch_arrival(P, env, t, sh, r, g.lane_num);
         B::ph_lock_slot(g.base, t, sh, r);
@@ -475,11 +473,15 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         B::ph_lock2_slot(t, sh, r);
         lds_barrier();
         const Outputs O = B::template tick_outputs<false>(P, R, k);
-        T::template ph_final<true>(g, P, O, env, t, sh, r, fc);
-        lds_barrier();                                // A: nobody reads the tick's work arrays any more
-        T::ph_stage(g, t, sh, r, fc);
-        lds_barrier();                                // B: the staging area is complete
-        if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
+        T::template ph_final<true>(g, P, O, env, t, sh, r, fc, k + 1 == n_ticks);
+        if (fc.still) {                               // (uniform) nobody moves: the registers carry over
+            T::ph_carry_over(t, sh, r, fc);
+        } else {
+            lds_barrier();                            // A: nobody reads the tick's work arrays any more
+            T::ph_stage(g, t, sh, r, fc);
+            lds_barrier();                            // B: the staging area is complete
+            if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
+        }
     }
     {
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);

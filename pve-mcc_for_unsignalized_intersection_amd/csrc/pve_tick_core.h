@@ -1276,18 +1276,24 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         bool lead = false;
         r.cyc = 0;
         if (r.alive && !r.del && (r.meta & M_CONTROL)) {
-            const double dv = sh.virdis[t];
+            // cycles are rare: the first walk only chases pointers (one read per hop); a member walks its cycle again for
+            // the smallest slot and its rank in the sorted record list
             int cur = t, len = 0, mn = t, rank = 0;
-            bool found = false;
             for (int hop = 0; hop < 10; hop++) {                                  // ref :1470-1478
                 cur = sh.hdr[cur];
                 if (cur < 0) break;
-                if (cur == t) { found = true; len = hop + 1; break; }
-                const double d = sh.virdis[cur];
-                rank += (d < dv || (d == dv && cur < t)) ? 1 : 0;
-                mn = cur < mn ? cur : mn;
+                if (cur == t) { len = hop + 1; break; }
             }
+            const bool found = len > 0;
             if (found) {
+                const double dv = sh.virdis[t];
+                cur = t;
+                for (int hop = 1; hop < len; hop++) {
+                    cur = sh.hdr[cur];
+                    const double d = sh.virdis[cur];
+                    rank += (d < dv || (d == dv && cur < t)) ? 1 : 0;
+                    mn = cur < mn ? cur : mn;
+                }
                 r.cyc = 1 | (len << 1) | (rank << 5) | (mn << 9);
                 lead = (mn == t);
                 if (lead) sh.cyc_off[t] = lds_claim(&sh.lead_n, len);

@@ -784,9 +784,11 @@ template <int CAP> struct TickGeo {
 
     // RES = false: the tick kernel -- state and header go back to HBM (`O` = P.out).  RES = true: k_rollout_geo -- outputs
     // only; the persistent fields and the header updates are handed to ph_stage through `fc` and stay on the chip.
+    // k_rollout_geo, `still` ticks (cf. Tick::ph_final): nobody is deleted and nobody spawns -> every vehicle keeps its slot,
+    // nothing is staged, the registers carry over; `full` (uniform) forces the staged form (the last tick of a launch).
     template <bool RES, class OutT>
     static PVE_HD void ph_final(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh,
-                                Regs &r, FinCarry &fc)
+                                Regs &r, FinCarry &fc, bool full = true)
     {
         const PVE_AS4 Const &c = g.base;
         EnvHeader &gh = P.headers[env];
@@ -794,7 +796,7 @@ template <int CAP> struct TickGeo {
         const int LN = g.lane_num;
         const size_t gpre = (size_t)env * CAP + t;
         const bool fused = RES || (P.mode == MODE_FUSED);
-        fc.still = 0; fc.meta = 0;
+        fc.meta = 0;
         const unsigned want = (unsigned)(sh.m_spawn[0] & 0xFFFull);
         unsigned sp = 0; int room = CAP - N;
 #pragma unroll
@@ -803,6 +805,10 @@ template <int CAP> struct TickGeo {
         u64 keep[NW];
 #pragma unroll
         for (int k = 0; k < NW; k++) keep[k] = fused ? (sh.m_alive[k] & ~sh.m_del[k]) : sh.m_alive[k];
+        bool still = RES && !full && sp == 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) still = still && (sh.m_del[k] == 0);
+        fc.still = still;
         int meta = 0, hdr_word = -1, new_slot = -1, lockf = 0;
         if (r.alive) {
             int coll = r.coll_fin > M_COLL_MASK ? M_COLL_MASK : r.coll_fin;
@@ -822,11 +828,12 @@ template <int CAP> struct TickGeo {
                 }
             }
             if (r.del) meta |= M_DEL;
+            fc.meta = meta;
             hdr_word = pack_lanej(sh, r.hdr);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
                 if (!RES) Base::store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
-                else {                     // EARLY staging (these registers die here)
+                else if (!still) {         // EARLY staging (these registers die here)
                     const int s = new_slot;
                     sh.template stf<Sh::SF_JERK>()[s] = r.jerk; sh.template stf<Sh::SF_JERK_SUM>()[s] = r.jerk_sum;
                     sh.template stf<Sh::SF_VIR_DIS>()[s] = r.vir_dis; sh.template stf<Sh::SF_CLOSER_P>()[s] = r.closer_p;
@@ -1008,6 +1015,13 @@ template <int CAP> struct TickGeo {
         if (t == 0 && g.lane_num != 12) sh.hd.intention_re += fc.n_sp;               // ref :388, :392
         Base::ph_stage_header(t, sh, fc);
     }
+    // a still tick: the vehicle stays in the registers, only the flags word and the next action change hands
+    static PVE_HD void ph_carry_over(int t, Sh &sh, Regs &r, const FinCarry &fc)
+    {
+        Base::ph_stage_header(t, sh, fc);
+        r.meta = fc.meta;
+        r.act = r.act_nx;
+    }
     // RELOAD (after barrier B): slot t's vehicle from the staging arrays, its action from the prefetch register
     static PVE_HD void ph_reload(int t, Sh &sh, Regs &r)
     {
@@ -1033,6 +1047,11 @@ template <int CAP> struct TickGeo {
             sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0;
             sh.hd.current_time = sh.hd.current_time + g.base.deltaT;                  // ref :223 (repeated +=)
         }
+    }
+    // the per-route / per-list counters of the NEXT tick's list build (S1 counts the routes with atomics): cleared in the FX
+    // phase, behind the barrier that ends their last use (WALK), so that the loop needs no barrier between TICK_INIT and S1
+    static PVE_HD void ph_lists_clear(int t, Sh &sh)
+    {
         if (t < ND) { sh.rc[t] = 0; sh.rfill[t] = 0; sh.fill[t] = 0; sh.cnt2[t] = 0; }
     }
 

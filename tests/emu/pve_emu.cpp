@@ -196,13 +196,18 @@ template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &
             if (k + 1 < R.n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
             for (int t = 0; t < CAP; t++) B::ph_prefetch_action(P, R, env, t, nx, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_effects(g, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_lists_clear(t, sh);
             for (int t = 0; t < CAP; t++) B::ph_prefetch_arrival(P, env, t, sh, regs[t], g.lane_num);
             for (int t = 0; t < CAP; t++) B::ph_lock_slot(g.base, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) B::ph_lock2_slot(t, sh, regs[t]);
             const Outputs O = B::template tick_outputs<false>(P, R, k);
-            for (int t = 0; t < CAP; t++) T::template ph_final<true>(g, P, O, env, t, sh, regs[t], fcs[t]);
-            for (int t = 0; t < CAP; t++) T::ph_stage(g, t, sh, regs[t], fcs[t]);
-            if (k + 1 < R.n_ticks) for (int t = 0; t < CAP; t++) T::ph_reload(t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::template ph_final<true>(g, P, O, env, t, sh, regs[t], fcs[t], k + 1 == R.n_ticks);
+            if (fcs[0].still) {                       // (uniform) nobody moves: the registers carry over
+                for (int t = 0; t < CAP; t++) T::ph_carry_over(t, sh, regs[t], fcs[t]);
+            } else {
+                for (int t = 0; t < CAP; t++) T::ph_stage(g, t, sh, regs[t], fcs[t]);
+                if (k + 1 < R.n_ticks) for (int t = 0; t < CAP; t++) T::ph_reload(t, sh, regs[t]);
+            }
         }
         for (int t = 0; t < CAP; t++) B::ph_flush(P, env, t, sh);
     }
