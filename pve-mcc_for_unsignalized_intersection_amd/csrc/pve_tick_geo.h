@@ -293,11 +293,25 @@ template <int CAP> struct TickGeo {
             const int o3 = c8 ? (c4 ? (c2 ? pb[15] : pb[13]) : (c2 ? pb[11] : pb[9]))
                               : (c4 ? (c2 ? pb[7] : pb[5]) : (c2 ? pb[3] : pb[1]));
             const int rt = (c8 ? 8 : 0) + (c4 ? 4 : 0) + (c2 ? 2 : 0) + ((q >= o3) ? 1 : 0);
-            const int off = q - sh.pbase[rt], n = sh.tab.nl[rt];
-            const int i = (off * (int)sh.tab.ninv[rt]) >> 15, k = off - i * n;          // off / n, off % n (exact: off < 2048, n <= 10)
-            const int x = sh.ctl_by_route[sh.rbase[rt] + i], d = sh.tab.lst[rt][k];
-            double vo;
-            if (!member(g, sh, d, sh.tab.dir_lane[d], sh.tab.dir_index[d], x, vo)) continue;
+            // membership of the pair's vehicle x in list d = member() in straight-line form: x comes from route rt's segment
+            // of the route-sorted list, so its lane and intention are table entries of rt (no reads of the vehicle's own
+            // bytes), every table read is unconditional on a clamped index (batches of independent LDS reads instead of a
+            // chain of guarded ones), both outcomes are computed and selected
+            const int off = q - sh.pbase[rt], n = sh.tab.nl[rt], ni = (int)sh.tab.ninv[rt], rb = sh.rbase[rt];
+            const int lx = sh.tab.dir_lane[rt], ix = sh.tab.dir_index[rt];
+            const int i = (off * ni) >> 15, k = off - i * n;                            // off / n, off % n (exact: off < 2048, n <= 10)
+            const int x = sh.ctl_by_route[rb + i], d = sh.tab.lst[rt][k];
+            const double px = sh.p[x];
+            const int li = sh.tab.dir_lane[d], m = sh.tab.dir_index[d], kk = sh.tab.pos[d][rt], ty = sh.tab.dty[d];
+            const double inb_x = sh.tab.inbox[ix];
+            const double *ev = sh.tab.vd[ty][kk < 0 ? 0 : kk];
+            const double e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3], inb_m = sh.tab.inbox[m];
+            const double qd = px - inb_x;                                               // ref :251-252
+            const double delta = (px - e0) + e1;                                        // ref :453-660 / :733-803
+            const bool own = rt == d, same = lx == li;
+            const bool ok = own | (same ? (qd > 0) : ((kk >= 0) & (delta > 0)));       // ref :246-270
+            if (!ok) continue;
+            const double vo = own ? px : (same ? qd + inb_m : (delta + e2) - e3);
             if (COUNT) { lds_add(&sh.cnt2[d], 1); continue; }
             const int e = sh.lbase[d] + lds_claim(&sh.fill[d], 1);
             sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)x; sh.u_list[e] = (uint8_t)d;
