@@ -255,6 +255,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         T::ph_lock(c, t, sh, r);
         lds_barrier();
         T::ph_lock2(t, sh, r);
+        T::ph_keep_prefix(t, sh);
         lds_barrier();                                // (also what orders the previous tick's output stores before this tick's)
         PVE_PHASE_MARK(8)
         if constexpr (!ACT && !IDT) T::ph_park_action(t, sh, r);

@@ -253,6 +253,10 @@ template <int CAP, bool LJ = (CAP == 128)> struct Shared {
     {
         return K < 4 ? u_vd + (K + 1) * CAP : (K == SF_P ? u_vd : (K == SF_V ? v : a));
     }
+    // k_rollout, LOCK2 -> FIN: kept vehicles below every slot (index CAP: all of them), so that FIN's new lane starts and the
+    // dense threads' new slots are one read each instead of a two-word popcount; lives behind the 2 CAP ints of the EARLY
+    // staging in the sorted-list storage (dead since WALK)
+    PVE_HD uint8_t *keep_pre() { return DIRECT ? (uint8_t *)s_vd + 7 * CAP * 4 : (uint8_t *)s_idx + 2 * CAP * 4; }
     // FX -> LOCK: what FX decided about the reward of the vehicle in slot t (0 = keep, 1 = -10, 2 = +5), for the dense
     // thread that holds the reward; u_list[CAP ..) is free between RANK and the EARLY staging of FIN
     PVE_HD uint8_t *fxcode() { return u_list + CAP; }
@@ -1262,6 +1266,15 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             sh.lk_slot[e] = (uint8_t)t;
         }
     }
+    // k_rollout only (same phase as LOCK2; the delete votes are complete since the barrier behind FX)
+    static PVE_HD void ph_keep_prefix(int t, Sh &sh)
+    {
+        u64 keep[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) keep[k] = sh.m_alive[k] & ~sh.m_del[k];
+        sh.keep_pre()[t] = (uint8_t)mask_rank<NW>(keep, t);
+        if (t == 0) sh.keep_pre()[CAP] = (uint8_t)mask_count<NW>(keep);
+    }
     // the same two phases with everything per slot (general-geometry kernel: no dense mapping there)
     static PVE_HD void ph_lock_slot(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
@@ -1418,13 +1431,14 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         // ---- new lane starts
         int n_post;
         {
-            int ls12 = mask_below<NW>(keep, sh.hd.lane_start[NL]) + __builtin_popcount(sp);
+            int ls12 = (RES ? (int)sh.keep_pre()[sh.hd.lane_start[NL]] : mask_below<NW>(keep, sh.hd.lane_start[NL])) + __builtin_popcount(sp);
             n_post = ls12;
         }
         fc.new_slot = new_slot;
         fc.ls = 0; fc.sp_slot = -1; fc.sp_id = 0; fc.sp_vnum = 0;
         if (t <= NL) {
-            int ls = mask_below<NW>(keep, sh.hd.lane_start[t]) + __builtin_popcount(sp & ((1u << t) - 1u));
+            int ls = (RES ? (int)sh.keep_pre()[sh.hd.lane_start[t]] : mask_below<NW>(keep, sh.hd.lane_start[t])) +
+                     __builtin_popcount(sp & ((1u << t) - 1u));
             if (RES) fc.ls = ls; else gh.lane_start[t] = ls;
         }
         // ---- spawned vehicles (one per lane at most), ref :395-433
@@ -1519,7 +1533,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const int sl = r.ds;
             const size_t gd = (size_t)env * CAP + sl;                 // pre-compaction indexing, as above
             int ns = -1;
-            if (mask_test(keep, sl)) ns = mask_below<NW>(keep, sl) + __builtin_popcount(sp & ((1u << r.dlane) - 1u));
+            if (mask_test(keep, sl))
+                ns = (RES ? (int)sh.keep_pre()[sl] : mask_below<NW>(keep, sl)) + __builtin_popcount(sp & ((1u << r.dlane) - 1u));
             if (O.reward) O.reward[gd] = r.reward;
             if (adst) *adst = ns;
             // the 6 neighbours' speed, acceleration, lane and lane start: two batches of unconditional LDS gathers on clamped

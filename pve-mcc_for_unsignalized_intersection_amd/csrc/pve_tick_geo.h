@@ -42,7 +42,7 @@ template <int CAP> struct SharedGeo {
     static constexpr bool DIRECT = false;   // (walk_window: sorted lists are index arrays into the entries)
     static constexpr bool HAS_LJ = false;   // (no room for the lane << 16 | j words at 10 workgroups per CU)
     static constexpr bool DENSE = false;    // every phase per slot (the 12-lane kernels run the controlled-vehicle phases on a dense mapping)
-    static constexpr bool PIN_READS = false;
+    static constexpr bool PIN_READS = false;  // (walk_window's pinned reads: no gain here, measured)
     union {                                 // p1 / v1 die at the barrier after S3, the lists are born after it
         struct { double p1[CAP], v1[CAP]; };
         double u_vd[PE];                    // entry pool; LOCK2 re-uses [0, CAP) as the dead-lock scratch (records by rank)

@@ -93,6 +93,7 @@ template <int CAP> static void emu_rollout(const Const &c, const Params &P, cons
             }
             for (int t = 0; t < CAP; t++) T::ph_lock(c, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_keep_prefix(t, sh);
             if (!idt) for (int t = 0; t < CAP; t++) T::ph_park_action(t, sh, regs[t]);
             const Outputs O = T::tick_outputs(P, R, k);
             for (int t = 0; t < CAP; t++)
