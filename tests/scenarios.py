@@ -165,11 +165,11 @@ def _overflow_guard(b, fn):
         raise
 
 
-def symmetric_arrivals(n_envs, gap_s, rows, lane_groups):
+def symmetric_arrivals(n_envs, gap_s, rows, lane_groups, lane_num=12):
     """Arrival streams in which the lanes of a group spawn in the SAME tick (identical arrival times): while nobody steers
     them apart, vehicles of symmetric lanes keep identical positions, i.e. identical virtual distances in every list they
     share -- runs of 2 .. 4 equal keys in RANK (the claim / fix-up path) in every tick."""
-    out = np.full((n_envs, rows, 12), np.inf, dtype=np.float64)
+    out = np.full((n_envs, rows, lane_num), np.inf, dtype=np.float64)
     for e in range(n_envs):
         for g, lanes in enumerate(lane_groups):
             t = 1.0 + 0.3 * g + 0.7 * e + gap_s * np.arange(rows - 1)
@@ -313,14 +313,16 @@ def check_general_path_equals_fast_path(backend, n_envs=6, capacity=128, ticks=3
             batches_equal(bf, bg, "tick %d" % t)
 
 
-def check_geo_fuzz_vs_oracle(backend, lane_num, n_envs, capacity, ticks, rate, seed, action_scale=3.0, quantize=None):
+def check_geo_fuzz_vs_oracle(backend, lane_num, n_envs, capacity, ticks, rate, seed, action_scale=3.0, quantize=None,
+                             arrivals=None):
     """Random action tapes on a batch of 4- or 8-lane envs (own arrival + intention streams), fused ticks, every env
     against its own sequential oracle every tick: processing order, controlled set, neighbours, rewards,
     observations, collision counters, lock counts; full persistent state at the end."""
     from oracle.oracle_geo import OracleGeoEnv
     from pve_mcc_amd.arrivals import synthetic_intentions
     rng = np.random.default_rng(seed)
-    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed, lane_num=lane_num)
+    arr = arrivals if arrivals is not None else synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 30, seed=seed,
+                                                                   lane_num=lane_num)
     ch = synthetic_intentions(n_envs, arr.shape[1], seed=seed, lane_num=lane_num) if lane_num == 8 else None
     b = make_batch(arr, n_envs, capacity, backend, lane_num=lane_num, intentions=ch,
                    outputs=("obs_post", "obs_pre", "reward", "flags", "nbr", "env_out", "new_slot", "lanej"))

@@ -69,3 +69,13 @@ def test_emulated_step_many_geo_equals_single_ticks():
     scenarios.check_step_many_geo(BACKEND, 8, n_envs=3, chunks=(1, 7, 30, 3), trajectory_chunk=8)
     scenarios.check_step_many_geo(BACKEND, 4, n_envs=3, capacity=64, chunks=(1, 7, 40, 3), trajectory_chunk=8, quantize=1.0)
     scenarios.check_step_many_geo(BACKEND, 4, n_envs=2, capacity=128, chunks=(25, 30), trajectory_chunk=6)
+
+
+@pytest.mark.parametrize("lane_num,gap", [(8, 3.0), (4, 1.6)])
+def test_geo_symmetric_lanes_equal_distances(lane_num, gap):
+    """All lanes spawn in the same tick and nobody steers: runs of equal virtual distances in the per-route lists every
+    tick (RANK's claim / fix-up path of the general-geometry kernels) and symmetric collisions inside the box."""
+    arr = scenarios.symmetric_arrivals(2, gap_s=gap, rows=60, lane_groups=[list(range(lane_num))], lane_num=lane_num)
+    for scale, quant in ((0.0, None), (3.0, 3.0)):
+        scenarios.check_geo_fuzz_vs_oracle(BACKEND, lane_num, n_envs=2, capacity=128, ticks=260, rate=0.0, seed=13,
+                                           action_scale=scale, quantize=quant, arrivals=arr)

@@ -160,6 +160,15 @@ def test_gpu_step_many_symmetric_lanes_equal_distances():
     scenarios.check_step_many(BACKEND, "zero", n_envs=6, chunks=(1, 30, 90, 7, 120), trajectory_chunk=20, arrivals=arr)
 
 
+@pytest.mark.parametrize("lane_num,gap", [(8, 3.0), (4, 1.6)])
+def test_gpu_geo_symmetric_lanes_equal_distances(lane_num, gap):
+    """The same for the 4- / 8-lane layouts (per-route lists of k_tick_geo): all lanes spawn in the same tick."""
+    arr = scenarios.symmetric_arrivals(8, gap_s=gap, rows=70, lane_groups=[list(range(lane_num))], lane_num=lane_num)
+    for scale, quant in ((0.0, None), (3.0, 3.0)):
+        scenarios.check_geo_fuzz_vs_oracle(BACKEND, lane_num, n_envs=8, capacity=128, ticks=320, rate=0.0, seed=13,
+                                           action_scale=scale, quantize=quant, arrivals=arr)
+
+
 def test_gpu_fuzz_more_than_64_controlled_vehicles():
     """Dense traffic (1400 / 1500 veh/h/lane, gentle actions): more than 64 controlled vehicles per intersection, i.e. the
     second wave takes part in the dense-mapped phases; 16 envs vs 16 oracles every tick, no deferred spawn."""
