@@ -45,7 +45,7 @@ template <int CAP> struct SharedGeo {
     static constexpr bool PIN_READS = false;  // (walk_window's pinned reads: no gain here, measured)
     union {                                 // p1 / v1 die at the barrier after S3, the lists are born after it
         struct { double p1[CAP], v1[CAP]; };
-        double u_vd[PE];                    // entry pool; LOCK2 re-uses [0, CAP) as the dead-lock scratch (records by rank)
+        double u_vd[PE + 8];                // entry pool (+ the pad RANK's tail round may read); LOCK2 re-uses [0, CAP) as the dead-lock scratch (records by rank)
     };
     double s_vd[1];
     alignas(8) unsigned s_idx[PE];          // sorted position -> entry | tick tag << 16 (cf. Shared<128>, Tick::ph_rank)
@@ -256,11 +256,17 @@ template <int CAP> struct TickGeo {
         if (r.alive && r.ctl) sh.rk[t] = (uint8_t)lds_claim(&sh.rfill[r.route], 1);
         if (r.alive) {
             const int ls = sh.hd.lane_start[r.lane], le = sh.hd.lane_start[r.lane + 1];
-            int o = ls;
-            for (int k = 0; k < 3; k++) {
-                if (k < r.intent) o += mask_below<NW>(sh.m_int[k], le) - mask_below<NW>(sh.m_int[k], ls);
-                else if (k == r.intent) o += mask_below<NW>(sh.m_int[k], t) - mask_below<NW>(sh.m_int[k], ls);
+            // o = ls + (vehicles of the lane with a smaller intention) + (those with the same intention in the slots below t):
+            // the two masks are selected per lane and counted in straight-line form (a loop over the intentions with a
+            // branch per case runs every case for every wave that mixes intentions: ten two-word popcounts instead of three)
+            u64 mlt[NW], meq[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const u64 m0 = sh.m_int[0][w], m1 = sh.m_int[1][w], m2 = sh.m_int[2][w];
+                mlt[w] = r.intent == 0 ? 0ull : (r.intent == 1 ? m0 : (m0 | m1));
+                meq[w] = r.intent == 0 ? m0 : (r.intent == 1 ? m1 : m2);
             }
+            const int o = ls + (mask_below<NW>(mlt, le) - mask_below<NW>(mlt, ls)) + (mask_rank<NW>(meq, t) - mask_below<NW>(meq, ls));
             r.ord = o;
             sh.ord[t] = (int16_t)o;
             sh.slot_at[o] = (int16_t)t;
@@ -421,11 +427,11 @@ template <int CAP> struct TickGeo {
 #pragma unroll
                 for (int k = 0; k < 8; k++) pos += (w[k] < vd) ? 1 : 0;
             }
-            if (f < hi) {                                 // tail (< 8 entries): one more round of independent reads
-                const int n = hi - f;
+            if (f < hi) {                                 // tail (< 8 entries): one more round of independent reads; what lies
+                const int n = hi - f;                     // behind the list (the next list, unclaimed capacity, the pad) is masked
                 double w[7];
 #pragma unroll
-                for (int k = 0; k < 7; k++) w[k] = sh.u_vd[f + (k < n ? k : 0)];
+                for (int k = 0; k < 7; k++) w[k] = sh.u_vd[f + k];
 #pragma unroll
                 for (int k = 0; k < 7; k++) pos += (k < n) & (w[k] < vd);
             }
