@@ -232,9 +232,9 @@ template <int CAP, bool LJ = (CAP == 128)> struct Shared {
     double p[CAP], v[CAP + 1], a[CAP + 1];
     union {                          // p1/v1 die at the barrier after S3, the lists are born after it
         struct { double p1[CAP], v1[CAP]; };   // step outcome "if braking" (S1-S3 only)
-        double u_vd[POOL];           // virtual distance of every list entry (segment order)
+        double u_vd[POOL];           // virtual distance of every list entry (segment order); RANK's tail round may read up to 6
     };
-    double virdis[CAP];
+    double virdis[CAP];              // doubles past the pool, i.e. into this array (masked): it must stay the next member
     int cnt[CAP];                    // collision hits received: early | late << 16
     // sorted position -> entry | tick tag << 16: RANK claims a position with one exchange and learns from the tag it gets
     // back whether an entry with the SAME distance was there first (ph_rank); readers take the low half
@@ -808,11 +808,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 pos += (w0 < vd) + (w1 < vd) + (w2 < vd) + (w3 < vd) + (w4 < vd) + (w5 < vd) + (w6 < vd) + (w7 < vd);
                 if (Sh::DIRECT) eq += (w0 == vd) + (w1 == vd) + (w2 == vd) + (w3 == vd) + (w4 == vd) + (w5 == vd) + (w6 == vd) + (w7 == vd);
             }
-            if (f < hi) {                                 // tail (< 8 entries): one more round of independent reads,
-                const int n = hi - f;                     // out-of-range lanes re-read entry f and are masked out
-                double w[7];
+            if (f < hi) {                                 // tail (< 8 entries): one more round of independent reads of
+                const int n = hi - f;                     // CONSECUTIVE entries; what lies behind the list is masked out (the
+                double w[7];                              // last list may run up to 6 doubles into `virdis`, the next member)
+                const double *uv = sh.u_vd;
 #pragma unroll
-                for (int k = 0; k < 7; k++) w[k] = sh.u_vd[f + (k < n ? k : 0)];
+                for (int k = 0; k < 7; k++) w[k] = uv[f + k];
 #pragma unroll
                 for (int k = 0; k < 7; k++) { pos += (k < n) & (w[k] < vd); if (Sh::DIRECT) eq += (k < n) & (w[k] == vd); }
             }
