@@ -24,10 +24,14 @@
 
 namespace pve {
 
+#ifndef PVE_GEO_ZROW
+#define PVE_GEO_ZROW 1
+#endif
+
 template <int CAP> struct SharedGeo {
     static constexpr int NW = CAP / 64;
     EnvHeader hd;
-    double p[CAP], v[CAP], a[CAP];
+    double p[CAP], v[CAP + 1], a[CAP + 1];  // cell CAP of v / a / lane_of / route_of: a vehicle that is not there (zeros, cf. Shared)
     double virdis[CAP];
     double red_reward[NW], red_jerk[NW];
     // Virtual-lane lists (ref :240-270), one per route: list d = [lbase[d], lbase[d] + fill[d]) of the entry pool; an
@@ -84,7 +88,7 @@ template <int CAP> struct SharedGeo {
     int cnt[CAP];
     int acc_passed_steps, acc_collisions, lead_n, emu_scan, emu_scan2, emu_scan3;
     alignas(8) int16_t hdr[CAP], cyc_off[CAP], ord[CAP], slot_at[CAP];
-    uint8_t bb[CAP], rew_ovr[CAP], lane_of[CAP], route_of[CAP], intent_of[CAP], lk_slot[CAP];
+    uint8_t bb[CAP], rew_ovr[CAP], lane_of[CAP + 1], route_of[CAP + 1], intent_of[CAP], lk_slot[CAP];
     u64 m_alive[NW], m_ctl[NW], m_del[NW], m_fin[NW], m_ctlnow[NW], m_lead[NW], m_coll[NW], m_keep[NW], m_spawn[NW];
     u64 m_int[3][NW];                // alive slots by intention
     u64 m_ctl_ord[NW];               // "controlled" flags in processing order
@@ -185,7 +189,10 @@ template <int CAP> struct TickGeo {
             r.seq = P.i32[I_SEQ][gi]; r.vnum = P.i32[I_VNUM][gi]; r.count = P.i32[I_COUNT][gi];
         }
         sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
-        if (t == 0) { sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0; }
+        if (t == 0) {
+            sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0;
+            sh.v[CAP] = 0; sh.a[CAP] = 0; sh.lane_of[CAP] = 0; sh.route_of[CAP] = 0;      // the zero cell (FIN's absent neighbours)
+        }
         if (t < ND) { sh.rc[t] = 0; sh.rfill[t] = 0; sh.fill[t] = 0; sh.cnt2[t] = 0; }
     }
 
@@ -957,10 +964,11 @@ template <int CAP> struct TickGeo {
         if (r.alive && r.ctl && (O.nbr || O.obs_pre || (O.obs_post && new_slot >= 0))) {
             // the 6 neighbours' speed, acceleration, lane and route, then their lane starts: two batches of unconditional LDS
             // gathers on clamped slots (a guarded block per neighbour is a chain of six round trips), shared by the ids and the row
+            constexpr bool ZROW = RES && PVE_GEO_ZROW;   // (the single-tick kernel at 96 VGPR would spill the longer live ranges)
             int xc[NNB], nln[NNB], nrt[NNB], nls[NNB]; double nv[NNB], na[NNB];
 #pragma unroll
             for (int k = 0; k < NNB; k++) {
-                xc[k] = r.kr[k] < 0 ? 0 : r.kr[k];
+                xc[k] = r.kr[k] < 0 ? (ZROW ? CAP : 0) : r.kr[k];
                 nln[k] = (int)sh.lane_of[xc[k]]; nrt[k] = (int)sh.route_of[xc[k]];
                 nv[k] = sh.v[xc[k]]; na[k] = sh.a[xc[k]];
             }
@@ -981,8 +989,9 @@ template <int CAP> struct TickGeo {
 #pragma unroll
             for (int k = 0; k < NNB; k++) {
                 const bool has = r.kr[k] >= 0;
-                row[4 + 4 * k] = has ? r.kv[k] : 0.0; row[5 + 4 * k] = has ? nv[k] : 0.0;
-                row[6 + 4 * k] = has ? na[k] : 0.0; row[7 + 4 * k] = has ? (double)nrt[k] : 0.0;
+                // (absent neighbour: the scan left kv = 0, the gathers came from the zero cell)
+                row[4 + 4 * k] = (ZROW || has) ? r.kv[k] : 0.0; row[5 + 4 * k] = (ZROW || has) ? nv[k] : 0.0;
+                row[6 + 4 * k] = (ZROW || has) ? na[k] : 0.0; row[7 + 4 * k] = (ZROW || has) ? (double)nrt[k] : 0.0;
             }
             if (O.obs_pre) {
                 double *o = O.obs_pre + gpre * OBSW;
