@@ -236,7 +236,7 @@ template <int CAP> struct TickGeo {
         r.ord = t;
         // list capacities, route-sorted controlled vehicles and pair counts: three prefix sums over the 16 routes / lists
         // in the first 16 lanes (rc is complete: barrier behind S1)
-        {
+        if (t < 64) {                                     // (uniform per wave: the other waves skip the sums and scans)
             int cap = 0, rcv = 0, prs = 0;
             if (t < ND) {
                 const unsigned mr = sh.tab.mroutes[t];
