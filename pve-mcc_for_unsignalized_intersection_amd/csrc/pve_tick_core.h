@@ -123,7 +123,13 @@ PVE_HD int lds_claim(int *p, int n)  // reserves n consecutive units, returns th
 PVE_HD unsigned lds_xchg(unsigned *p, unsigned v)   // stores v, returns what was there
 {
 #if PVE_DEVICE_CODE
-    return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // RANK relies on the order "own stores, then the claim, then the fix-up stores" as the LDS sees it: the hardware keeps a
+    // wave's LDS operations in program order, the two compiler fences keep the program order what the source says (a relaxed
+    // atomic alone would let the compiler move plain stores to other addresses across it); no wait is emitted for them
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    const unsigned o = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    return o;
 #else
     const unsigned o = *p; *p = v; return o;
 #endif
