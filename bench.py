@@ -114,14 +114,36 @@ def cpu_baseline(arr, pool, cap, lane_num=12, choice=None, id_sin=False):
                        "workload and action pool, %d threads, %.2f s wall" % (n, CPU_TICKS, CPU_WARM, min(cores, n), dt))
 
 
+KNOBS = ("PVE_NO_ROLLOUT_KERNEL", "PVE_NO_ROLLOUT_ACTOR", "PVE_ROLLOUT_WPE5", "PVE_ROLLOUT_GEO_WPE5", "PVE_ACTOR_GRID",
+         "PVE_LIBRARY_PATH", "PVE_NO_PERSISTENT")
+
+
 def csrc_sha():
-    """Fingerprint of the kernel sources: a committed PMC traffic figure only applies to the build it was measured on."""
-    d = os.path.join(ROOT, "pve-mcc_for_unsignalized_intersection_amd", "csrc")
+    """Fingerprint of the BUILD the committed counter figures apply to: the kernel sources, the Makefile (= the default
+    compiler flags) and the flags the library next to the package was actually built with (csrc/Makefile records them in
+    libpveenv.flags; `make EXTRA=...` variants therefore get another fingerprint).  None when a launch / library knob of
+    the A-B tooling is set in the environment: such a run measures another kernel than the profiled one."""
+    if any(os.environ.get(k) for k in KNOBS):
+        return None
+    pkg = os.path.join(ROOT, "pve-mcc_for_unsignalized_intersection_amd")
+    d = os.path.join(pkg, "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip", ".inc")):
+        if f.endswith((".h", ".hip", ".inc")) or f == "Makefile":
             h.update(open(os.path.join(d, f), "rb").read())
+    flags = os.path.join(pkg, "libpveenv.flags")
+    if os.path.isfile(flags):
+        h.update(b"flags:" + open(flags, "rb").read().strip())
     return h.hexdigest()[:16]
+
+
+def _latest_profile(pattern):
+    """The newest profiles/rNN_<pattern> (files whose name does not start with rNN_ are ignored)."""
+    import glob
+    import re
+    files = [(int(m.group(1)), f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_" + pattern))
+             for m in [re.match(r"r(\d+)_", os.path.basename(f))] if m]
+    return max(files)[1] if files else None
 
 
 def pmc_traffic(envs_per_launch, cap, outputs, mode, ticks_per_launch, other):
@@ -129,40 +151,36 @@ def pmc_traffic(envs_per_launch, cap, outputs, mode, ticks_per_launch, other):
     Counters cannot be read from inside the process, so they come from the committed rocprofv3 passes of this very
     command (tools/collect_profiles.sh -> profiles/r*_traffic.json); null unless kernel sources, config and launch
     shape are the profiled ones."""
-    import glob
-    import re
     default_outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
-    if other or cap != 128 or tuple(outputs) != default_outputs:
+    sha = csrc_sha()
+    if other or cap != 128 or tuple(outputs) != default_outputs or sha is None:
         return None, None
-    files = glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))
-    if not files:
+    f = _latest_profile("traffic.json")
+    if not f:
         return None, None
-    files.sort(key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)))
-    j = json.load(open(files[-1]))
+    j = json.load(open(f))
     t = j.get("%s%d" % (mode, ticks_per_launch)) or j.get(mode)      # (a launch shape of its own, e.g. rollout5, else the mode's)
-    if not t or int(t.get("envs_per_launch", 4096)) != envs_per_launch or t.get("csrc_sha") != csrc_sha() \
+    if not t or int(t.get("envs_per_launch", 4096)) != envs_per_launch or t.get("csrc_sha") != sha \
             or int(t.get("ticks_per_launch", 1)) != ticks_per_launch:
         return None, None
-    return t, os.path.relpath(files[-1], ROOT)
+    return t, os.path.relpath(f, ROOT)
 
 
 def binding_profile(mode, ticks_per_launch, cap, other):
     """What actually binds the dominant kernel (it is not bandwidth): instruction counts per wave and tick, LDS bank
     conflicts and wait share from the committed SQ counter passes of this very build (profiles/r*_binding.json,
     tools/collect_profiles.sh); null unless the kernel sources are the profiled ones."""
-    import glob
-    import re
-    if other or cap != 128:
+    sha = csrc_sha()
+    if other or cap != 128 or sha is None:
         return None, None
-    files = glob.glob(os.path.join(ROOT, "profiles", "r*_binding.json"))
-    if not files:
+    f = _latest_profile("binding.json")
+    if not f:
         return None, None
-    files.sort(key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)))
-    j = json.load(open(files[-1]))
+    j = json.load(open(f))
     t = j.get("%s%d" % (mode, ticks_per_launch)) or j.get(mode)
-    if not t or t.get("csrc_sha") != csrc_sha() or int(t.get("ticks_per_launch", 1)) != ticks_per_launch:
+    if not t or t.get("csrc_sha") != sha or int(t.get("ticks_per_launch", 1)) != ticks_per_launch:
         return None, None
-    return t, os.path.relpath(files[-1], ROOT)
+    return t, os.path.relpath(f, ROOT)
 
 
 def verify_against_oracle(locate, last_outputs, arr, pool_np, total_ticks, lane_num, choice, n_sample=VERIFY_ENVS, table_np=None):

@@ -398,7 +398,9 @@ class BatchedIntersections:
     def prepare_step_many(self, n_ticks, source=None, chunk=0):
         """A prepared pve_step_many call (trajectory=False): everything the call needs is built once; the returned callable
         re-issues it (only the position in the action pool advances) at the cost of one ctypes call -- for loops whose host
-        side is measured in microseconds (RL inner loops, bench.py's timed region)."""
+        side is measured in microseconds (RL inner loops, bench.py's timed region).  The prepared call keeps the pool / table
+        tensor it was built on alive and refuses to run (PveError) once set_action_pool / set_action_table has replaced
+        the source of ITS kind; a batch without a stream of its own re-binds torch's current stream on every call."""
         n_ticks = int(n_ticks)
         if source is None:
             source = "pool" if getattr(self, "_pool", None) is not None else "zero"
@@ -422,14 +424,22 @@ class BatchedIntersections:
         self._bind_stream()
         o = self._outputs_struct(flip_obs=False)
         fn, h, pro, po, n_pool = self.lib.pve_step_many, self._h, C.byref(ro), C.byref(o), max(1, int(ro.n_pool))
+        src_attr = {"pool": "_pool", "table": "_table"}.get(source)
+        src_tensor = getattr(self, src_attr) if src_attr else None
+        follow_stream = self._stream_obj is None
 
         def call():
+            if src_attr is not None and getattr(self, src_attr) is not src_tensor:
+                raise PveError("prepared step_many call is stale: the action %s was replaced after prepare_step_many"
+                               % source)
+            if follow_stream:
+                self._bind_stream()
             ro.pool_tick0 = self.ticks % n_pool
             rc = fn(h, pro, po)
             if rc != 0:
                 check(self.lib, rc, "pve_step_many")
             self.ticks += n_ticks
-        call._keep = (ro, o)
+        call._keep = (ro, o, src_tensor)
         return call
 
     def scene_update(self, actions=None):

@@ -612,6 +612,9 @@ struct Backend {
         if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
         static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
         const bool train = P.out.obs_pre || P.out.state_pre;
+        // the phase-cycle diagnostics exist for the default kernel only: every other variant (table, actor, training outputs)
+        // answers "no resident kernel" and the caller falls back to per-tick launches, which record the cycles
+        if (train && P.phase_cycles) return 1;
         if (R.source == 3) {                                                  // PVE_SRC_TABLE
             if (train || P.phase_cycles) return 1;
             if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);

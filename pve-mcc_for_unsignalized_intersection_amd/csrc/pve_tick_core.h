@@ -120,18 +120,28 @@ PVE_HD int lds_claim(int *p, int n)  // reserves n consecutive units, returns th
     int o = *p; *p += n; return o;
 #endif
 }
+// RANK's claim protocol (ph_rank): "own stores, then the claim, then the fix-up stores".  Under the HIP memory model the claim
+// is an acquire-release exchange at workgroup scope and every store that can meet another wave's store to the same word
+// (the owner's mypos / s_slot, the fix-up rewrites of s_idx / s_slot / mypos) is a relaxed ATOMIC store: whoever gets the
+// current tag back synchronises with every earlier claimant of that position (release sequence of the exchanges), so an
+// owner's stores before its claim happen-before the fix-up stores of a later claimant, and two fix-ups of the same run write
+// the same values, whatever their order.  No plain access races with them (the readers sit behind the phase barrier).
+// On gfx950 outside threadgroup-split mode this costs one `s_waitcnt lgkmcnt(0)` in front of the ds_wrxchg_rtn_b32 (the
+// one behind it is needed for the returned word anyway); the stores compile to the same ds_write_b8 / b16 / b32.
 PVE_HD unsigned lds_xchg(unsigned *p, unsigned v)   // stores v, returns what was there
 {
 #if PVE_DEVICE_CODE
-    // RANK relies on the order "own stores, then the claim, then the fix-up stores" as the LDS sees it: the hardware keeps a
-    // wave's LDS operations in program order, the two compiler fences keep the program order what the source says (a relaxed
-    // atomic alone would let the compiler move plain stores to other addresses across it); no wait is emitted for them
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    const unsigned o = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    return o;
+    return __hip_atomic_exchange(p, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
     const unsigned o = *p; *p = v; return o;
+#endif
+}
+template <class T> PVE_HD void lds_store_relaxed(T *p, T v)
+{
+#if PVE_DEVICE_CODE
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    *p = v;
 #endif
 }
 // sorted position -> entry: the low half of a tagged word (Shared<128>, see ph_rank) or a plain 16-bit index (SharedGeo)
@@ -831,7 +841,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 sh.s_vd[lo + pos] = vd; sh.s_slot[lo + pos] = (uint8_t)myslot;
                 if (e - lo < nown) sh.mypos[myslot] = (uint8_t)pos;
             } else {
-                if (e - lo < nown) sh.mypos[myslot] = (uint8_t)pos;               // (before the claim: a fix-up comes after it)
+                if (e - lo < nown) lds_store_relaxed(&sh.mypos[myslot], (uint8_t)pos);   // (before the claim -- released by it: a fix-up comes after it)
                 const unsigned old = lds_xchg(&sh.s_idx[Sh::DIRECT ? 0 : lo + pos], tag | (unsigned)e);
                 if ((old & 0xFFFF0000u) == tag) {         // somebody with the same distance was here first (or a stale word)
                     for (f = lo; f < hi; f++) {
@@ -839,8 +849,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                         const int sf = sh.u_slot[f];
                         int rk = 0;
                         for (int g = lo; g < hi; g++) rk += (sh.u_vd[g] == vd && sh.u_slot[g] < sf) ? 1 : 0;
-                        sh.s_idx[Sh::DIRECT ? 0 : lo + pos + rk] = tag | (unsigned)f;
-                        if (f - lo < nown) sh.mypos[sf] = (uint8_t)(pos + rk);
+                        lds_store_relaxed(&sh.s_idx[Sh::DIRECT ? 0 : lo + pos + rk], tag | (unsigned)f);
+                        if (f - lo < nown) lds_store_relaxed(&sh.mypos[sf], (uint8_t)(pos + rk));
                     }
                 }
             }

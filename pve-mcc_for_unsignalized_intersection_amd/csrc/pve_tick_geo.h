@@ -442,8 +442,8 @@ template <int CAP> struct TickGeo {
 #pragma unroll
                 for (int k = 0; k < 7; k++) pos += (k < n) & (w[k] < vd);
             }
-            sh.s_slot[lo + pos] = (uint8_t)slot;
-            if (d == sh.route_of[slot]) sh.mypos[slot] = (int16_t)pos;            // the vehicle's own entry (vd = p)
+            lds_store_relaxed(&sh.s_slot[lo + pos], (uint8_t)slot);               // (relaxed atomics released by the claim: Tick::ph_rank)
+            if (d == sh.route_of[slot]) lds_store_relaxed(&sh.mypos[slot], (int16_t)pos);   // the vehicle's own entry (vd = p)
             const unsigned old = lds_xchg(&sh.s_idx[lo + pos], tag | (unsigned)e);
             if ((old & 0xFFFF0000u) == tag) {             // an entry with the same distance was here first (or a stale word)
                 for (f = lo; f < hi; f++) {
@@ -451,9 +451,9 @@ template <int CAP> struct TickGeo {
                     const int sf = sh.u_slot[f];
                     int rk = 0;
                     for (int g = lo; g < hi; g++) rk += (sh.u_vd[g] == vd && sh.u_slot[g] < sf) ? 1 : 0;
-                    sh.s_idx[lo + pos + rk] = tag | (unsigned)f;
-                    sh.s_slot[lo + pos + rk] = (uint8_t)sf;
-                    if (d == sh.route_of[sf]) sh.mypos[sf] = (int16_t)(pos + rk);
+                    lds_store_relaxed(&sh.s_idx[lo + pos + rk], tag | (unsigned)f);
+                    lds_store_relaxed(&sh.s_slot[lo + pos + rk], (uint8_t)sf);
+                    if (d == sh.route_of[sf]) lds_store_relaxed(&sh.mypos[sf], (int16_t)(pos + rk));
                 }
             }
         }

@@ -108,6 +108,19 @@ def test_emulated_prepared_step_many_equals_step_many():
         live = a.state_field("meta").numpy() != 0
         assert np.array_equal(x[live], y[live]), k
     assert a.ticks == 42 and all(sub.ticks == 42 for sub in b.subs)
+    # a prepared call holds the address of the pool it was built on: replacing the pool must make it refuse, not read
+    # recycled memory; a call prepared on another source kind is unaffected
+    import pytest as _pytest
+    from pve_mcc_amd._capi import PveError
+    g = a.prepare_step_many(3)
+    z = a.prepare_step_many(2, source="zero")
+    assert g._keep[2] is a._pool
+    a.set_action_pool(pool.clone())
+    with _pytest.raises(PveError, match="stale"):
+        g()
+    z()
+    a.prepare_step_many(3)()
+    assert a.ticks == 47
 
 
 def test_emulated_step_many_table_source_equals_single_ticks():
