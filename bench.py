@@ -242,6 +242,143 @@ def verify_against_oracle(locate, last_outputs, arr, pool_np, total_ticks, lane_
     return res
 
 
+ACTION_TOL = 5e-4       # |a_device - a_numpy| on actions in [-3, 3]: two float32 evaluation orders (tests/actor_scenarios.py)
+STATE_FIELDS = ("p", "v", "a", "jerk", "jerk_sum", "vir_dis", "closer_p", "id", "seq", "vnum", "step", "count", "meta", "hdr")
+
+
+def verify_closed_loop(torch, dev, locate, arr, total_ticks, cap, obs_dtype, weights, n_sample=2 * VERIFY_ENVS):
+    """Closed loop (BASELINE config 5), outside the timed region: `n_sample` of the envs this rank just timed are replayed
+    from reset on the GPU as ONE small batch in the two-launch form (step_with_actor: actor kernel + tick kernel per tick,
+    whose tick is the kernel the oracle certifies) for the same number of ticks.  The timed path (the actor inside the
+    resident kernel) and the replay run the same float32 actor routine on the same rows, so the persistent state of every
+    live slot and the observation rows of the controlled vehicles must be BIT-equal; then the actions the device computes
+    on those final rows are held against the NumPy restatement of the actor (oracle/actor_np.py, the checker) at the
+    action-level bar.  A trajectory-level oracle does not exist for the closed loop: the NumPy actor's float32 round-off
+    (1e-7) is amplified ~270x over 400 ticks.  -> dict(verified=bool, ...)."""
+    import pve_mcc_amd
+    from oracle.actor_np import actor_forward
+    n_envs = arr.shape[0]
+    sample = sorted(set(np.linspace(0, n_envs - 1, n_sample).astype(int).tolist()))
+    res = dict(verified=True, envs=sample, ticks_replayed=int(total_ticks), action_tol=ACTION_TOL,
+               checker="the same streams as a %d-env batch in the two-launch form (k_actor_h + k_tick per tick) on the GPU, bit for "
+                       "bit; actions on the final rows vs oracle/actor_np.py" % len(sample),
+               compared="every persistent field of every live slot + observation rows of the controlled vehicles (exact); "
+                        "actor actions on those rows (|da| <= %g)" % ACTION_TOL)
+    if total_ticks < 1:
+        res.update(verified=None, reason="no tick executed")
+        return res
+    small = pve_mcc_amd.BatchedIntersections(len(sample), cap, arr[sample], device=dev, obs_dtype=obs_dtype,
+                                             outputs=("obs_post", "reward", "flags", "env_out"))
+    small.reset()
+    small.set_actor(weights)
+    for _ in range(int(total_ticks)):
+        small.step_with_actor()
+    torch.cuda.synchronize(dev)
+    try:
+        meta_s = small.state_field("meta")
+        for i, e in enumerate(sample):
+            b, le = locate(e)
+            live = meta_s[i] != 0
+            assert torch.equal(b.state_field("meta")[le] != 0, live), "env %d: alive slots differ from the two-launch replay" % e
+            for f in STATE_FIELDS:
+                assert torch.equal(b.state_field(f)[le][live], small.state_field(f)[i][live]), \
+                    "env %d: field %s differs from the two-launch replay" % (e, f)
+            ctl = live & ((meta_s[i] & 1) != 0)
+            assert torch.equal(b.obs[le][ctl], small.obs[i][ctl]), "env %d: observation rows differ from the two-launch replay" % e
+        a_dev = small.act().cpu().numpy()
+        ctl = (meta_s.cpu().numpy() & 1) != 0
+        a_np = actor_forward(weights, small.obs.cpu().numpy()).astype(np.float64)
+        worst = float(np.abs(a_dev - a_np)[ctl].max()) if ctl.any() else 0.0
+        res.update(controlled_rows=int(ctl.sum()), max_action_diff=worst)
+        assert ctl.any(), "no controlled vehicle in the sample"
+        assert worst <= ACTION_TOL, "actor actions differ from the NumPy restatement by %.3e" % worst
+    except AssertionError as ex:
+        res.update(verified=False, mismatch=str(ex))
+    small.close()
+    return res
+
+
+def actor_weights():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "actor_66.npz"))
+    return {k: z[k] for k in z.files}       # the reference's pretrained actor (model_data/baseline/66.cptk)
+
+
+def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
+    """A second BASELINE configuration timed OUTSIDE the headline region, on envs of its own, with the headline's protocol
+    in small (300 un-timed prefill ticks, W warm-up ticks, exactly K timed ticks between synchronisations, the launch
+    shape the headline would use at this K) -- so that the driver's single `bench.py` line carries driver-timed numbers
+    for them as well:
+      closed_loop: BASELINE config 5 -- 4096 x 128, the MADDPG actor inside the resident kernel (pve_step_many(PVE_SRC_ACTOR)),
+                   float32 rows, 1000 veh/h/lane; verified by verify_closed_loop;
+      cap64:       BASELINE config 2 -- 4096 x 64, the slot-indexed sin pool, 350 veh/h/lane (500 overflows 64 slots, DESIGN 5);
+                   verified by the oracle replay (verify_against_oracle)."""
+    import pve_mcc_amd
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    closed = kind == "closed_loop"
+    cap, rate = (128, 1000.0) if closed else (64, 350.0)
+    prefill = PREFILL_MIN
+    seed = 20250213 + (104729 if closed else 1299709) + rank * n_envs
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=(prefill + W + K) * 0.1 + 20.0, seed=seed, lane_num=12)
+    obs_dtype = torch.float32 if closed else torch.float64
+    outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
+    env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=2, device=dev, outputs=outputs, obs_dtype=obs_dtype)
+    chunk = (25 if K >= 100 else 5) if cap == 128 else 0
+    env.reset()
+    pool_np, w = None, None
+    if closed:
+        w = actor_weights()
+        env.set_actor(w)
+
+        def run(n):
+            if n > 0:
+                env.step_many(n, actor=True, chunk=chunk)
+    else:
+        pool_np = action_pool(n_envs, cap, seed=1234 + rank)
+        env.set_action_pool(torch.as_tensor(pool_np, device=dev))
+        calls = {n: env.prepare_step_many(n, chunk=chunk) for n in {prefill, W, K} if n > 0}
+
+        def run(n):
+            if n > 0:
+                calls[n]()
+    run(prefill)
+    run(W)
+    torch.cuda.synchronize(dev)
+    m0 = env.metrics()
+    t0 = time.perf_counter()
+    run(K)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    m1 = env.metrics()
+    total = prefill + W + K
+
+    def locate(e):
+        k, le = env.sub_of(e)
+        return env.subs[k], le
+    if not verify:
+        ver = dict(verified=None, reason="skipped (--no-verify)")
+    elif closed:
+        ver = verify_closed_loop(torch, dev, locate, arr, total, cap, obs_dtype, w)
+    else:
+        ver = verify_against_oracle(locate, lambda e: {n: locate(e)[0].out[n][locate(e)[1]].cpu().numpy() for n in ("flags", "reward", "env_out")},
+                                    arr, pool_np, total, 12, None)
+    b_nom = B_ALG_OBS_F32 if closed else B_ALG_FP64
+    tpl = chunk if chunk > 0 else K
+    b_alg = b_nom - (B_STATE_IN + B_STATE_OUT) * (1.0 - 1.0 / tpl)
+    res = {"what": ("BASELINE config 5: %d x %d, 1000 veh/h/lane, MADDPG actor (pretrained 66.cptk weights) inside the resident "
+                    "kernel, float32 rows, pve_step_many(PVE_SRC_ACTOR)" if closed else
+                    "BASELINE config 2: %d x %d, slot-indexed sin pool, 350 veh/h/lane (BASELINE.md's 500 overflows 64 slots in "
+                    "4096 envs: DESIGN.md 5)") % (n_envs, cap),
+           "ms_per_step": dt / K * 1e3, "value": float(cap) * n_envs * K / dt, "unit": "env-steps/s", "steps": K, "warmup": W,
+           "prefill_ticks": prefill, "ticks_per_launch": tpl, "sub_batches": 2,
+           "verified": ver["verified"], "verification": ver,
+           "overflow": m1["overflow"], "mean_alive_per_env": (m1["alive_steps"] - m0["alive_steps"]) / float(K * n_envs),
+           "mean_ctl_per_env": (m1["ctl_steps"] - m0["ctl_steps"]) / float(K * n_envs),
+           "hbm_frac": b_alg * cap * n_envs / (dt / K) / 1e9 / HBM_PEAK_GBS}
+    del env
+    torch.cuda.empty_cache()
+    return res
+
+
 def self_launch(args_list, n):
     """--gpus N without an outer torchrun: start the N ranks as a child process group (this process has not touched the
     GPU), forward stdout (rank 0's JSON line) and return the children's exit code."""
@@ -424,9 +561,7 @@ def main(argv=None, env_factory=None):
     env.reset()
     sub_streams = getattr(env, "streams", None) if not emu else None
     if args.actor:
-        wpath = os.path.join(ROOT, "tests", "golden", "actor_66.npz")
-        z = np.load(wpath)
-        env.set_actor({k: z[k] for k in z.files})       # the reference's pretrained actor (model_data/baseline/66.cptk)
+        env.set_actor(actor_weights())
     if mode == "rollout" and not args.actor:
         if id_sin:
             env.set_action_table(torch.as_tensor(table_np))
@@ -556,17 +691,19 @@ def main(argv=None, env_factory=None):
 
     # ---- self-check, outside the timed region: the envs that were timed against the CPU oracle
     verify = dict(verified=None, reason="skipped (--no-verify)")
-    if args.actor:
-        verify = dict(verified=None, reason="closed loop: the actor's float32 actions have an action-level bar only "
-                                            "(tests/actor_scenarios.py), no trajectory-level oracle")
-    elif not args.no_verify:
-        subs = getattr(env, "subs", None)
+    subs = getattr(env, "subs", None)
 
-        def locate(e):
-            if subs is None:
-                return env, e
-            k, le = env.sub_of(e)
-            return subs[k], le
+    def locate(e):
+        if subs is None:
+            return env, e
+        k, le = env.sub_of(e)
+        return subs[k], le
+    if args.actor and not args.no_verify and not emu and lane_num == 12:
+        sync()
+        verify = verify_closed_loop(torch, dev, locate, arr, tick[0], cap, obs_dtype, actor_weights())
+    elif args.actor:
+        verify = dict(verified=None, reason="closed loop: skipped (--no-verify) or no GPU replay available")
+    elif not args.no_verify:
 
         def last_outputs(e):
             b, le = locate(e)
@@ -622,7 +759,15 @@ def main(argv=None, env_factory=None):
         tape_id_sin = {"what": "the same envs continued for %d ticks under BASELINE.md 3's tape a = float32(sin(0.37 id + 0.05 tick)) by "
                                "vehicle id (pve_step_many(PVE_SRC_TABLE)); not part of the verified region" % K,
                        "ms_per_step": ti / K * 1e3, "value": float(cap) * n_envs * K / ti, "unit": "env-steps/s", "steps": K}
-    ok_flag = 0.0 if verify["verified"] is False else 1.0
+    # ---- BASELINE configs 5 and 2 beside the headline (config 3), each on envs of its own, timed outside the headline region
+    closed_loop = cap64 = None
+    if mode == "rollout" and not id_sin and not traj_on and not args.actor and not emu and world == 1 and lane_num == 12 \
+            and cap == 128 and not args.no_companion and K > 0:
+        del env
+        torch.cuda.empty_cache()
+        closed_loop = run_companion(torch, dev, "closed_loop", K, W, rank, n_envs, verify=not args.no_verify)
+        cap64 = run_companion(torch, dev, "cap64", K, W, rank, n_envs, verify=not args.no_verify)
+    ok_flag = 0.0 if (verify["verified"] is False or any(c and c["verified"] is False for c in (closed_loop, cap64))) else 1.0
     if world > 1:
         tv = torch.tensor([ok_flag], dtype=torch.float64, device=dev)
         dist.all_reduce(tv, op=dist.ReduceOp.MIN)
@@ -686,6 +831,7 @@ def main(argv=None, env_factory=None):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "synthetic (injected test environment: timings meaningless)",
             "verified": verify["verified"], "verification": verify,
             "retained_outputs": companion, "tape_id_sin": tape_id_sin,
+            "closed_loop": closed_loop, "cap64": cap64,
             "config": {"workload": "%d parallel %d-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
@@ -745,7 +891,8 @@ def main(argv=None, env_factory=None):
         dist.barrier()                # every rank leaves together (rank 0 may still be timing the CPU baseline)
         dist.destroy_process_group()
     if ok_flag < 1.0:
-        sys.exit("bench.py: the timed environments do NOT match the oracle (%s)" % verify.get("mismatch"))
+        bad = [v.get("mismatch") for v in [verify] + [c["verification"] for c in (closed_loop, cap64) if c] if v.get("verified") is False]
+        sys.exit("bench.py: the timed environments do NOT match the checker (%s)" % "; ".join(str(b) for b in bad))
 
 
 if __name__ == "__main__":

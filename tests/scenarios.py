@@ -889,6 +889,65 @@ def check_driver_shape_vs_oracle(backend, n_envs=4096, n_sub=2, capacity=128, ra
     return m, peak
 
 
+def check_closed_loop_rollout_vs_two_launch(backend, n_envs=4096, n_sub=2, capacity=128, rate=1000.0, chunk=5, n_sample=16,
+                                            calls=(50, 50, 50, 50, 50, 50, 5, 25), seed=4243, obs_dtype=torch.float64):
+    """BASELINE config 5 at full size through the product's fast path: PipelinedIntersections,
+    `n_sub` sub-batches on their own streams, pve_step_many(PVE_SRC_ACTOR) -- the actor INSIDE the resident kernel
+    (k_rollout<.., ACT>) -- in launches of `chunk` ticks, against `n_sample` of the same arrival streams stepped as ONE
+    small batch with step_with_actor (actor launch + tick launch per tick).  Both forms run the same actor_tile32 on
+    the same float32 rows, so after every call the persistent state of the sampled envs (live slots, every field), the
+    observation rows of their controlled vehicles and the last tick's outputs must be BIT-equal; overflow == 0 over the
+    whole batch.  Also bounds the on-device actions against the NumPy restatement (action-level bar 5e-4) on the final
+    rows."""
+    from oracle.actor_np import actor_forward, flat_weights, load_weights
+    from pve_mcc_amd.batched import PipelinedIntersections
+    from tests.hip_adapter import emulator_lib
+    total = sum(calls)
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed)
+    outs = ("obs_post", "reward", "flags", "env_out", "new_slot")
+    kw = dict(device="cpu", _lib=emulator_lib()) if backend == "emu" else dict(device="cuda")
+    sample = sorted(set(np.linspace(0, n_envs - 1, n_sample).astype(int).tolist()))
+    big = PipelinedIntersections(n_envs, capacity, arr, n_sub=n_sub, outputs=outs, obs_dtype=obs_dtype, **kw)
+    small = make_batch(arr[sample], len(sample), capacity, backend, outputs=outs, obs_dtype=obs_dtype)
+    wd = load_weights()
+    w = flat_weights(wd)
+    for b in (big, small):
+        b.reset()
+        b.set_actor(w)
+    t = 0
+    for n in calls:
+        big.step_many(n, actor=True, chunk=chunk)
+        for _ in range(n):
+            small.step_with_actor()
+        big.synchronize(); small.synchronize()
+        t += n
+        for i, e in enumerate(sample):
+            k, le = big.sub_of(e)
+            sub = big.subs[k]
+            live = _np(small.state_field("meta")[i]) != 0
+            assert np.array_equal(_np(sub.state_field("meta")[le]) != 0, live), "alive set: env %d after %d ticks" % (e, t)
+            for f in STATE_F + STATE_I:
+                x, y = _np(sub.state_field(f)[le]), _np(small.state_field(f)[i])
+                assert np.array_equal(x[live], y[live]), "%s: env %d after %d ticks" % (f, e, t)
+            ctl = live & ((_np(small.state_field("meta")[i]) & 1) != 0)
+            assert np.array_equal(_np(sub.obs[le])[ctl], _np(small.obs[i])[ctl]), "obs rows: env %d after %d ticks" % (e, t)
+            for o in ("flags", "env_out"):
+                assert np.array_equal(_np(sub.out[o][le]), _np(small.out[o][i])), "%s: env %d after %d ticks" % (o, e, t)
+            fl = _np(small.out["flags"][i])
+            was_ctl = (fl & 2) != 0
+            assert np.array_equal(_np(sub.out["reward"][le])[was_ctl], _np(small.out["reward"][i])[was_ctl]), "reward: env %d" % e
+    # action-level bar against the NumPy restatement on the rows the loop ended with
+    a_dev = _np(small.act())
+    meta = _np(small.state_field("meta"))
+    ctl = (meta & 1) != 0
+    a_np = actor_forward(wd, _np(small.obs)).astype(np.float64)
+    worst = float(np.abs(a_dev - a_np)[ctl].max()) if ctl.any() else 0.0
+    assert ctl.sum() > 10 * len(sample) * (capacity // 64) / 4 and worst <= 5e-4, (int(ctl.sum()), worst)
+    m = big.metrics()
+    assert m["ticks"] == total * n_envs and m["overflow"] == 0, (m["ticks"], m["overflow"])
+    return m, worst
+
+
 def check_geo_lists_equal_scan(backend, lane_num, n_envs=6, capacity=128, ticks=250, rate=None, seed=91, quantize=None):
     """General-geometry kernel: the per-route list path == its membership-scan fallback (PVE_CFG_GEO_SCAN), bit for bit,
     on random (optionally quantised: exact ties) action tapes; dense traffic makes some intersections overflow the list

@@ -410,6 +410,16 @@ def test_gpu_full_size_actor_closed_loop_matches_small_batch():
     assert m["overflow"] == 0 and m["alive_steps"] / m["ticks"] > 40
 
 
+@pytest.mark.parametrize("chunk,dtype", [(5, torch.float64), (25, torch.float32), (25, torch.float64), (5, torch.float32)])
+def test_gpu_full_size_closed_loop_inside_rollout_kernel(chunk, dtype):
+    """BASELINE config 5 in its fast form at FULL size: 2 x 2048 envs x 128 slots, 1000 veh/h/lane, the actor inside the
+    resident kernel (pve_step_many(PVE_SRC_ACTOR), launches of 5 / 25 ticks, 330 ticks) == step_with_actor on a 16-env
+    sample batch, bit for bit after every call (state, rows, outputs); float32 and float64 rows; overflow 0."""
+    m, worst = scenarios.check_closed_loop_rollout_vs_two_launch(BACKEND, chunk=chunk, obs_dtype=dtype)
+    assert m["alive_steps"] / m["ticks"] > 40
+    print("closed loop in k_rollout<ACT>, chunk %d, %s rows: max |a_dev - a_numpy| = %.3e" % (chunk, dtype, worst))
+
+
 @pytest.mark.parametrize("exact,tol", [(True, 2e-6), (False, 1e-4)])
 def test_gpu_actor_kernel_follows_the_canonical_order(exact, tol):
     """exact: k_actor_t (v_mfma_f32_16x16x4_f32, PVE_CFG_ACTOR_F32) computes every dot product and LayerNorm sum in the

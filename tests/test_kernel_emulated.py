@@ -78,6 +78,13 @@ def test_emulated_driver_launch_shape_vs_oracle():
         assert m["ctl_steps"] > 0
 
 
+def test_emulated_closed_loop_rollout_vs_two_launch():
+    """Small-batch CPU version of the full-size config-5 certification (the GPU test runs it at 4096 x 128)."""
+    m, worst = scenarios.check_closed_loop_rollout_vs_two_launch(BACKEND, n_envs=5, n_sub=2, n_sample=3, chunk=5,
+                                                                 calls=(30, 30, 5, 25), obs_dtype=torch.float32)
+    assert m["ctl_steps"] > 0 and worst <= 5e-4
+
+
 def test_emulated_step_many_emits_training_states():
     """state_pre / obs_pre / 7-action vectors over pve_step_many trajectories, every tick vs the oracle (f64 and f32 rows)."""
     scenarios.check_step_many_state_rows(BACKEND, n_envs=2, calls=(30, 12, 25), chunk=0)
