@@ -115,7 +115,7 @@ def cpu_baseline(arr, pool, cap, lane_num=12, choice=None, id_sin=False):
 
 
 KNOBS = ("PVE_NO_ROLLOUT_KERNEL", "PVE_NO_ROLLOUT_ACTOR", "PVE_ROLLOUT_WPE5", "PVE_ROLLOUT_GEO_WPE5", "PVE_ACTOR_GRID",
-         "PVE_LIBRARY_PATH", "PVE_NO_PERSISTENT")
+         "PVE_LIBRARY_PATH", "PVE_NO_PERSISTENT", "PVE_TAPER_TAIL", "PVE_PERSISTENT_GRID")
 
 
 def csrc_sha():
@@ -321,8 +321,11 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
     arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=(prefill + W + K) * 0.1 + 20.0, seed=seed, lane_num=12)
     obs_dtype = torch.float32 if closed else torch.float64
     outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
-    env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=2, device=dev, outputs=outputs, obs_dtype=obs_dtype)
-    chunk = (25 if K >= 100 else 5) if cap == 128 else 0
+    n_sub, chunk, pers = launch_shape(cap, K, 12, closed)
+    if n_sub == 1:
+        env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs, obs_dtype=obs_dtype)
+    else:
+        env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=n_sub, device=dev, outputs=outputs, obs_dtype=obs_dtype)
     env.reset()
     pool_np, w = None, None
     if closed:
@@ -335,7 +338,7 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
     else:
         pool_np = action_pool(n_envs, cap, seed=1234 + rank)
         env.set_action_pool(torch.as_tensor(pool_np, device=dev))
-        calls = {n: env.prepare_step_many(n, chunk=chunk) for n in {prefill, W, K} if n > 0}
+        calls = {n: env.prepare_step_many(n, chunk=chunk, persistent=pers) for n in {prefill, W, K} if n > 0}
 
         def run(n):
             if n > 0:
@@ -352,6 +355,8 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
     total = prefill + W + K
 
     def locate(e):
+        if n_sub == 1:
+            return env, e
         k, le = env.sub_of(e)
         return env.subs[k], le
     if not verify:
@@ -362,14 +367,16 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
         ver = verify_against_oracle(locate, lambda e: {n: locate(e)[0].out[n][locate(e)[1]].cpu().numpy() for n in ("flags", "reward", "env_out")},
                                     arr, pool_np, total, 12, None)
     b_nom = B_ALG_OBS_F32 if closed else B_ALG_FP64
-    tpl = chunk if chunk > 0 else K
+    # ticks per launch / per queue item: the state crosses HBM once per that many ticks
+    tpl = (K / float(persistent_items(K, chunk))) if pers else (chunk if chunk > 0 else K)
     b_alg = b_nom - (B_STATE_IN + B_STATE_OUT) * (1.0 - 1.0 / tpl)
     res = {"what": ("BASELINE config 5: %d x %d, 1000 veh/h/lane, MADDPG actor (pretrained 66.cptk weights) inside the resident "
                     "kernel, float32 rows, pve_step_many(PVE_SRC_ACTOR)" if closed else
                     "BASELINE config 2: %d x %d, slot-indexed sin pool, 350 veh/h/lane (BASELINE.md's 500 overflows 64 slots in "
                     "4096 envs: DESIGN.md 5)") % (n_envs, cap),
            "ms_per_step": dt / K * 1e3, "value": float(cap) * n_envs * K / dt, "unit": "env-steps/s", "steps": K, "warmup": W,
-           "prefill_ticks": prefill, "ticks_per_launch": tpl, "sub_batches": 2,
+           "prefill_ticks": prefill, "ticks_per_launch": K if (pers or chunk == 0) else chunk, "ticks_per_item": tpl,
+           "sub_batches": n_sub, "launch": "persistent work queue" if pers else "one launch per chunk and sub-batch",
            "verified": ver["verified"], "verification": ver,
            "overflow": m1["overflow"], "mean_alive_per_env": (m1["alive_steps"] - m0["alive_steps"]) / float(K * n_envs),
            "mean_ctl_per_env": (m1["ctl_steps"] - m0["ctl_steps"]) / float(K * n_envs),
@@ -377,6 +384,30 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
     del env
     torch.cuda.empty_cache()
     return res
+
+
+def persistent_items(K, T):
+    """Items per intersection of a persistent call of K ticks with items of at most T ticks (pve_capi.inc: the ticks are
+    dealt into the fewest equal items, the call ends with one item of 3 ticks)."""
+    tail = 3 if K >= 8 and K - 3 >= 1 else 0
+    return -(-(K - tail) // T) + (1 if tail else 0)
+
+
+def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False):
+    """Default launch shape of a roll-out of K ticks: (sub-batches, ticks per launch or queue item, persistent).
+    Measured on MI355X with 4096 envs (tools/ab_launch_shapes.py, same process, medians):
+      12 lanes x 128 slots, pool / zero actions: ONE batch and ONE persistent launch per call whose workgroups pull
+        (intersection, <= T ticks) items from a queue -- 618 us for 20 ticks (T = 6) against 671 us for two stream-pipelined
+        sub-batches in launches of 5; 26.4 against 27.5 us per tick in a 1000-tick region (T = 10 / launches of 25);
+      12 lanes x 64 slots: every intersection is resident at once (16 one-wave workgroups per CU): one launch for a short call
+        (323 against 341 us for 20 ticks), the persistent queue with T = 10 for a long one (13.6 against 13.9 / 14.4 us);
+      closed loop, id-indexed table, trajectories, 4 / 8 lanes: two stream-pipelined sub-batches, one launch per chunk
+        (their resident kernels have no queue form)."""
+    if lane_num == 12 and not actor and not table and not trajectory:
+        if cap == 128:
+            return 1, (10 if K >= 100 else 6), True
+        return (1, 10, True) if K >= 100 else (1, 0, False)
+    return 2, ((25 if K >= 100 else 5) if cap == 128 else 0), False
 
 
 def self_launch(args_list, n):
@@ -437,15 +468,20 @@ def main(argv=None, env_factory=None):
     ap.add_argument("--outputs", default="obs_post,reward,flags,nbr,new_slot,env_out")
     ap.add_argument("--lane-num", type=int, default=12, choices=(12, 8, 4),
                     help="intersection layout; 12 = BASELINE metric (k_tick), 4 / 8 = SURVEY 8 f4 (k_tick_geo)")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=None,
                     help="free-running sub-batches per GPU, each on its own HIP stream (PipelinedIntersections); 1 = one "
                          "launch over all envs per step")
     ap.add_argument("--mode", default=None, choices=("step", "rollout"),
                     help="step: one pve_step_all launch per tick and sub-batch, enqueued from Python (the reference's "
                          "caller protocol, main.py:397-441); rollout: pve_step_many -- the K ticks of the timed region are "
                          "one call per sub-batch with the action source (pool / actor) on the device")
-    ap.add_argument("--chunk", type=int, default=0,
-                    help="rollout mode: ticks per kernel launch (0 = the whole call in one launch)")
+    ap.add_argument("--persistent", type=int, default=None, choices=(0, 1),
+                    help="rollout mode, lane_num 12, action pool: 1 = ONE batch of all envs and ONE persistent launch per call; its "
+                         "workgroups pull (intersection, --chunk ticks) items from a queue (pve_rollout.persistent); 0 = "
+                         "stream-pipelined sub-batches, one launch per chunk")
+    ap.add_argument("--chunk", type=int, default=None,
+                    help="rollout mode: ticks per kernel launch / per item of the persistent launch (0 = the whole call in one "
+                         "launch; default: launch_shape())")
     ap.add_argument("--trajectory", type=int, default=None, choices=(0, 1),
                     help="rollout mode: 1 = every tick's outputs are RETAINED (trajectory roll-outs into a ring of two "
                          "chunk buffers per sub-batch, what a trainer consumes, main.py:397-441); 0 = each tick overwrites "
@@ -528,7 +564,19 @@ def main(argv=None, env_factory=None):
         table_np = np.sin(0.37 * np.arange(cols_t, dtype=np.float64)[None, :] + 0.05 * np.arange(rows_t, dtype=np.float64)[:, None])
         table_np = table_np.astype(np.float32).astype(np.float64)
     outputs = tuple(x for x in args.outputs.split(",") if x)
-    n_sub = max(1, min(args.pipeline, n_envs))
+    # launch shape: launch_shape()'s measured default unless --pipeline / --chunk / --persistent say otherwise
+    rollout_like = (args.mode or ("rollout" if not emu else "step")) == "rollout"
+    d_sub, d_chunk, d_pers = launch_shape(cap, K, lane_num, args.actor, table=(args.tape == "id-sin"), trajectory=bool(args.trajectory))
+    if not rollout_like:
+        d_sub, d_chunk, d_pers = 2, 0, False
+    can_pers = lane_num == 12 and not args.actor and rollout_like and not emu and args.tape == "pool" and not args.trajectory
+    pers = can_pers and args.chunk != 0 and \
+        (bool(args.persistent) if args.persistent is not None else (d_pers and args.pipeline in (None, 1)))
+    if args.pipeline is None:
+        args.pipeline = 1 if pers else (d_sub if args.persistent is None else 2)
+    if args.chunk is None:
+        args.chunk = d_chunk if (pers == d_pers and args.pipeline == d_sub) else ((25 if K >= 100 else 5) if (cap == 128 or pers) else 0)
+    n_sub = 1 if pers else max(1, min(args.pipeline, n_envs))
     obs_dtype = torch.float32 if args.obs_f32 else torch.float64
     if emu:
         env = env_factory(n_envs, cap, arr, outputs)
@@ -541,16 +589,11 @@ def main(argv=None, env_factory=None):
         # LOAD / FIN bursts of one sub-batch overlap the compute phases of the other), DESIGN.md 5
         env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=n_sub, device=dev, outputs=outputs,
                                                  lane_num=lane_num, intentions=choice, obs_dtype=obs_dtype)
-    # auto: pve_step_many (state resident on the chip, host out of the loop) is the faster product path for the 12-lane
-    # layout -- capacity 64: one wave per intersection, all 4096 resident at once (14.8 vs 20.6 us per tick); capacity 128:
-    # launches of 25 ticks per sub-batch keep the chip full (30.0 vs 32.9 us); a short timed region (the driver's --steps
-    # 20) takes launches of 5 ticks so that the two sub-batches still interleave (35.3 vs 36.6 us incl. fill and drain)
+    # auto: pve_step_many (state resident on the chip, host out of the loop) is the faster product path; launch_shape() above
     mode = args.mode or ("rollout" if not emu else "step")
     if id_sin and mode != "rollout":
         id_sin, table_np = False, None                   # (one launch per tick: the slot-indexed pool)
     src = "table" if id_sin else None
-    if mode == "rollout" and args.chunk == 0 and cap == 128:
-        args.chunk = 25 if K >= 100 else 5
     if mode == "rollout" and not hasattr(env, "step_many"):
         sys.exit("--mode rollout: this build has no pve_step_many")
     traj_on = bool(args.trajectory) if args.trajectory is not None else False
@@ -575,6 +618,7 @@ def main(argv=None, env_factory=None):
     ring_pos = [0, None, 0]                              # next buffer, (buffer, ticks) of the last call
 
     prepared = {}
+    pers_kw = {"persistent": True} if pers else {}
 
     launch_seq = {}
     if os.environ.get("PVE_BENCH_CHUNKS") and mode == "rollout" and hasattr(env, "prepare_step_many"):
@@ -596,7 +640,7 @@ def main(argv=None, env_factory=None):
                 tick[0] += n
                 return
             if n not in prepared:
-                prepared[n] = env.prepare_step_many(n, source=src, chunk=args.chunk)
+                prepared[n] = env.prepare_step_many(n, source=src, chunk=args.chunk, **pers_kw)
             prepared[n]()
             tick[0] += n
             return
@@ -640,7 +684,7 @@ def main(argv=None, env_factory=None):
 
     run_ticks(W)
     if mode == "rollout" and not traj_on and not args.actor and hasattr(env, "prepare_step_many") and K > 0 and K not in prepared:
-        prepared[K] = env.prepare_step_many(K, source=src, chunk=args.chunk)      # (built outside the timed region)
+        prepared[K] = env.prepare_step_many(K, source=src, chunk=args.chunk, **pers_kw)      # (built outside the timed region)
     sync()
     if world > 1:
         dist.barrier()
@@ -780,12 +824,16 @@ def main(argv=None, env_factory=None):
         value = slot_steps / wall
         envs_per_launch = n_envs / float(n_sub)
         tpl = (traj_len if traj_on else (args.chunk if args.chunk > 0 else K)) if mode == "rollout" else 1      # ticks per kernel launch
+        if pers:
+            tpl = K                                       # one launch for the whole call ...
+        # ... whose items move an intersection's state across HBM once each
+        t_state = (K / float(persistent_items(K, args.chunk))) if pers else tpl
         # ---- algorithmic bytes.  SURVEY 8d's per-unit figure (380 B per vehicle-slot-step, FP64 layout) assumes the
         # persistent state is read and written every tick.  pve_step_many keeps it on the chip: a launch of T ticks
         # moves the state once, so per slot-step it must move 380 - 124 + 124 / T bytes.  `achieved` / `frac` charge what
         # the measured mode has to move; `nominal` is the 8d figure whatever the mode (an "equivalent" rate).
         b_nom = B_ALG_OBS_F32 if args.obs_f32 else B_ALG_FP64
-        b_alg = b_nom if mode != "rollout" else b_nom - (B_STATE_IN + B_STATE_OUT) * (1.0 - 1.0 / tpl)
+        b_alg = b_nom if mode != "rollout" else b_nom - (B_STATE_IN + B_STATE_OUT) * (1.0 - 1.0 / t_state)
         # per GPU: algorithmic bytes of one tick of all the rank's envs / wall-clock per tick (NOT per-launch x launches)
         achieved = b_alg * cap * n_envs / (wall / K) / 1e9
         nominal = b_nom * cap * n_envs / (wall / K) / 1e9
@@ -793,9 +841,11 @@ def main(argv=None, env_factory=None):
         per_launch = b_alg * cap * envs_per_launch / kern_s / 1e9
         kname = (("k_rollout<%d>" if mode == "rollout" else "k_tick<%d>") if lane_num == 12 else
                  ("k_rollout_geo<%d>" if mode == "rollout" else "k_tick_geo<%d>")) % cap
+        if pers:
+            kname += " persistent (PERS: work queue)"
         if args.actor:
             kname += " with the actor inside (ACT)" if mode == "rollout" else " + k_actor_h"
-        other = args.actor or lane_num != 12 or args.obs_f32 or traj_on
+        other = args.actor or lane_num != 12 or args.obs_f32 or traj_on or pers
         tr, traffic_src = (None, None) if (emu or not steady) else pmc_traffic(int(envs_per_launch), cap, outputs, mode, tpl, other)
         traffic = tr["hbm_bytes_per_launch"] if tr else None
         counter_rate = (traffic / tpl * n_sub / (wall / K) / 1e9) if traffic else None
@@ -837,6 +887,8 @@ def main(argv=None, env_factory=None):
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
                                       if args.actor else pool_desc),
                        "envs_per_gpu": n_envs, "capacity": cap, "mode": mode, "ticks_per_launch": tpl,
+                       "launch": ("persistent: one launch per call, %d-tick (intersection, chunk) items pulled from a work queue"
+                                  % args.chunk) if pers else "one launch per chunk and sub-batch",
                        "per_tick_outputs": ("every tick's outputs written to their own block (trajectory roll-out, ring of 2 "
                                             "chunk buffers per sub-batch)" if traj_on else
                                             ("overwritten by the next tick of the same launch (only the last tick of a call "
@@ -854,7 +906,9 @@ def main(argv=None, env_factory=None):
             "mean_alive_per_env": mean_alive,
             "mean_ctl_per_env": tot["ctl_steps"] / (K * n_envs * world),
             "overflow": tot["overflow"],
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limited_by": "vector-instruction issue and LDS round-trip latency, not bandwidth (`binding`; "
+                                                        "`bound` names the roofline SURVEY 8d prices this scan / element-wise path against)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "alg_bytes_per_slot_step": b_alg,
                          "nominal": {"alg_bytes_per_slot_step": b_nom, "achieved": nominal, "frac": nominal / HBM_PEAK_GBS,
@@ -871,7 +925,7 @@ def main(argv=None, env_factory=None):
                          "concurrent_launches": n_sub, "per_launch_achieved": per_launch,
                          "definition": "achieved = algorithmic bytes the measured mode must move (step: 380 B per slot-step, "
                                        "SURVEY 8d; pve_step_many launch of T ticks: 380 - 124 (1 - 1/T), the persistent state "
-                                       "crosses HBM once per launch) x capacity x envs of the GPU, every slot counted / "
+                                       "crosses HBM once per launch -- once per queue ITEM of the persistent launch) x capacity x envs of the GPU, every slot counted / "
                                        "wall-clock per tick; per_launch_achieved = the bytes of one sub-batch / "
                                        "its tick time on its own stream (HIP events), sub-batches overlap; "
                                        "achieved_counter_bytes = HBM bytes the PMC counters saw (traffic, profiled on this "

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PVE_ABI_VERSION 4
+#define PVE_ABI_VERSION 5
 #define PVE_LANES 12          /* physical lanes: lane_num = 4, 8 or 12 (arrays are padded to 12) */
 #define PVE_MAX_DIRS 16       /* virtual-lane lists (routes): 12 for lane_num 4 / 12, 16 for lane_num 8 (ref :86, :132, :167) */
 #define PVE_OBS_WIDTH 28      /* (o_agent_num + 1) * 4, ref :1295 */
@@ -246,6 +246,12 @@ typedef struct pve_rollout {
                                      launch lasts as long as its slowest intersection: with several handles stepped on their
                                      own streams, shorter launches let the other handles' workgroups fill the slots that the
                                      fast intersections free (bench.py --chunk). */
+    int32_t persistent;           /* 1 (with chunk_ticks > 0, PVE_SRC_ZERO / PVE_SRC_POOL, lane_num 12, no obs_pre / state_pre): the
+                                     whole call is ONE launch of as many workgroups as the chip holds at once; they pull
+                                     (intersection, chunk) items from a queue in the handle's workspace, so nothing waits in
+                                     launch order for the slowest intersection of a chunk (the reference's episode loop
+                                     main.py:397-441 has no such boundary either).  Same results as persistent = 0; ignored
+                                     (chunked launches as above) where the configuration has no such kernel. */
 } pve_rollout;
 int pve_step_many(pve_handle h, const pve_rollout *ro, const pve_outputs *out);
 

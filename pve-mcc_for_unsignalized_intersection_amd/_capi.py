@@ -22,7 +22,7 @@ PVE_NBR = 6
 PVE_N_METRICS = 12
 PVE_ENV_OUT_N = 8
 PVE_ACTOR_N_WEIGHTS = 6393
-ABI_VERSION = 4
+ABI_VERSION = 5
 SRC_ZERO, SRC_POOL, SRC_ACTOR, SRC_TABLE = 0, 1, 2, 3
 
 F_ALIVE, F_CTL, F_DONE, F_DELETED, F_FINISHED, F_LOCK = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
@@ -52,7 +52,8 @@ class PveOutputs(C.Structure):
 class PveRollout(C.Structure):
     _fields_ = [("n_ticks", C.c_int32), ("source", C.c_int32), ("pool", C.c_void_p), ("n_pool", C.c_int32),
                 ("pool_tick0", C.c_int32), ("actor_weights", C.c_void_p), ("actor_obs", C.c_void_p),
-                ("actor_actions", C.c_void_p), ("trajectory", C.c_int32), ("table_ids", C.c_int32), ("chunk_ticks", C.c_int32)]
+                ("actor_actions", C.c_void_p), ("trajectory", C.c_int32), ("table_ids", C.c_int32), ("chunk_ticks", C.c_int32),
+                ("persistent", C.c_int32)]
 
 
 class PveVehicle(C.Structure):

@@ -323,7 +323,7 @@ class BatchedIntersections:
                 traj[n] = torch.zeros((n_ticks,) + tuple(tns.shape), dtype=tns.dtype, device=dev)
         return traj
 
-    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0, update_views=True):
+    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0, update_views=True, persistent=False):
         """n_ticks fused ticks in ONE call, the action source on the device (the reference's episode loop
         main.py:397-441 without the host in it): source = "pool" (set_action_pool), "actor" (set_actor; closed loop)
         or "zero".  Bit-identical to n_ticks step() / step_with_actor() calls.
@@ -331,7 +331,10 @@ class BatchedIntersections:
         trajectory=True: returns a dict of freshly allocated [n_ticks, ...] tensors with every tick's outputs (a roll-out).
         trajectory=<dict from alloc_trajectory(m), m >= n_ticks>: the same into the caller's buffers (blocks 0 .. n_ticks-1).
         update_views=False (trajectory roll-outs only): skip the copy of the last tick into the handle's single-tick views
-        (`obs`, `out`) -- not with source="actor", whose next call reads `obs`."""
+        (`obs`, `out`) -- not with source="actor", whose next call reads `obs`.
+        persistent=True (with chunk > 0; pool / zero sources, lane_num 12): the call is ONE launch whose workgroups pull
+        (intersection, chunk) items from a queue -- for a batch of at least twice as many intersections as the chip holds
+        workgroups (4096 x 128 slots on one MI355X); same results."""
         n_ticks = int(n_ticks)
         if source is None:
             source = "actor" if actor else ("pool" if getattr(self, "_pool", None) is not None else "zero")
@@ -340,6 +343,7 @@ class BatchedIntersections:
         ro.n_ticks = n_ticks
         ro.trajectory = 1 if trajectory else 0
         ro.chunk_ticks = int(chunk)
+        ro.persistent = 1 if persistent else 0
         if source == "pool":
             if getattr(self, "_pool", None) is None:
                 raise PveError("step_many(source='pool'): call set_action_pool first")
@@ -395,7 +399,7 @@ class BatchedIntersections:
                     tns.copy_(traj[n][n_ticks - 1])
         return traj
 
-    def prepare_step_many(self, n_ticks, source=None, chunk=0):
+    def prepare_step_many(self, n_ticks, source=None, chunk=0, persistent=False):
         """A prepared pve_step_many call (trajectory=False): everything the call needs is built once; the returned callable
         re-issues it (only the position in the action pool advances) at the cost of one ctypes call -- for loops whose host
         side is measured in microseconds (RL inner loops, bench.py's timed region).  The prepared call keeps the pool / table
@@ -407,7 +411,7 @@ class BatchedIntersections:
         if source == "actor" or "state_pre" in self.out:
             raise PveError("prepare_step_many: pool / zero sources without state_pre (use step_many)")
         ro = PveRollout()
-        ro.n_ticks, ro.trajectory, ro.chunk_ticks = n_ticks, 0, int(chunk)
+        ro.n_ticks, ro.trajectory, ro.chunk_ticks, ro.persistent = n_ticks, 0, int(chunk), (1 if persistent else 0)
         if source == "pool":
             if getattr(self, "_pool", None) is None:
                 raise PveError("prepare_step_many(source='pool'): call set_action_pool first")
@@ -593,18 +597,19 @@ class PipelinedIntersections:
     def alloc_trajectory(self, n_ticks):
         return [sub.alloc_trajectory(n_ticks) for sub in self.subs]
 
-    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0, update_views=True):
+    def step_many(self, n_ticks, actor=False, source=None, trajectory=False, chunk=0, update_views=True, persistent=False):
         """n_ticks of every sub-batch, one pve_step_many call each (on its own stream).  chunk > 0 splits every call into
         launches of `chunk` ticks: a launch lasts as long as its slowest intersection, and the other sub-batches'
         workgroups fill the slots its fast ones free, so short launches keep the chip full.
         trajectory: False / True / the list alloc_trajectory() returned (one dict per sub-batch)."""
         tr = trajectory if isinstance(trajectory, (list, tuple)) else [trajectory] * self.n_sub
-        return [sub.step_many(n_ticks, actor=actor, source=source, trajectory=tr[k], chunk=chunk, update_views=update_views)
+        return [sub.step_many(n_ticks, actor=actor, source=source, trajectory=tr[k], chunk=chunk, update_views=update_views,
+                              persistent=persistent)
                 for k, sub in enumerate(self.subs)]
 
-    def prepare_step_many(self, n_ticks, source=None, chunk=0):
+    def prepare_step_many(self, n_ticks, source=None, chunk=0, persistent=False):
         """One prepared call per sub-batch (BatchedIntersections.prepare_step_many); the returned callable issues them all."""
-        calls = [sub.prepare_step_many(n_ticks, source=source, chunk=chunk) for sub in self.subs]
+        calls = [sub.prepare_step_many(n_ticks, source=source, chunk=chunk, persistent=persistent) for sub in self.subs]
 
         def call():
             for c in calls:

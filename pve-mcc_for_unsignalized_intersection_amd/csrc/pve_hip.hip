@@ -127,6 +127,69 @@ __device__ __forceinline__ void rollout_actor(const unsigned char *packed, const
     }
 }
 
+// ------------------------------------------------------------------ persistent roll-out: the work queue
+// One launch for a whole pve_step_many call: as many workgroups as the chip holds at once, each pulling (intersection,
+// chunk) items -- chunk c of intersection e = ticks [c T, (c + 1) T) of the call -- until the call is done.  Nothing waits in
+// launch order for the slowest intersection of a chunk; an item only waits for the previous chunk of ITS intersection.
+//
+// Hand-off of an intersection between two workgroups (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility"): the eight XCDs' L2s are not coherent with each other and a CU's vector L1 is never
+// refreshed by another CU's stores.  So (1) every intersection is worked by ONE XCD for the whole launch: env e belongs to
+// shard e % n_shards, and a shard belongs to the first XCD -- HW_REG_XCC_ID as read by the executing wave, not an
+// assumption about dispatch -- whose workgroup claims it (compare-and-swap on owner[]; an XCD starts with the shard of
+// its own number and adopts what nobody has claimed once that is exhausted, so every shard is worked whatever the
+// placement).  All stores to an intersection's state AND to its output rows (which successive ticks overwrite) then
+// meet in one L2, in program order of the workgroups that are ordered by the done[] hand-off; (2) the finishing workgroup
+// drains its stores (`s_waitcnt vmcnt(0)` in every wave: the write-through L1 has handed them to the L2), joins at a
+// barrier and publishes done[e] with an agent-scope atomic store; (3) the next workgroup polls done[e] with agent-scope
+// atomic loads (one lane, `s_sleep` between polls), joins at a barrier and reads the state with agent-scope atomic
+// loads (`sc1`: served by the L2, never by its own L1).  Queue heads and done[] are agent-scope atomics throughout.
+// Items of a shard are handed out chunk-major (all intersections' chunk c before any chunk c + 1) by a returning
+// atomic add, so whoever holds an item is a RUNNING workgroup and the item it may wait for was handed out earlier:
+// the oldest unfinished item never waits, whatever the grid size or whoever shares the chip.
+__device__ __forceinline__ unsigned q_xcc_id()
+{
+    return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xFu;      // HW_REG_XCC_ID[3:0] (gfx942 / gfx950)
+}
+__device__ __forceinline__ unsigned q_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void q_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane: the next item of this workgroup's XCD -> (env, chunk), env < 0 when the call has no work left for it.
+// `shard` / `probe` persist across calls (the shard being worked, the number of shards this workgroup has looked at).
+__device__ __forceinline__ void q_dequeue(RolloutQueue *Q, int n_shards, int n_envs, int n_chunks, unsigned xcc, int &shard, int &probe,
+                                          int &env, int &chunk)
+{
+    for (;;) {
+        if (shard >= 0) {
+            const unsigned es = (unsigned)(n_envs - shard + n_shards - 1) / (unsigned)n_shards;   // intersections of the shard
+            const unsigned i = __hip_atomic_fetch_add(&Q->s[shard].head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < es * (unsigned)n_chunks) {
+                const unsigned c = i / es;
+                env = shard + (int)(i - c * es) * n_shards; chunk = (int)c;
+                return;
+            }
+        }
+        // the shard is exhausted (or this is the first call): the next shard this XCD may work -- its own number first.
+        // Loads before atomics: at the end of a call every workgroup comes through here, and a compare-and-swap per
+        // workgroup and shard on lines the running workgroups' XCDs share is a flood (measured: the last items of a call ran
+        // 1.4x slower under it)
+        shard = -1;
+        while (probe < n_shards) {
+            const int cand = (int)((xcc + (unsigned)probe) % (unsigned)n_shards);
+            probe++;
+            if (cand >= n_envs) continue;
+            unsigned seen = q_load(&Q->s[cand].owner);
+            if (seen == 0u)
+                __hip_atomic_compare_exchange_strong(&Q->s[cand].owner, &seen, xcc + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen != 0u && seen != xcc + 1u) continue;          // another XCD's
+            const unsigned es = (unsigned)(n_envs - cand + n_shards - 1) / (unsigned)n_shards;
+            if (q_load(&Q->s[cand].head) >= es * (unsigned)n_chunks) continue;      // ours, but handed out already
+            shard = cand;
+            break;
+        }
+        if (shard < 0) { env = -1; chunk = 0; return; }
+    }
+}
+
 // pve_step_many: R.n_ticks ticks of one intersection per workgroup, the state resident in registers / LDS between the
 // ticks (pve_tick_core.h, "k_rollout").  Per tick only the outputs go to HBM; the action of the next tick (pool) and
 // the next arrival times are prefetched under the tail of the current one.
@@ -144,18 +207,22 @@ __device__ __forceinline__ void rollout_actor(const unsigned char *packed, const
 // IDT: PVE_SRC_TABLE -- the action is a function of (tick, vehicle id) given as a table: every vehicle's own thread gathers
 // its next action under FX (the id travels with the vehicle), the lanes that spawn gather theirs right behind FIN (in flight
 // under barrier A and STAGE), and the values are parked at the vehicles' NEW slots (act_next) where RELOAD looks for them.
-template <int CAP, int WPE, bool PROF = false, bool ACT = false, bool TRAIN = false, bool IDT = false>
+// PERS: the persistent form -- the workgroup pulls (intersection, chunk) items from the queue above; n_ticks = ticks per item.
+template <int CAP, int WPE, bool PROF = false, bool ACT = false, bool TRAIN = false, bool IDT = false, bool PERS = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout(const Const c_arg, const Params P_arg,
                                                                                                const RolloutArgs R_arg)
 {
+    static_assert(!PERS || (!PROF && !ACT && !TRAIN && !IDT), "the persistent form exists for the pool / zero sources");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     __shared__ Shared<CAP> sh;
     __shared__ __attribute__((aligned(64))) float aprm[ACT ? PV_TOTAL : 1];
     __shared__ uint8_t adsts[ACT ? CAP : 1];         // post-compaction slot of every dense thread's vehicle (255: gone)
+    __shared__ int q_word[4];                       // PERS: item (env, chunk) of the workgroup + the dequeue state of lane 0
     int adst = -1;
     int t0_ = threadIdx.x;
-    int env0_ = blockIdx.x;
+    int env0_ = PERS ? 0 : blockIdx.x;
+    int k_base_ = 0, chunk_ = 0;                     // PERS: first tick of the item within the call, its chunk number
     // the first wave carries the dense-mapped phases (the critical chain of the workgroup), the second one mostly waits at
     // the barriers: the first wave gets the issue slots first (30.0 -> 29.6 us per tick; not in k_tick, where the closed
     // loop's actor kernel shares the chip and loses more than the tick gains)
@@ -175,12 +242,44 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         tprev_ = now_;                                                                   \
     }
     int pool_idx, n_ticks;
+    if constexpr (PERS) { if (t0_ == 0) { q_word[2] = -1; q_word[3] = 0; } }
+  for (;;) {                                        // PERS: one pass per item; else exactly one pass
     {
         const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka0_;
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
         pool_idx = R.pool_tick0;
         n_ticks = R.n_ticks;
+        const double *act0 = nullptr;
+        if constexpr (PERS) {
+            RolloutQueue *Q = (RolloutQueue *)R.queue;
+            unsigned *done = R.queue + sizeof(RolloutQueue) / 4;
+            if (t0_ == 0) {
+                int shard = q_word[2], probe = q_word[3], e, ch;
+                const unsigned long long tq0 = R.q_trace ? wall_clock64() : 0ull;
+                q_dequeue(Q, R.n_shards, P.n_envs, R.n_full + R.n_taper, q_xcc_id(), shard, probe, e, ch);
+                q_word[0] = e; q_word[1] = ch; q_word[2] = shard; q_word[3] = probe;
+                const unsigned long long tq1 = R.q_trace ? wall_clock64() : 0ull;
+                if (e >= 0)                           // the previous chunk of this intersection (another workgroup's item)
+                    while ((int)(q_load(&done[e]) - (R.done_base + (unsigned)ch)) < 0) __builtin_amdgcn_s_sleep(8);
+                if (R.q_trace && e >= 0) {            // diagnostics: dequeue start, item known, predecessor done, who
+                    unsigned long long *row = R.q_trace + ((size_t)ch * P.n_envs + e) * 8;
+                    row[0] = tq0; row[1] = tq1; row[2] = wall_clock64();
+                    row[6] = (unsigned long long)blockIdx.x | ((unsigned long long)q_xcc_id() << 32);
+                }
+            }
+            lds_barrier();
+            const int e = __builtin_amdgcn_readfirstlane(q_word[0]), ch = __builtin_amdgcn_readfirstlane(q_word[1]);
+            if (e < 0) break;
+            env0_ = e; chunk_ = ch;
+            k_base_ = (ch < R.n_full ? ch : R.n_full) * R.n_ticks;
+            for (int q = 0; q < ch - R.n_full; q++) k_base_ += R.taper[q];              // (uniform: scalar loop over <= 7 entries)
+            n_ticks = ch < R.n_full ? R.n_ticks : (int)R.taper[ch - R.n_full];
+            if (R.source == 1) {
+                pool_idx = (R.pool_tick0 + k_base_) % R.n_pool;
+                act0 = R.pool + (size_t)pool_idx * (size_t)P.n_envs * CAP;
+            }
+        }
         if constexpr (ACT) {
             // the first tick's actions = actor(rows in HBM), before the state is loaded (nothing else is live): the controlled
             // slots are compacted into `adsts` as if they were dense threads (wave 1's ranks follow wave 0's count)
@@ -197,7 +296,10 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             rollout_actor<CAP>(R.actor_packed, aprm, sh.act_next, adsts, nc, R.actor_obs, P.obs_f32 != 0, (size_t)env0_ * CAP, t0_);
             lds_barrier();
         }
-        T::ph_load(c, P, env0_, t0_, sh, r);            // P.actions = the first tick's actions
+        if constexpr (PERS) {
+            T::template ph_load<true>(c, P, env0_, t0_, sh, r, act0, true);
+            if (R.q_trace && t0_ == 0) R.q_trace[((size_t)chunk_ * P.n_envs + env0_) * 8 + 3] = wall_clock64();
+        } else T::ph_load(c, P, env0_, t0_, sh, r);     // P.actions = the first tick's actions
         if constexpr (ACT) r.act = sh.act_next[t0_];    // (uncontrolled slots: whatever is there, masked in S1)
         if constexpr (IDT) {                            // the first tick's action of the vehicle in this slot: table[row][id]
             const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
@@ -210,6 +312,8 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         // loop-invariant code motion hoists every kernel-argument load and every per-thread address out of the loop
         // (~150 scalar + ~140 vector registers live across the whole tick -> spills / 2 waves per SIMD).
         // (the SAME variables are re-defined every iteration: a loop-carried value in one register, not an invariant plus a copy)
+        // (PERS: the item's intersection travels through the outer loop's phi, which the compiler keeps in a vector register)
+        if constexpr (PERS) env0_ = __builtin_amdgcn_readfirstlane(env0_);
         asm volatile("" : "+s"(kav_), "+v"(t0_), "+s"(env0_));
         const KernargPtr ka = kav_;
         const int t = t0_, env = env0_;
@@ -259,7 +363,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         lds_barrier();                                // (also what orders the previous tick's output stores before this tick's)
         PVE_PHASE_MARK(8)
         if constexpr (!ACT && !IDT) T::ph_park_action(t, sh, r);
-        const Outputs O = T::template tick_outputs<TRAIN>(P, R, k);
+        const Outputs O = T::template tick_outputs<TRAIN>(P, R, k_base_ + k);
         if constexpr (ACT) {
             adst = -1;
             T::template ph_final<true>(c, P, O, env, t, sh, r, fc, true, &adst);
@@ -304,6 +408,33 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
             for (int k = 0; k < 12; k++) row[k] += pc_[k];
             row[12] += clock64() - sclk0_; row[13] += wall_clock64() - wclk0_;
+        }
+    }
+    if constexpr (PERS) {
+        // hand the intersection on: every wave's stores (state, header, the ticks' output rows) have reached the L2, then
+        // the count of completed items of this intersection goes up by one
+        const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
+        const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
+        const unsigned long long tf0 = (R.q_trace && t0_ == 0) ? wall_clock64() : 0ull;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (t0_ == 0) q_store(R.queue + sizeof(RolloutQueue) / 4 + env0_, R.done_base + (unsigned)chunk_ + 1u);
+        if (R.q_trace && t0_ == 0) {                  // diagnostics: state flushed (stores issued), handed on
+            unsigned long long *row = R.q_trace + ((size_t)chunk_ * P.n_envs + env0_) * 8;
+            row[4] = tf0; row[5] = wall_clock64();
+        }
+    } else break;
+  }
+    if constexpr (PERS) {
+        // the last workgroup to leave clears the queue words for the next launch (done[] stays: it is cumulative)
+        const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
+        RolloutQueue *Q = (RolloutQueue *)R.queue;
+        if (t0_ == 0) {
+            const unsigned left = __hip_atomic_fetch_add(&Q->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (left + 1u == gridDim.x) {
+                for (int k = 0; k < QUEUE_MAX_SHARDS; k++) { q_store(&Q->s[k].head, 0u); q_store(&Q->s[k].owner, 0u); }
+                q_store(&Q->exits, 0u);
+            }
         }
     }
 }
@@ -571,6 +702,17 @@ struct Backend {
         return p;
     }
     static void dfree(void *p) { (void)hipFree(p); }
+    static int memset0(void *p, size_t n, void *stream)
+    {
+        return hipMemsetAsync(p, 0, n, (hipStream_t)stream) == hipSuccess ? 0 : -1;
+    }
+    // XCDs of the device: the persistent roll-out shards the intersections over them (every shard is worked by one XCD)
+    static int n_xcc(int dev)
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || v <= 0) v = 8;
+        return v > QUEUE_MAX_SHARDS ? QUEUE_MAX_SHARDS : v;
+    }
     static int d2h(void *dst, const void *src, size_t n, void *stream)
     {
         hipStream_t s = (hipStream_t)stream;
@@ -612,6 +754,32 @@ struct Backend {
         if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
         static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
         const bool train = P.out.obs_pre || P.out.state_pre;
+        if (R.queue) {                                                        // persistent form (pve_rollout.persistent)
+            if (train || (R.source != 0 && R.source != 1)) return 1;
+            Rk.q_trace = P.phase_cycles;                                      // diagnostics: per-item timestamps instead of phase cycles
+            // as many workgroups as the chip holds at once (the queue needs no more; fewer when the call has fewer items)
+            static int wgs_per_cu[2] = {0, 0}, n_cu = 0;
+            const int ci = cap == 64 ? 0 : 1;
+            if (!wgs_per_cu[ci]) {
+                int nb = 0, dev = 0;
+                hipDeviceProp_t prop;
+                hipError_t e = (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout<64, 4, false, false, false, false, true>, 64, 0)
+                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout<128, 4, false, false, false, false, true>, 128, 0);
+                if (e != hipSuccess || nb <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+                    err = hip_err("occupancy query of the persistent roll-out", e);
+                    return -1;
+                }
+                n_cu = prop.multiProcessorCount;
+                wgs_per_cu[ci] = nb;
+            }
+            const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
+            long long grid = (long long)wgs_per_cu[ci] * n_cu;
+            if (const char *g = getenv("PVE_PERSISTENT_GRID")) { const long long v = atoll(g); if (v > 0) grid = v; }   // A/B knob
+            if (grid > items) grid = items;
+            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, false, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
+            else hipLaunchKernelGGL((k_rollout<128, 4, false, false, false, false, true>), dim3((unsigned)grid), dim3(128), 0, s, c, P, Rk);
+            return check_launch(err);
+        }
         // the phase-cycle diagnostics exist for the default kernel only: every other variant (table, actor, training outputs)
         // answers "no resident kernel" and the caller falls back to per-tick launches, which record the cycles
         if (train && P.phase_cycles) return 1;

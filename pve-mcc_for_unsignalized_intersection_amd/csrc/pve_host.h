@@ -232,4 +232,5 @@ struct pve_handle_s {
     long long ticks_since_reset;
     unsigned long long *phase_cycles;
     bool has_actor;                   // pve_set_actor installed an actor in the workspace
+    unsigned q_done_base;             // persistent roll-out: items completed per intersection since pve_reset (cumulative)
 };

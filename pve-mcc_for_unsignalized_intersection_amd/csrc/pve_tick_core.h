@@ -144,6 +144,26 @@ template <class T> PVE_HD void lds_store_relaxed(T *p, T v)
     *p = v;
 #endif
 }
+// Global loads that may meet data ANOTHER workgroup of the same launch has stored (the persistent roll-out hands an
+// intersection from one workgroup to the next): COH = agent-scope relaxed atomic loads (`global_load ... sc1`), which are
+// served by the L2 instead of this CU's vector L1 -- the L1 is never refreshed by another CU's stores.
+template <bool COH, class T> PVE_HD T gld(const T *p)
+{
+#if PVE_DEVICE_CODE
+    if constexpr (COH) {
+        static_assert(sizeof(T) == 4 || sizeof(T) == 8, "gld: 4- or 8-byte scalars");
+        if constexpr (sizeof(T) == 8) {
+            const unsigned long long u = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T v; __builtin_memcpy(&v, &u, 8); return v;
+        } else {
+            const unsigned u = __hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T v; __builtin_memcpy(&v, &u, 4); return v;
+        }
+    } else return *p;
+#else
+    return *p;
+#endif
+}
 // sorted position -> entry: the low half of a tagged word (Shared<128>, see ph_rank) or a plain 16-bit index (SharedGeo)
 template <class W> PVE_HD int sidx_at(const W *s, int i)
 {
@@ -590,16 +610,20 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static constexpr int NW = CAP / 64;
 
     // ============================================================== L: load
-    static PVE_HD void ph_load(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    // COH: the state may have been stored by another workgroup of this launch (persistent roll-out): coherent loads.
+    // act0: the first tick's actions of this roll-out item ([n_envs][CAP], or null), instead of P.actions.
+    template <bool COH = false>
+    static PVE_HD void ph_load(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r,
+                               const double *act0 = nullptr, bool use_act0 = false)
     {
         const EnvHeader &gh = P.headers[env];
         {
             const int *src = (const int *)&gh;
             int *dst = (int *)&sh.hd;
-            for (int w = t + 2; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];   // words 0-1 = clock
+            for (int w = t + 2; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = gld<COH>(src + w);   // words 0-1 = clock
         }
-        if (t == 0) sh.hd.current_time = gh.current_time + c.deltaT;      // ref :223 (repeated +=, not tick*dt)
-        const int N = gh.n_alive;
+        if (t == 0) sh.hd.current_time = gld<COH>(&gh.current_time) + c.deltaT;      // ref :223 (repeated +=, not tick*dt)
+        const int N = gld<COH>(&gh.n_alive);
         const size_t g = (size_t)env * CAP + t;
         r.alive = t < N;
         r.jerk = 0;
@@ -609,16 +633,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         // not wait for n_alive: one memory latency instead of two on the critical path.  Later waves (slots >= 64) are
         // off the critical path and mostly empty: they wait for n_alive and read the live slots only.
         r.act = 0;
+        const double *acts = use_act0 ? act0 : P.actions;
         if (t < 64 || t < N) {
             // what S1 - S3 need comes first; the fields that are merely carried to FIN (or first read in WALK) are requested
             // behind them and arrive under the step phases (the kernel's barriers do not wait for global loads)
-            if (P.actions) r.act = P.actions[g];          // with the state loads: one latency, not a second one in S1
-            r.p = P.f64[F_P][g]; r.v = P.f64[F_V][g]; r.a = P.f64[F_A][g];
-            r.meta = P.i32[I_META][g]; r.step = P.i32[I_STEP][g];
-            r.jerk_sum = P.f64[F_JERK_SUM][g]; r.vir_dis = P.f64[F_VIR_DIS][g];
-            r.closer_p = P.f64[F_CLOSER_P][g];
-            r.id = P.i32[I_ID][g]; r.seq = P.i32[I_SEQ][g]; r.vnum = P.i32[I_VNUM][g];
-            r.count = P.i32[I_COUNT][g];
+            if (acts) r.act = acts[g];                    // with the state loads: one latency, not a second one in S1
+            r.p = gld<COH>(P.f64[F_P] + g); r.v = gld<COH>(P.f64[F_V] + g); r.a = gld<COH>(P.f64[F_A] + g);
+            r.meta = gld<COH>(P.i32[I_META] + g); r.step = gld<COH>(P.i32[I_STEP] + g);
+            r.jerk_sum = gld<COH>(P.f64[F_JERK_SUM] + g); r.vir_dis = gld<COH>(P.f64[F_VIR_DIS] + g);
+            r.closer_p = gld<COH>(P.f64[F_CLOSER_P] + g);
+            r.id = gld<COH>(P.i32[I_ID] + g); r.seq = gld<COH>(P.i32[I_SEQ] + g); r.vnum = gld<COH>(P.i32[I_VNUM] + g);
+            r.count = gld<COH>(P.i32[I_COUNT] + g);
         }
         sh.cnt[t] = 0;                                    // (rew_ovr / hdr share storage with S2-S3 arrays: BUILD)
         if (t == 0) {

@@ -147,6 +147,32 @@ struct RolloutArgs {
     int32_t n_ticks, source, n_pool, pool_tick0, trajectory;
     int32_t table_ids;           // PVE_SRC_TABLE: `pool` is [n_pool][table_ids], indexed by (tick, vehicle id)
     int32_t exact_f32;           // PVE_CFG_ACTOR_F32: the resident kernel has no exact-float32 actor (per-tick launches instead)
+    // persistent form (pve_rollout.persistent): ONE launch for the whole call; its workgroups pull (intersection, chunk)
+    // items from the queue below instead of owning one intersection each (k_rollout<.., PERS>)
+    unsigned *queue;             // RolloutQueue words followed by done[n_envs] (device, in the handle's workspace)
+    int32_t call_ticks;          // ticks of the whole call (n_ticks = ticks per full item here)
+    // item schedule: n_full items of n_ticks ticks, then n_taper shorter ones (taper[k] ticks each): the last items of a call
+    // are short so that the chip drains evenly (a workgroup's last item is what it is still busy with when the queue is empty)
+    int32_t n_full, n_taper;
+    uint8_t taper[8];
+    int32_t n_shards;            // env e belongs to shard e % n_shards; a shard is worked by ONE XCD
+    uint32_t done_base;          // done[e] - done_base = items of intersection e completed in this call
+    unsigned long long *q_trace; // diagnostics (pve_debug_phase_cycles armed): [chunk][env][8] timestamps of every item, or null
+};
+
+// Work queue of the persistent roll-out (device words, zero between launches: the last workgroup to leave clears them).
+// done[e] (behind this block) counts the items of intersection e completed since pve_reset, cumulatively (wrap-safe compares).
+constexpr int QUEUE_MAX_SHARDS = 16;
+struct RolloutQueue {
+    // one 128-byte line per shard: 2048 workgroups pulling from ONE line serialise at ~12 ns per atomic (measured: 15 us
+    // mean start-up delay and a congested tail when every exiting workgroup probed the other shards with atomics)
+    struct Shard {
+        unsigned head;                  // items handed out
+        unsigned owner;                 // 0 = nobody yet, else 1 + HW_REG_XCC_ID of the XCD whose workgroups work the shard
+        unsigned pad_[30];
+    } s[QUEUE_MAX_SHARDS];
+    unsigned exits;                     // workgroups that have left the launch
+    unsigned pad_[31];
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -156,7 +182,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 constexpr size_t ACTOR_FLAT_BYTES = 25600, ACTOR_PACKED_BYTES = 26880;
 
 struct Layout {
-    size_t off_headers, off_f64[NF64], off_i32[NI32], off_actor_flat, off_actor_packed, total;
+    size_t off_headers, off_f64[NF64], off_i32[NI32], off_actor_flat, off_actor_packed, off_queue, total;
 };
 
 inline Layout make_layout(int n_envs, int cap)
@@ -168,6 +194,7 @@ inline Layout make_layout(int n_envs, int cap)
     for (int k = 0; k < NI32; k++) { L.off_i32[k] = o; o = align_up(o + 4 * (size_t)n_envs * cap, 256); }
     L.off_actor_flat = o; o = align_up(o + ACTOR_FLAT_BYTES, 256);
     L.off_actor_packed = o; o = align_up(o + ACTOR_PACKED_BYTES, 256);
+    L.off_queue = o; o = align_up(o + sizeof(RolloutQueue) + 4 * (size_t)n_envs, 256);
     L.total = o;
     return L;
 }

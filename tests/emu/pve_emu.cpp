@@ -234,6 +234,8 @@ struct Backend {
     static void leave_device(int) {}
     static void *dmalloc(size_t n) { return calloc(1, n); }
     static void dfree(void *p) { free(p); }
+    static int memset0(void *p, size_t n, void *) { memset(p, 0, n); return 0; }
+    static int n_xcc(int) { return 1; }
     static int d2h(void *dst, const void *src, size_t n, void *) { memcpy(dst, src, n); return 0; }
     static int sync(void *, std::string &) { return 0; }
     static int launch_tick(const Const &c, const Params &P, int cap, void *, std::string &)
@@ -244,6 +246,7 @@ struct Backend {
     static int launch_rollout(const Const &c, const Params &P_in, const RolloutArgs &R, int cap, void *, std::string &)
     {
         if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2) return 1;
+        if (R.queue) return 1;    // the persistent form is a launch shape of the HIP library; the emulator runs the chunked one
         Params P = P_in;
         RolloutArgs Rk = R;
         if (R.source == 1) {

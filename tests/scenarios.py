@@ -495,9 +495,11 @@ def check_pipelined_equals_single(backend, n_envs=7, n_sub=3, capacity=128, tick
 
 
 def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1, 7, 40, 3, 60), rate=1100.0,
-                    prefill=0, trajectory_chunk=12, arrivals=None):
+                    prefill=0, trajectory_chunk=12, arrivals=None, persistent=False):
     """pve_step_many (n ticks per call, action source on the device) == n single-tick calls, bit for bit: persistent
-    state, headers, observation rows, last-tick outputs and -- trajectory mode -- the outputs of every tick."""
+    state, headers, observation rows, last-tick outputs and -- trajectory mode -- the outputs of every tick.
+    persistent=True: the calls that are split into several chunks run as ONE launch whose workgroups pull (intersection,
+    chunk) items from the work queue (pve_rollout.persistent)."""
     from pve_mcc_amd._capi import PveError
     n_pool = 5
     rng = np.random.default_rng(seed)
@@ -544,7 +546,7 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
     for n in chunks:
         for _ in range(n):
             o1 = single()
-        o2 = many.step_many(n, source=source, chunk=(0 if n < 6 else (n // 3 + 1)))     # also in several launches
+        o2 = many.step_many(n, source=source, chunk=(0 if n < 6 else (n // 3 + 1)), persistent=persistent)     # also in several launches
         one.synchronize(); many.synchronize()
         assert many.ticks == one.ticks
         batches_equal(one, many, "%s, chunk of %d" % (source, n))
@@ -816,7 +818,7 @@ def check_full_size_vs_oracle(backend, n_envs, capacity, rate, ticks=420, n_samp
 
 
 def check_driver_shape_vs_oracle(backend, n_envs=4096, n_sub=2, capacity=128, rate=1100.0, chunk=5, n_sample=16,
-                                 calls=(50, 50, 50, 50, 50, 50, 5, 20), n_pool=16, seed=20250213, trajectory=False):
+                                 calls=(50, 50, 50, 50, 50, 50, 5, 20), n_pool=16, seed=20250213, trajectory=False, persistent=False):
     """Exactly the launch shape the driver's `bench.py --steps 20 --warmup 5` runs:
     PipelinedIntersections, `n_sub` sub-batches on their own streams, pve_step_many calls of 50 (prefill) / 5 (warm-up) /
     20 (timed) ticks split into launches of `chunk` ticks, action pool of 16 slot-indexed entries.  `n_sample` envs spread
@@ -861,7 +863,7 @@ def check_driver_shape_vs_oracle(backend, n_envs=4096, n_sub=2, capacity=128, ra
         if trajectory:
             trajs = pipe.step_many(n, trajectory=ring[ci & 1], chunk=chunk, update_views=False)
         else:
-            pipe.step_many(n, chunk=chunk)
+            pipe.step_many(n, chunk=chunk, persistent=persistent)
         pipe.synchronize()
         for e in sample:
             k, le = pipe.sub_of(e)

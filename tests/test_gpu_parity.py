@@ -385,6 +385,23 @@ def test_gpu_driver_launch_shape_vs_oracle(trajectory):
     assert m["alive_steps"] / m["ticks"] > 50 and peak <= 128
 
 
+@pytest.mark.parametrize("cap,n_envs,chunks,rate", [(128, 37, (1, 7, 40, 3, 60), 1100.0), (64, 300, (30, 5, 47), 400.0),
+                                                    (128, 700, (25, 61), 1100.0)])
+def test_gpu_persistent_step_many_equals_single_ticks(cap, n_envs, chunks, rate):
+    """pve_step_many(persistent = 1): one launch per call, the workgroups pull (intersection, chunk) items from the queue
+    (intersections change hands between workgroups and CUs inside the launch) == single ticks, bit for bit."""
+    scenarios.check_step_many(BACKEND, "pool", n_envs=n_envs, capacity=cap, chunks=chunks, rate=rate, persistent=True)
+    scenarios.check_step_many(BACKEND, "zero", n_envs=max(9, n_envs // 8), capacity=cap, chunks=chunks, rate=rate, persistent=True, seed=5)
+
+
+@pytest.mark.parametrize("chunk", [5, 2])
+def test_gpu_persistent_driver_shape_vs_oracle(chunk):
+    """The persistent launch at full size: ONE batch of 4096 x 128, calls of 50 / 5 / 20 ticks in items of `chunk` ticks
+    pulled from the queue by as many workgroups as the chip holds, 16 envs against their oracles after every call."""
+    m, peak = scenarios.check_driver_shape_vs_oracle(BACKEND, n_sub=1, chunk=chunk, persistent=True)
+    assert m["alive_steps"] / m["ticks"] > 50 and peak <= 128
+
+
 def test_gpu_full_size_actor_closed_loop_matches_small_batch():
     """step_with_actor on 4096 envs == the same streams stepped as a 16-env batch (config 5 at full size)."""
     from pve_mcc_amd.arrivals import synthetic_arrivals
