@@ -321,7 +321,7 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
     arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=(prefill + W + K) * 0.1 + 20.0, seed=seed, lane_num=12)
     obs_dtype = torch.float32 if closed else torch.float64
     outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
-    n_sub, chunk, pers = launch_shape(cap, K, 12, closed)
+    n_sub, chunk, pers = launch_shape(cap, K, 12, closed, n_envs=n_envs)
     if n_sub == 1:
         env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs, obs_dtype=obs_dtype)
     else:
@@ -393,7 +393,7 @@ def persistent_items(K, T):
     return -(-(K - tail) // T) + (1 if tail else 0)
 
 
-def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False):
+def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=4096):
     """Default launch shape of a roll-out of K ticks: (sub-batches, ticks per launch or queue item, persistent).
     Measured on MI355X with 4096 envs (tools/ab_launch_shapes.py, same process, medians):
       12 lanes x 128 slots, pool / zero actions: ONE batch and ONE persistent launch per call whose workgroups pull
@@ -401,9 +401,9 @@ def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False):
         sub-batches in launches of 5; 26.4 against 27.5 us per tick in a 1000-tick region (T = 10 / launches of 25);
       12 lanes x 64 slots: every intersection is resident at once (16 one-wave workgroups per CU): one launch for a short call
         (323 against 341 us for 20 ticks), the persistent queue with T = 10 for a long one (13.6 against 13.9 / 14.4 us);
-      closed loop, id-indexed table, trajectories, 4 / 8 lanes: two stream-pipelined sub-batches, one launch per chunk
-        (their resident kernels have no queue form)."""
-    if lane_num == 12 and not actor and not table and not trajectory:
+      closed loop, 4 / 8 lanes, small batches: two stream-pipelined sub-batches, one launch per chunk (their resident kernels
+        have no queue form; a batch below twice the chip's resident workgroups gives the queue nothing to balance)."""
+    if lane_num == 12 and not actor and n_envs >= 4096:     # (the queue balances a batch of >= 2x the workgroups the chip holds)
         if cap == 128:
             return 1, (10 if K >= 100 else 6), True
         return (1, 10, True) if K >= 100 else (1, 0, False)
@@ -566,10 +566,10 @@ def main(argv=None, env_factory=None):
     outputs = tuple(x for x in args.outputs.split(",") if x)
     # launch shape: launch_shape()'s measured default unless --pipeline / --chunk / --persistent say otherwise
     rollout_like = (args.mode or ("rollout" if not emu else "step")) == "rollout"
-    d_sub, d_chunk, d_pers = launch_shape(cap, K, lane_num, args.actor, table=(args.tape == "id-sin"), trajectory=bool(args.trajectory))
+    d_sub, d_chunk, d_pers = launch_shape(cap, K, lane_num, args.actor, n_envs=n_envs)
     if not rollout_like:
         d_sub, d_chunk, d_pers = 2, 0, False
-    can_pers = lane_num == 12 and not args.actor and rollout_like and not emu and args.tape == "pool" and not args.trajectory
+    can_pers = lane_num == 12 and not args.actor and rollout_like and not emu
     pers = can_pers and args.chunk != 0 and \
         (bool(args.persistent) if args.persistent is not None else (d_pers and args.pipeline in (None, 1)))
     if args.pipeline is None:
@@ -613,7 +613,7 @@ def main(argv=None, env_factory=None):
     tick = [0]
     step_kw = {"wait": False} if sub_streams else {}     # the pool upload was synchronised above
     # retained per-tick outputs: a ring of two chunk buffers per sub-batch (the consumer reads one while the next fills)
-    traj_len = (args.chunk if args.chunk > 0 else 25) if traj_on else 0
+    traj_len = ((25 if pers else args.chunk) if args.chunk > 0 else 25) if traj_on else 0      # ticks per call = per ring buffer
     ring = [env.alloc_trajectory(traj_len) for _ in range(2)] if traj_on else None
     ring_pos = [0, None, 0]                              # next buffer, (buffer, ticks) of the last call
 
@@ -647,7 +647,8 @@ def main(argv=None, env_factory=None):
         if traj_on:
             for c0 in range(0, n, traj_len):
                 m = min(traj_len, n - c0)
-                env.step_many(m, source=src, trajectory=ring[ring_pos[0]], update_views=False)
+                env.step_many(m, source=src, trajectory=ring[ring_pos[0]], update_views=False,
+                              **({"chunk": args.chunk, "persistent": True} if pers else {}))
                 ring_pos[1], ring_pos[2] = ring_pos[0], m
                 ring_pos[0] ^= 1
         elif mode == "rollout":
@@ -767,11 +768,14 @@ def main(argv=None, env_factory=None):
     # trainer consumes) are timed right behind it, outside the headline region
     companion = None
     if mode == "rollout" and not traj_on and not args.actor and not emu and world == 1 and not args.no_companion:
-        tl = args.chunk if args.chunk > 0 else 25
+        # calls of `tl` ticks, each into one buffer of the ring (with the persistent launch: one launch per call, items of
+        # args.chunk ticks, every tick writing its own block)
+        tl = (min(K, 25) if pers else (args.chunk if args.chunk > 0 else 25))
         ring2 = [env.alloc_trajectory(tl) for _ in range(2)]
         def traj_ticks(n):
             for i, c0 in enumerate(range(0, n, tl)):
-                env.step_many(min(tl, n - c0), source=src, trajectory=ring2[i & 1], update_views=False)
+                env.step_many(min(tl, n - c0), source=src, trajectory=ring2[i & 1], update_views=False,
+                              **({"chunk": args.chunk, "persistent": True} if pers else {}))
         traj_ticks(2 * tl)
         sync()
         tc0 = time.perf_counter()
@@ -779,7 +783,7 @@ def main(argv=None, env_factory=None):
         sync()
         tc = time.perf_counter() - tc0
         tick[0] += 2 * tl + K
-        companion = {"what": "the same workload with every tick's outputs retained (pve_step_many trajectory = 1, launches of %d "
+        companion = {"what": "the same workload with every tick's outputs retained (pve_step_many trajectory = 1, calls of %d "
                              "ticks into a ring of two buffers per sub-batch)" % tl,
                      "ms_per_step": tc / K * 1e3, "value": float(cap) * n_envs * K / tc, "unit": "env-steps/s", "steps": K}
         del ring2
@@ -792,8 +796,8 @@ def main(argv=None, env_factory=None):
         cols_t = int(12 * (rows_t * 0.1 + 4)) + 64
         tab = np.sin(0.37 * np.arange(cols_t, dtype=np.float64)[None, :] + 0.05 * np.arange(rows_t, dtype=np.float64)[:, None])
         env.set_action_table(torch.as_tensor(tab.astype(np.float32).astype(np.float64)))
-        call = env.prepare_step_many(K, source="table", chunk=args.chunk)
-        warm = env.prepare_step_many(min(K, 50), source="table", chunk=args.chunk)
+        call = env.prepare_step_many(K, source="table", chunk=args.chunk, **pers_kw)
+        warm = env.prepare_step_many(min(K, 50), source="table", chunk=args.chunk, **pers_kw)
         warm(); sync()
         ti0 = time.perf_counter()
         call()
@@ -886,7 +890,7 @@ def main(argv=None, env_factory=None):
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
                                       if args.actor else pool_desc),
-                       "envs_per_gpu": n_envs, "capacity": cap, "mode": mode, "ticks_per_launch": tpl,
+                       "envs_per_gpu": n_envs, "capacity": cap, "mode": mode, "ticks_per_launch": tpl, "ticks_per_state_move": t_state,
                        "launch": ("persistent: one launch per call, %d-tick (intersection, chunk) items pulled from a work queue"
                                   % args.chunk) if pers else "one launch per chunk and sub-batch",
                        "per_tick_outputs": ("every tick's outputs written to their own block (trajectory roll-out, ring of 2 "

@@ -212,7 +212,7 @@ template <int CAP, int WPE, bool PROF = false, bool ACT = false, bool TRAIN = fa
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout(const Const c_arg, const Params P_arg,
                                                                                                const RolloutArgs R_arg)
 {
-    static_assert(!PERS || (!PROF && !ACT && !TRAIN && !IDT), "the persistent form exists for the pool / zero sources");
+    static_assert(!PERS || (!PROF && !ACT && !TRAIN), "the persistent form exists for the pool / zero / table sources");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     __shared__ Shared<CAP> sh;
@@ -275,10 +275,8 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             k_base_ = (ch < R.n_full ? ch : R.n_full) * R.n_ticks;
             for (int q = 0; q < ch - R.n_full; q++) k_base_ += R.taper[q];              // (uniform: scalar loop over <= 7 entries)
             n_ticks = ch < R.n_full ? R.n_ticks : (int)R.taper[ch - R.n_full];
-            if (R.source == 1) {
-                pool_idx = (R.pool_tick0 + k_base_) % R.n_pool;
-                act0 = R.pool + (size_t)pool_idx * (size_t)P.n_envs * CAP;
-            }
+            if (R.source == 1 || R.source == 3) pool_idx = (R.pool_tick0 + k_base_) % R.n_pool;
+            if (R.source == 1) act0 = R.pool + (size_t)pool_idx * (size_t)P.n_envs * CAP;
         }
         if constexpr (ACT) {
             // the first tick's actions = actor(rows in HBM), before the state is loaded (nothing else is live): the controlled
@@ -755,7 +753,7 @@ struct Backend {
         static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
         const bool train = P.out.obs_pre || P.out.state_pre;
         if (R.queue) {                                                        // persistent form (pve_rollout.persistent)
-            if (train || (R.source != 0 && R.source != 1)) return 1;
+            if (train || R.source == 2) return 1;
             Rk.q_trace = P.phase_cycles;                                      // diagnostics: per-item timestamps instead of phase cycles
             // as many workgroups as the chip holds at once (the queue needs no more; fewer when the call has fewer items)
             static int wgs_per_cu[2] = {0, 0}, n_cu = 0;
@@ -776,7 +774,10 @@ struct Backend {
             long long grid = (long long)wgs_per_cu[ci] * n_cu;
             if (const char *g = getenv("PVE_PERSISTENT_GRID")) { const long long v = atoll(g); if (v > 0) grid = v; }   // A/B knob
             if (grid > items) grid = items;
-            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, false, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
+            if (R.source == 3) {                                               // PVE_SRC_TABLE (same register budget: same residency)
+                if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, true, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
+                else hipLaunchKernelGGL((k_rollout<128, 4, false, false, false, true, true>), dim3((unsigned)grid), dim3(128), 0, s, c, P, Rk);
+            } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, false, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
             else hipLaunchKernelGGL((k_rollout<128, 4, false, false, false, false, true>), dim3((unsigned)grid), dim3(128), 0, s, c, P, Rk);
             return check_launch(err);
         }

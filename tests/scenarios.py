@@ -552,7 +552,7 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
         batches_equal(one, many, "%s, chunk of %d" % (source, n))
         same_outputs(o1, o2, "%s, chunk of %d" % (source, n))
     # trajectory mode: every tick's outputs
-    traj = many.step_many(trajectory_chunk, source=source, trajectory=True, chunk=trajectory_chunk // 2 + 1)
+    traj = many.step_many(trajectory_chunk, source=source, trajectory=True, chunk=trajectory_chunk // 2 + 1, persistent=persistent)
     for k in range(trajectory_chunk):
         o1 = single()
         same_outputs(o1, {n: traj[n][k] for n in traj}, "trajectory tick %d" % k)

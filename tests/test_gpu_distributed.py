@@ -60,7 +60,7 @@ def test_bench_gpus_1_through_the_self_launcher_path():
     per_tick = 128 * 256 / (d["ms_per_step"] * 1e-3) / 1e9
     assert abs(r["nominal"]["achieved"] - 380.0 * per_tick) / r["nominal"]["achieved"] < 1e-9
     # pve_step_many launches of T ticks move the persistent state (124 of the 380 B) once per launch, not once per tick
-    T = d["config"]["ticks_per_launch"]
+    T = d["config"]["ticks_per_state_move"]            # (= ticks per launch; per queue item of a persistent launch)
     assert d["config"]["mode"] == "rollout" and abs(r["alg_bytes_per_slot_step"] - (380.0 - 124.0 * (1 - 1.0 / T))) < 1e-9
     assert abs(r["achieved"] - r["alg_bytes_per_slot_step"] * per_tick) / r["achieved"] < 1e-9
     assert d["verified"] is True and d["ranks"]["seen"] == 1

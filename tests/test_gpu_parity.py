@@ -392,6 +392,8 @@ def test_gpu_persistent_step_many_equals_single_ticks(cap, n_envs, chunks, rate)
     (intersections change hands between workgroups and CUs inside the launch) == single ticks, bit for bit."""
     scenarios.check_step_many(BACKEND, "pool", n_envs=n_envs, capacity=cap, chunks=chunks, rate=rate, persistent=True)
     scenarios.check_step_many(BACKEND, "zero", n_envs=max(9, n_envs // 8), capacity=cap, chunks=chunks, rate=rate, persistent=True, seed=5)
+    scenarios.check_step_many(BACKEND, "table", n_envs=max(9, n_envs // 4), capacity=cap, chunks=chunks, rate=rate, persistent=True, seed=6,
+                              trajectory_chunk=24)
 
 
 @pytest.mark.parametrize("chunk", [5, 2])
