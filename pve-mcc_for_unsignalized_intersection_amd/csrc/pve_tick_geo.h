@@ -622,7 +622,88 @@ template <int CAP> struct TickGeo {
             // otherwise (near ties) the exact insertion below decides.
             const int base = sh.lbase[d], n = sh.fill[d], mp = sh.mypos[t];
             bool done = false;
-            {
+            if (tabf) {
+                // TABLE FORM (the common case): the current value of an opposing entry is one table cell, so every lookup is an
+                // UNCONDITIONAL read on a clamped index and the members of a round go through three batches of independent
+                // LDS reads (position -> slot / entry; entry -> distance, slot -> route / rank; rank -> table cell) instead of
+                // a guarded chain of two dependent reads per member; the 6 winners and the predecessor are re-read the same
+                // way, as one batch of 7.  (Round 3 spent 29 % of the 4-lane wave time here, almost all of it LDS round trips.)
+                const int tsafe = sh.tstart;                  // a cell that exists whenever the table does
+                unsigned k7[NNB + 1];
+#pragma unroll
+                for (int k = 0; k < NNB + 1; k++) k7[k] = ~0u;
+                for (int i0 = 0; i0 < n; i0 += 8) {
+                    int xs[8], es[8], rts[8], rks[8]; double vos[8], tvs[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int i = (i0 + k < n) ? i0 + k : n - 1;
+                        xs[k] = sh.s_slot[base + i]; es[k] = sidx_at(sh.s_idx, base + i);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { PVE_PIN(xs[k]); PVE_PIN(es[k]); }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { vos[k] = sh.u_vd[es[k]]; rts[k] = sh.route_of[xs[k]]; rks[k] = sh.rk[xs[k]]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { PVE_PIN(vos[k]); PVE_PIN(rts[k]); PVE_PIN(rks[k]); }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) tvs[k] = sh.u_vd[rts[k] == opp ? tcol + rks[k] * tcols : tsafe];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) PVE_PIN(tvs[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int i = i0 + k;
+                        const bool valid = (i < n) & (i != mp);
+                        const double vc = rts[k] == opp ? tvs[k] : vos[k];
+                        const unsigned key = valid ? ((Base::f32_bits((float)fabs(vc - me)) & ~127u) | (unsigned)i) : ~0u;
+                        unsigned c = key;                     // insertion into the sorted 7: one min / max pair per place
+#pragma unroll
+                        for (int q = 0; q < NNB + 1; q++) { const unsigned lo_ = Base::umin(k7[q], c), hi_ = Base::umax(k7[q], c); k7[q] = lo_; c = hi_; }
+                    }
+                }
+                // the winners (and the predecessor, element NNB) in float64: one batch of 7 through the same three reads
+                int wi[NNB + 1], wx[NNB + 1], we[NNB + 1], wr[NNB + 1], wk[NNB + 1]; double wo[NNB + 1], wt[NNB + 1];
+                bool ok = (k7[NNB] == ~0u) | (((k7[NNB] ^ k7[NNB - 1]) >> 7) != 0u) | (k7[NNB - 1] == ~0u);
+#pragma unroll
+                for (int k = 0; k < NNB + 1; k++) {
+                    wi[k] = k < NNB ? ((k7[k] != ~0u) ? (int)(k7[k] & 127u) : 0) : (mp > 0 ? mp - 1 : 0);
+                    wx[k] = sh.s_slot[base + wi[k]]; we[k] = sidx_at(sh.s_idx, base + wi[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < NNB + 1; k++) { PVE_PIN(wx[k]); PVE_PIN(we[k]); }
+#pragma unroll
+                for (int k = 0; k < NNB + 1; k++) { wo[k] = sh.u_vd[we[k]]; wr[k] = sh.route_of[wx[k]]; wk[k] = sh.rk[wx[k]]; }
+#pragma unroll
+                for (int k = 0; k < NNB + 1; k++) { PVE_PIN(wo[k]); PVE_PIN(wr[k]); PVE_PIN(wk[k]); }
+#pragma unroll
+                for (int k = 0; k < NNB + 1; k++) wt[k] = sh.u_vd[wr[k] == opp ? tcol + wk[k] * tcols : tsafe];
+#pragma unroll
+                for (int k = 0; k < NNB + 1; k++) PVE_PIN(wt[k]);
+                double wv[NNB], wd[NNB];
+#pragma unroll
+                for (int k = 0; k < NNB; k++) {
+                    const bool has = k7[k] != ~0u;
+                    const double vc = wr[k] == opp ? wt[k] : wo[k];
+                    wx[k] = has ? wx[k] : -1; wv[k] = has ? vc : 0.0; wd[k] = has ? fabs(vc - me) : INFINITY;
+                }
+#pragma unroll
+                for (int k = 1; k < NNB; k++)
+                    ok = ok & ((wx[k] < 0) | (wd[k - 1] < wd[k]) | ((wd[k - 1] == wd[k]) & (wi[k - 1] < wi[k])));
+                if (ok) {
+#pragma unroll
+                    for (int k = 0; k < NNB; k++) { r.kr[k] = wx[k]; r.kv[k] = wv[k]; }
+                    // predecessor in list order (ref :1353) with its current value
+                    const int bs = mp > 0 ? wx[NNB] : -1;
+                    const double bv = wr[NNB] == opp ? wt[NNB] : wo[NNB];
+                    r.hdr = bs;                                                             // ref :1348-1354
+                    r.vir_dis = (bs >= 0) ? (me - bv) : 100.0;
+                    sh.hdr[t] = (int16_t)bs;
+                    sh.virdis[t] = r.vir_dis;
+                    r.count += 1;                                                           // ref :292
+                    done = true;
+                }
+            } else {
+                // REPLAY FORM (no room for the table behind the entry pool): the same selection with the adjustments replayed
+                // per opposing member (a guarded block per member)
                 unsigned k7[NNB + 1];
 #pragma unroll
                 for (int k = 0; k < NNB + 1; k++) k7[k] = ~0u;

@@ -20,7 +20,7 @@ def free_port():
     return p
 
 
-def check_line(out, n):
+def check_line(out, n, envs=12):
     lines = [l for l in out.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
     d = json.loads(lines[0])
@@ -36,16 +36,16 @@ def check_line(out, n):
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     else:
         assert "cpu_baseline" not in d
-    assert abs(d["value"] - 64 * 12 * 6 * n / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6
+    assert abs(d["value"] - 64 * envs * 6 * n / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6
     # roofline.achieved follows from the line's own wall clock: B_alg x slots of ONE GPU / time per tick
-    assert abs(r["achieved"] - 380.0 * 64 * 12 / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
+    assert abs(r["achieved"] - 380.0 * 64 * envs / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
     assert d["population"] in ("steady", "cold") and "mean_alive_per_env" in d and "prefill_ticks" in d
     # the line certifies itself: sampled envs of the timed run replayed by the oracle
-    assert d["verified"] is True and d["verification"]["ticks_replayed"] == 9 and len(d["verification"]["envs"]) == 8
+    assert d["verified"] is True and d["verification"]["ticks_replayed"] == 9 and len(d["verification"]["envs"]) == min(8, envs)
     # ... and shows that n ranks took part, each with its own envs (item 2d / 7)
     rk = d["ranks"]
     assert rk["seen"] == n and len(rk["ms"]) == n and rk["ticks"] == [6.0] * n
-    assert rk["first_env"] == [12 * k for k in range(n)] and rk["envs_per_rank"] == 12      # disjoint env ranges = disjoint seeds
+    assert rk["first_env"] == [envs * k for k in range(n)] and rk["envs_per_rank"] == envs      # disjoint env ranges = disjoint seeds
     assert all(ms > 0 for ms in rk["ms"]) and max(rk["ms"]) <= d["ms_per_step"] * 6 * (1 + 1e-9)
     assert r["nominal"]["alg_bytes_per_slot_step"] == 380.0 and "binding" in r
     return d
@@ -89,6 +89,26 @@ def test_bench_self_launches_two_ranks():
     assert p.returncode == 0
     d = check_line(p.stdout, 2)
     assert d["config"]["parallelism"] == "env-parallel x2"
+
+
+def test_bench_self_launches_eight_ranks_config_4_sharding():
+    """BASELINE config 4's shape on CPU: `bench.py --gpus 8` starts eight ranks itself, every rank owns its own envs
+    (weak scaling: rank k simulates global envs [k E, (k + 1) E), arrival seeds 20250213 + global env index), the single
+    all-gather carries eight metric vectors, the timing is the MAX over ranks and every rank's sampled envs verify.  With
+    E = 4096 that partition is exactly shard_range(32768, k, 8) -- 32 768 intersections x 64 slots over 8 GPUs."""
+    from pve_mcc_amd.distributed import shard_range
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, "tests/bench_emulated_launcher.py", "--gpus", "8", "--envs", "5", "--capacity", "64",
+                        "--steps", "6", "--warmup", "3", "--prefill", "0"], cwd=ROOT, text=True, timeout=1200, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    assert p.returncode == 0
+    d = check_line(p.stdout, 8, envs=5)
+    assert d["config"]["parallelism"] == "env-parallel x8" and d["ranks"]["seen"] == 8
+    assert d["ranks"]["arrival_seeds"] == "20250213 + first_env + e"
+    # the same rule at config 4's size: rank k's first env = k x 4096 = the start of shard k of 32 768
+    assert [shard_range(32768, k, 8) for k in range(8)] == [(4096 * k, 4096 * (k + 1)) for k in range(8)]
+    assert d["value"] > 0 and d["overflow"] == 0
 
 
 def test_bench_verification_detects_a_wrong_tape():
