@@ -100,8 +100,6 @@ class BatchedIntersections:
             self._obs = [torch.zeros(E, K, 28, dtype=obs_dtype, device=dev)
                          for _ in range(2 if "state_pre" in names else 1)]
             self._obs_cur = 0
-        if obs_dtype == torch.float32 and self.lane_num != 12 and ("obs_pre" in names or "state_pre" in names):
-            raise PveError("obs_pre / state_pre with float32 rows need lane_num = 12")
         shapes = dict(obs_pre=((E, K, 28), obs_dtype), state_pre=((E, K, 7, 28), obs_dtype),
                       reward=((E, K), torch.float64), flags=((E, K), torch.int32), lanej=((E, K), torch.int32),
                       nbr=((E, K, 6), torch.int32), new_slot=((E, K), torch.int32), env_out=((E, 8), torch.int32))

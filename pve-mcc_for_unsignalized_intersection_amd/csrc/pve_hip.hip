@@ -506,6 +506,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu((CAP == 64 
     PVE_PHASE_MARK(7)
     B::ph_prefetch_arrival(P, env, t, sh, r, g.lane_num);
     B::ph_lock_slot(g.base, t, sh, r);
+    if (P.out.state_pre) T::ph_state_order(t, sh, r);   // (uniform)
     lds_barrier();
     B::ph_lock2_slot(t, sh, r);
     lds_barrier();
@@ -530,7 +531,10 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu((CAP == 64 
 // prefetched actions / arrival times touch HBM.  What it buys beyond the bytes: a launch of k_tick_geo lasts as long as its
 // slowest intersection (43 us against a mean of 30 for 4 lanes x 64 slots); here a slow tick of one intersection is
 // averaged over the ticks of the launch.
-template <int CAP, bool FIX4 = false, int WPE = 4>
+// TRAIN: the training outputs (obs_pre, state_pre) per tick of a trajectory roll-out; IDT: PVE_SRC_TABLE (actions by (tick,
+// vehicle id), gathered by the vehicle's own thread and parked at its NEW slot in `p[]`, which is free between FIN and the next
+// S1) -- as in k_rollout, variants of their own so that the default kernel keeps its register allocation.
+template <int CAP, bool FIX4 = false, int WPE = 4, bool TRAIN = false, bool IDT = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout_geo(const GeoConst g_arg, const Params P_arg,
                                                                                                 const RolloutArgs R_arg)
 {
@@ -554,7 +558,12 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         T::ph_load(g, P, env0_, t0_, sh, r);            // P.actions = the first tick's actions
         lds_barrier();
         T::ph_load_late(P, env0_, t0_, sh, r);
+        if constexpr (IDT) {                            // the first tick's action of the vehicle in this slot: table[row][id]
+            const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
+            r.act = r.alive ? R.pool[(size_t)pool_idx * (size_t)R.table_ids + idc] : 0.0;
+        }
     }
+    double sp_act = 0;                                  // IDT: the action of the vehicle this lane spawns
     for (int k = 0; k < n_ticks; k++) {
         // (the same opaque re-definitions as in k_rollout: nothing derived from the arguments is hoisted out of the loop)
         asm volatile("" : "+s"(kav_), "+v"(t0_), "+s"(env0_));
@@ -593,24 +602,41 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         lds_barrier();
         int nx = -1;
         if (k + 1 < n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
-        B::ph_prefetch_action(P, R, env, t, nx, r);
+        if constexpr (IDT) {
+            const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
+            r.act_nx = (nx >= 0 && r.alive) ? R.pool[(size_t)nx * (size_t)R.table_ids + idc] : 0.0;
+        } else B::ph_prefetch_action(P, R, env, t, nx, r);
         T::ph_effects(g, t, sh, r);
         T::ph_lists_clear(t, sh);
         lds_barrier();
         B::ph_prefetch_arrival(P, env, t, sh, r, g.lane_num);
         B::ph_lock_slot(g.base, t, sh, r);
+        const Outputs O = B::template tick_outputs<TRAIN>(P, R, k);
+        if (TRAIN && O.state_pre) T::ph_state_order(t, sh, r);    // (uniform; `ord` is staging storage from FIN on)
         lds_barrier();
         B::ph_lock2_slot(t, sh, r);
         lds_barrier();
-        const Outputs O = B::template tick_outputs<false>(P, R, k);
-        T::template ph_final<true>(g, P, O, env, t, sh, r, fc, k + 1 == n_ticks);
+        T::template ph_final<true>(g, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
+        if constexpr (IDT) {
+            if (!fc.still && fc.new_slot >= 0) sh.p[fc.new_slot] = r.act_nx;      // (p[] is free between FIN and the next S1)
+            sp_act = 0;                               // the vehicle this lane spawns (id known since FIN): its first action
+            if (fc.sp_slot >= 0 && nx >= 0) {
+                const int idc = fc.sp_id < R.table_ids ? fc.sp_id : R.table_ids - 1;
+                sp_act = R.pool[(size_t)nx * (size_t)R.table_ids + idc];
+            }
+        }
         if (fc.still) {                               // (uniform) nobody moves: the registers carry over
             T::ph_carry_over(t, sh, r, fc);
         } else {
             lds_barrier();                            // A: nobody reads the tick's work arrays any more
+            if (TRAIN && O.state_pre) T::ph_state(P, O, env, t, sh, r);   // (uniform; barrier A also orders the obs_pre rows of this tick)
             T::ph_stage(g, t, sh, r, fc);
+            if constexpr (IDT) { if (fc.sp_slot >= 0) sh.p[fc.sp_slot] = sp_act; }
             lds_barrier();                            // B: the staging area is complete
-            if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
+            if (k + 1 < n_ticks) {
+                T::ph_reload(t, sh, r);
+                if constexpr (IDT) r.act = sh.p[t];
+            }
         }
     }
     {
@@ -808,7 +834,8 @@ struct Backend {
     static int launch_rollout_geo(const GeoConst &g, const Params &P_in, const RolloutArgs &R, int cap, void *stream, std::string &err)
     {
         static const bool off = getenv("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
-        if (off || R.source == 2 /* the actor reads 12-lane rows */ || P_in.phase_cycles || P_in.out.obs_pre || P_in.out.state_pre) return 1;
+        const bool train = P_in.out.obs_pre || P_in.out.state_pre;
+        if (off || R.source == 2 /* the actor reads 12-lane rows */ || P_in.phase_cycles || R.queue || (train && R.source == 3)) return 1;
         hipStream_t s = (hipStream_t)stream;
         Params P = P_in;
         RolloutArgs Rk = R;
@@ -816,15 +843,24 @@ struct Backend {
             Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
+        if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
+        const dim3 grid(P.n_envs);
+        // (variant = layout x capacity x {default, training outputs, id-indexed table})
+#define PVE_LAUNCH_GEO(CAP_, FIX_)                                                                                              \
+        do {                                                                                                                    \
+            if (train) hipLaunchKernelGGL((k_rollout_geo<CAP_, FIX_, 4, true, false>), grid, dim3(CAP_), 0, s, g, P, Rk);       \
+            else if (R.source == 3) hipLaunchKernelGGL((k_rollout_geo<CAP_, FIX_, 4, false, true>), grid, dim3(CAP_), 0, s, g, P, Rk); \
+            else hipLaunchKernelGGL((k_rollout_geo<CAP_, FIX_>), grid, dim3(CAP_), 0, s, g, P, Rk);                             \
+        } while (0)
         if (g.lane_num == 4) {
-            if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, true>), dim3(P.n_envs), dim3(64), 0, s, g, P, Rk);
-            else hipLaunchKernelGGL((k_rollout_geo<128, true>), dim3(P.n_envs), dim3(128), 0, s, g, P, Rk);
-        } else if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, false>), dim3(P.n_envs), dim3(64), 0, s, g, P, Rk);
+            if (cap == 64) PVE_LAUNCH_GEO(64, true); else PVE_LAUNCH_GEO(128, true);
+        } else if (cap == 64) PVE_LAUNCH_GEO(64, false);
         else {
             static const bool w5 = getenv("PVE_ROLLOUT_GEO_WPE5") != nullptr;     // A/B knob: 96-VGPR build, 10 workgroups per CU
-            if (w5) hipLaunchKernelGGL((k_rollout_geo<128, false, 5>), dim3(P.n_envs), dim3(128), 0, s, g, P, Rk);
-            else hipLaunchKernelGGL((k_rollout_geo<128, false>), dim3(P.n_envs), dim3(128), 0, s, g, P, Rk);
+            if (w5 && !train && R.source != 3) hipLaunchKernelGGL((k_rollout_geo<128, false, 5>), grid, dim3(128), 0, s, g, P, Rk);
+            else PVE_LAUNCH_GEO(128, false);
         }
+#undef PVE_LAUNCH_GEO
         return check_launch(err);
     }
     static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)

@@ -54,7 +54,7 @@ template <int CAP> struct SharedGeo {
     double s_vd[1];
     alignas(8) unsigned s_idx[PE];          // sorted position -> entry | tick tag << 16 (cf. Shared<128>, Tick::ph_rank)
     alignas(8) uint8_t u_slot[PE], u_list[PE];
-    alignas(8) uint8_t s_slot[PE];          // slot of the entry at every sorted position (read by the 4-lane left-turn egos)
+    alignas(8) uint8_t s_slot[PE];          // (k_rollout_geo's staging storage: sti<4>)
     // k_rollout_geo keeps the state on the chip between two ticks (cf. Shared<CAP>): every persistent field of every vehicle
     // moves to its new slot through storage that is dead by FIN -- the entry pool beyond the dead-lock records, virdis, the
     // sorted-list arrays, cnt, ord / slot_at (EARLY, at the top of FIN); p into u_vd[0 .. CAP), v and a in place (LATE,
@@ -72,6 +72,11 @@ template <int CAP> struct SharedGeo {
     int16_t mypos[CAP];                     // sorted position of every controlled vehicle's own entry in its route's list
     int rc[ND], rfill[ND], fill[ND], cnt2[ND], pool_ok;   // controlled vehicles per route, claimed so far; entries filed per list;
                                             // exact member counts (only when the upper bounds overflow the pool)
+    // 4-lane layout: the entries of the OPPOSING left-turn route in the list of a left-turn route are re-written ego by ego (ref
+    // :1301-1319), so they have no place in the sorted list: they are filed from the BACK of the list's capacity (ofill of
+    // them: entry lbase[d + 1] - 1 - k), unsorted, and every ego of the route merges those few into what the window walk over
+    // the sorted rest returns (round 3 visited every member of the list per ego: 23 % of the 4-lane tick)
+    int ofill[ND];
     int16_t lnew[ND];
     int16_t lbase[ND + 1];                  // list d owns [lbase[d], lbase[d] + fill[d]) (capacity: the next lbase)
     int16_t rbase[ND + 1], pbase[ND + 1];   // prefix of rc (route-sorted controlled vehicles) and of rc * nl (pairs)
@@ -193,7 +198,7 @@ template <int CAP> struct TickGeo {
             sh.acc_passed_steps = 0; sh.acc_collisions = 0; sh.lead_n = 0;
             sh.v[CAP] = 0; sh.a[CAP] = 0; sh.lane_of[CAP] = 0; sh.route_of[CAP] = 0;      // the zero cell (FIN's absent neighbours)
         }
-        if (t < ND) { sh.rc[t] = 0; sh.rfill[t] = 0; sh.fill[t] = 0; sh.cnt2[t] = 0; }
+        if (t < ND) { sh.rc[t] = 0; sh.rfill[t] = 0; sh.fill[t] = 0; sh.cnt2[t] = 0; sh.ofill[t] = 0; }
     }
 
     // jerk_sum, closer_p and vir_dis are first touched in WALK / REWARD (ref :302, :321, :1348), the id only by FIN: their
@@ -326,8 +331,10 @@ template <int CAP> struct TickGeo {
             if (!ok) continue;
             const double vo = own ? px : (same ? qd + inb_m : (delta + e2) - e3);
             if (COUNT) { lds_add(&sh.cnt2[d], 1); continue; }
-            const int e = sh.lbase[d] + lds_claim(&sh.fill[d], 1);
-            sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)x; sh.u_list[e] = (uint8_t)d;
+            // (4-lane layout, list of a left-turn route, member of the opposing left-turn route: from the back, not sorted)
+            const bool back = (g.lane_num == 4) & (ty == 0) & (rt == (int)sh.tab.opp[d]) & !own;
+            const int e = back ? (sh.lbase[d + 1] - 1 - lds_claim(&sh.ofill[d], 1)) : (sh.lbase[d] + lds_claim(&sh.fill[d], 1));
+            sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)x; sh.u_list[e] = (uint8_t)(back ? 0xFF : d);
         }
     }
     // The common case -- the capacity upper bounds fit the entry pool -- needs neither the counting pass nor the two
@@ -442,7 +449,7 @@ template <int CAP> struct TickGeo {
 #pragma unroll
                 for (int k = 0; k < 7; k++) pos += (k < n) & (w[k] < vd);
             }
-            lds_store_relaxed(&sh.s_slot[lo + pos], (uint8_t)slot);               // (relaxed atomics released by the claim: Tick::ph_rank)
+            // (relaxed atomic, released by the claim: Tick::ph_rank)
             if (d == sh.route_of[slot]) lds_store_relaxed(&sh.mypos[slot], (int16_t)pos);   // the vehicle's own entry (vd = p)
             const unsigned old = lds_xchg(&sh.s_idx[lo + pos], tag | (unsigned)e);
             if ((old & 0xFFFF0000u) == tag) {             // an entry with the same distance was here first (or a stale word)
@@ -452,7 +459,6 @@ template <int CAP> struct TickGeo {
                     int rk = 0;
                     for (int g = lo; g < hi; g++) rk += (sh.u_vd[g] == vd && sh.u_slot[g] < sf) ? 1 : 0;
                     lds_store_relaxed(&sh.s_idx[lo + pos + rk], tag | (unsigned)f);
-                    lds_store_relaxed(&sh.s_slot[lo + pos + rk], (uint8_t)sf);
                     if (d == sh.route_of[sf]) lds_store_relaxed(&sh.mypos[sf], (int16_t)(pos + rk));
                 }
             }
@@ -521,7 +527,14 @@ template <int CAP> struct TickGeo {
             if (sh.hd.lane_start[li + 1] > sh.hd.lane_start[li]) {
                 double best = INFINITY; int bs = -1;
                 if (lists) {
-                    if (sh.fill[d] > 0) bs = sh.u_slot[sidx_at(sh.s_idx, sh.lbase[d])];                  // sorted: the first entry
+                    if (sh.fill[d] > 0) { const int e0 = sidx_at(sh.s_idx, sh.lbase[d]); bs = sh.u_slot[e0]; best = sh.u_vd[e0]; }   // sorted: the first entry
+                    if (FIX4) {                           // ... or one of the unsorted opposing entries (4-lane left-turn lists)
+                        const int no = sh.ofill[d], eb = sh.lbase[d + 1] - 1;
+                        for (int k = 0; k < no; k++) {
+                            const double vo = sh.u_vd[eb - k]; const int x = sh.u_slot[eb - k];
+                            if (vo < best || (vo == best && x < bs)) { best = vo; bs = x; }
+                        }
+                    }
                 } else {
                     for (int w = 0; w < NW; w++)
                         for (u64 bits = sh.m_ctl[w]; bits; bits &= bits - 1) {
@@ -601,171 +614,56 @@ template <int CAP> struct TickGeo {
                 }
             }
         };
-        if (lists && !fix) {
-            // sorted list, no entry is ever re-written: the 12-lane kernel's window walk (ref :1340-1405)
+        if (lists) {
+            // sorted list: the 12-lane kernel's window walk (ref :1340-1405).  The lists of the 4-lane left-turn routes hold
+            // everything BUT the entries of the opposing left-turn route there, whose values this ego sees re-written (ref
+            // :1301-1319); those few (ofill[d], unsorted, at the back of the list's capacity) are merged into the walk's result:
+            // the predecessor by build-time order (ref :1353), the 6 nearest by current distance (ref :1383-1397).  Equal
+            // distances between a merged entry and a winner -- the reference's stable sort then decides by list position, which
+            // the split list does not carry -- take the exact insertion below.
             int pr; double pvd;
             Base::walk_window(sh, sh.lbase[d], sh.fill[d], sh.mypos[t], me, r, pr, pvd);
-            r.hdr = pr;                                                                 // ref :1348-1354
-            r.vir_dis = (pr >= 0) ? (me - pvd) : 100.0;
-            sh.hdr[t] = (int16_t)pr;
-            sh.virdis[t] = r.vir_dis;
-            r.count += 1;                                                               // ref :292
-            return;
-        }
-        if (lists) {
-            // 4-lane left-turn routes: the entries of the opposing left-turn route are re-written ego by ego (ref
-            // :1301-1319), so these egos look at every member of their list.  FAST FORM: the members are visited in list
-            // order, 8 at a time (two batches of independent LDS reads per 8 members); each becomes a 32-bit key = the
-            // float32 image of |current distance - own| with its low 7 bits replaced by the list position; the 7 smallest
-            // keys are kept by a min / max chain.  The 6 winners are then re-derived in float64 and must be strictly
-            // ordered by (distance, position), and the 7th key must differ from the 6th above the position bits --
-            // otherwise (near ties) the exact insertion below decides.
-            const int base = sh.lbase[d], n = sh.fill[d], mp = sh.mypos[t];
-            bool done = false;
-            if (tabf) {
-                // TABLE FORM (the common case): the current value of an opposing entry is one table cell, so every lookup is an
-                // UNCONDITIONAL read on a clamped index and the members of a round go through three batches of independent
-                // LDS reads (position -> slot / entry; entry -> distance, slot -> route / rank; rank -> table cell) instead of
-                // a guarded chain of two dependent reads per member; the 6 winners and the predecessor are re-read the same
-                // way, as one batch of 7.  (Round 3 spent 29 % of the 4-lane wave time here, almost all of it LDS round trips.)
-                const int tsafe = sh.tstart;                  // a cell that exists whenever the table does
-                unsigned k7[NNB + 1];
+            double pvo = pvd;                                 // build-time distance of the predecessor (order), pvd = its current value
+            bool amb = false;
+            if (fix) {
+                const int no = sh.ofill[d], eb = sh.lbase[d + 1] - 1;
+                double dk[NNB];
 #pragma unroll
-                for (int k = 0; k < NNB + 1; k++) k7[k] = ~0u;
-                for (int i0 = 0; i0 < n; i0 += 8) {
-                    int xs[8], es[8], rts[8], rks[8]; double vos[8], tvs[8];
+                for (int k = 0; k < NNB; k++) dk[k] = r.kr[k] >= 0 ? fabs(r.kv[k] - me) : INFINITY;
+                for (int q = 0; q < no; q++) {
+                    const int x = sh.u_slot[eb - q];
+                    const double vo = sh.u_vd[eb - q];
+                    const double vc = adj(x, vo);
+                    const bool before = vo < me || (vo == me && x < t);
+                    if (before && (pr < 0 || vo > pvo || (vo == pvo && x > pr))) { pvo = vo; pr = x; pvd = vc; }
+                    double cd = fabs(vc - me), cv = vc; int cs = x;
+                    bool ins = false;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int i = (i0 + k < n) ? i0 + k : n - 1;
-                        xs[k] = sh.s_slot[base + i]; es[k] = sidx_at(sh.s_idx, base + i);
+                    for (int k = 0; k < NNB; k++) {
+                        amb = amb | (cd == dk[k]);
+                        const bool sw = ins | (cd < dk[k]);
+                        ins = sw;
+                        const double td = sw ? dk[k] : cd, tv = sw ? r.kv[k] : cv; const int ts = sw ? r.kr[k] : cs;
+                        dk[k] = sw ? cd : dk[k]; r.kv[k] = sw ? cv : r.kv[k]; r.kr[k] = sw ? cs : r.kr[k];
+                        cd = td; cv = tv; cs = ts;
                     }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { PVE_PIN(xs[k]); PVE_PIN(es[k]); }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { vos[k] = sh.u_vd[es[k]]; rts[k] = sh.route_of[xs[k]]; rks[k] = sh.rk[xs[k]]; }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { PVE_PIN(vos[k]); PVE_PIN(rts[k]); PVE_PIN(rks[k]); }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) tvs[k] = sh.u_vd[rts[k] == opp ? tcol + rks[k] * tcols : tsafe];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) PVE_PIN(tvs[k]);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int i = i0 + k;
-                        const bool valid = (i < n) & (i != mp);
-                        const double vc = rts[k] == opp ? tvs[k] : vos[k];
-                        const unsigned key = valid ? ((Base::f32_bits((float)fabs(vc - me)) & ~127u) | (unsigned)i) : ~0u;
-                        unsigned c = key;                     // insertion into the sorted 7: one min / max pair per place
-#pragma unroll
-                        for (int q = 0; q < NNB + 1; q++) { const unsigned lo_ = Base::umin(k7[q], c), hi_ = Base::umax(k7[q], c); k7[q] = lo_; c = hi_; }
-                    }
-                }
-                // the winners (and the predecessor, element NNB) in float64: one batch of 7 through the same three reads
-                int wi[NNB + 1], wx[NNB + 1], we[NNB + 1], wr[NNB + 1], wk[NNB + 1]; double wo[NNB + 1], wt[NNB + 1];
-                bool ok = (k7[NNB] == ~0u) | (((k7[NNB] ^ k7[NNB - 1]) >> 7) != 0u) | (k7[NNB - 1] == ~0u);
-#pragma unroll
-                for (int k = 0; k < NNB + 1; k++) {
-                    wi[k] = k < NNB ? ((k7[k] != ~0u) ? (int)(k7[k] & 127u) : 0) : (mp > 0 ? mp - 1 : 0);
-                    wx[k] = sh.s_slot[base + wi[k]]; we[k] = sidx_at(sh.s_idx, base + wi[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < NNB + 1; k++) { PVE_PIN(wx[k]); PVE_PIN(we[k]); }
-#pragma unroll
-                for (int k = 0; k < NNB + 1; k++) { wo[k] = sh.u_vd[we[k]]; wr[k] = sh.route_of[wx[k]]; wk[k] = sh.rk[wx[k]]; }
-#pragma unroll
-                for (int k = 0; k < NNB + 1; k++) { PVE_PIN(wo[k]); PVE_PIN(wr[k]); PVE_PIN(wk[k]); }
-#pragma unroll
-                for (int k = 0; k < NNB + 1; k++) wt[k] = sh.u_vd[wr[k] == opp ? tcol + wk[k] * tcols : tsafe];
-#pragma unroll
-                for (int k = 0; k < NNB + 1; k++) PVE_PIN(wt[k]);
-                double wv[NNB], wd[NNB];
-#pragma unroll
-                for (int k = 0; k < NNB; k++) {
-                    const bool has = k7[k] != ~0u;
-                    const double vc = wr[k] == opp ? wt[k] : wo[k];
-                    wx[k] = has ? wx[k] : -1; wv[k] = has ? vc : 0.0; wd[k] = has ? fabs(vc - me) : INFINITY;
-                }
-#pragma unroll
-                for (int k = 1; k < NNB; k++)
-                    ok = ok & ((wx[k] < 0) | (wd[k - 1] < wd[k]) | ((wd[k - 1] == wd[k]) & (wi[k - 1] < wi[k])));
-                if (ok) {
-#pragma unroll
-                    for (int k = 0; k < NNB; k++) { r.kr[k] = wx[k]; r.kv[k] = wv[k]; }
-                    // predecessor in list order (ref :1353) with its current value
-                    const int bs = mp > 0 ? wx[NNB] : -1;
-                    const double bv = wr[NNB] == opp ? wt[NNB] : wo[NNB];
-                    r.hdr = bs;                                                             // ref :1348-1354
-                    r.vir_dis = (bs >= 0) ? (me - bv) : 100.0;
-                    sh.hdr[t] = (int16_t)bs;
-                    sh.virdis[t] = r.vir_dis;
-                    r.count += 1;                                                           // ref :292
-                    done = true;
-                }
-            } else {
-                // REPLAY FORM (no room for the table behind the entry pool): the same selection with the adjustments replayed
-                // per opposing member (a guarded block per member)
-                unsigned k7[NNB + 1];
-#pragma unroll
-                for (int k = 0; k < NNB + 1; k++) k7[k] = ~0u;
-                for (int i0 = 0; i0 < n; i0 += 8) {
-                    int xs[8], es[8], rts[8]; double vos[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int i = (i0 + k < n) ? i0 + k : n - 1;
-                        xs[k] = sh.s_slot[base + i]; es[k] = sidx_at(sh.s_idx, base + i);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { PVE_PIN(xs[k]); PVE_PIN(es[k]); }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { vos[k] = sh.u_vd[es[k]]; rts[k] = sh.route_of[xs[k]]; }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { PVE_PIN(vos[k]); PVE_PIN(rts[k]); }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int i = i0 + k;
-                        const bool valid = (i < n) & (i != mp);
-                        double vc = vos[k];
-                        if (valid && rts[k] == opp) vc = adj(xs[k], vc);
-                        const unsigned key = valid ? ((Base::f32_bits((float)fabs(vc - me)) & ~127u) | (unsigned)i) : ~0u;
-                        unsigned c = key;                     // insertion into the sorted 7: one min / max pair per place
-#pragma unroll
-                        for (int q = 0; q < NNB + 1; q++) { const unsigned lo_ = Base::umin(k7[q], c), hi_ = Base::umax(k7[q], c); k7[q] = lo_; c = hi_; }
-                    }
-                }
-                // the winners in float64 (their current values are what the observation row carries anyway)
-                int wx[NNB], wp[NNB]; double wv[NNB], wd[NNB];
-                bool ok = (k7[NNB] == ~0u) | (((k7[NNB] ^ k7[NNB - 1]) >> 7) != 0u) | (k7[NNB - 1] == ~0u);
-#pragma unroll
-                for (int k = 0; k < NNB; k++) {
-                    const bool has = k7[k] != ~0u;
-                    const int i = has ? (int)(k7[k] & 127u) : 0;
-                    const int x = sh.s_slot[base + i];
-                    double vc = sh.u_vd[sidx_at(sh.s_idx, base + i)];
-                    if (has && sh.route_of[x] == opp) vc = adj(x, vc);
-                    wx[k] = has ? x : -1; wp[k] = i; wv[k] = has ? vc : 0.0; wd[k] = has ? fabs(vc - me) : INFINITY;
-                }
-#pragma unroll
-                for (int k = 1; k < NNB; k++)
-                    ok = ok & ((wx[k] < 0) | (wd[k - 1] < wd[k]) | ((wd[k - 1] == wd[k]) & (wp[k - 1] < wp[k])));
-                if (ok) {
-#pragma unroll
-                    for (int k = 0; k < NNB; k++) { r.kr[k] = wx[k]; r.kv[k] = wv[k]; }
-                    // predecessor in list order (ref :1353) with its current value
-                    int bs = -1; double bv = 0;
-                    if (mp > 0) {
-                        bs = sh.s_slot[base + mp - 1];
-                        bv = sh.u_vd[sidx_at(sh.s_idx, base + mp - 1)];
-                        if (sh.route_of[bs] == opp) bv = adj(bs, bv);
-                    }
-                    r.hdr = bs;                                                             // ref :1348-1354
-                    r.vir_dis = (bs >= 0) ? (me - bv) : 100.0;
-                    sh.hdr[t] = (int16_t)bs;
-                    sh.virdis[t] = r.vir_dis;
-                    r.count += 1;                                                           // ref :292
-                    done = true;
                 }
             }
-            if (done) return;
+            if (!amb) {
+                r.hdr = pr;                                                                 // ref :1348-1354
+                r.vir_dis = (pr >= 0) ? (me - pvd) : 100.0;
+                sh.hdr[t] = (int16_t)pr;
+                sh.virdis[t] = r.vir_dis;
+                r.count += 1;                                                               // ref :292
+                return;
+            }
+            // (exact distance ties with a merged entry: every member through the full-key insertion)
+#pragma unroll
+            for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
+            {
+                const int no = sh.ofill[d], eb = sh.lbase[d + 1] - 1;
+                for (int q = 0; q < no; q++) consider(sh.u_slot[eb - q], sh.u_vd[eb - q]);
+            }
             const int e1 = sh.lbase[d] + sh.fill[d];
             for (int e = sh.lbase[d]; e < e1; e++) {
                 const int x = sh.u_slot[e];
@@ -1075,9 +973,15 @@ template <int CAP> struct TickGeo {
                 row[6 + 4 * k] = (ZROW || has) ? na[k] : 0.0; row[7 + 4 * k] = (ZROW || has) ? (double)nrt[k] : 0.0;
             }
             if (O.obs_pre) {
-                double *o = O.obs_pre + gpre * OBSW;
+                if (P.obs_f32) {                        // (obs_pre / state_pre follow the row type, as in the 12-lane kernels)
+                    float *o = (float *)O.obs_pre + gpre * OBSW;
 #pragma unroll
-                for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                    for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
+                } else {
+                    double *o = O.obs_pre + gpre * OBSW;
+#pragma unroll
+                    for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                }
             }
             if (O.obs_post && new_slot >= 0) {
                 if (P.obs_f32) {
@@ -1162,27 +1066,49 @@ template <int CAP> struct TickGeo {
     // phase, behind the barrier that ends their last use (WALK), so that the loop needs no barrier between TICK_INIT and S1
     static PVE_HD void ph_lists_clear(int t, Sh &sh)
     {
-        if (t < ND) { sh.rc[t] = 0; sh.rfill[t] = 0; sh.fill[t] = 0; sh.cnt2[t] = 0; }
+        if (t < ND) { sh.rc[t] = 0; sh.rfill[t] = 0; sh.fill[t] = 0; sh.cnt2[t] = 0; sh.ofill[t] = 0; }
     }
 
     // ============================================================== STATE: 7x28; a neighbour's row is this tick's
-    // if it was processed before us (order, not slot), else the row it stored last tick (ref :1332)
-    static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    // if it was processed before us (order, not slot), else the row it stored last tick (ref :1332).
+    // ph_state_order (LOCK phase, only when state_pre is requested): which of the 6 neighbours precede this vehicle in the
+    // processing order -- read HERE because k_rollout_geo's FIN re-uses `ord` as staging storage; the bits ride in r.mmask
+    // (dead since PAIRS).
+    static PVE_HD void ph_state_order(int t, const Sh &sh, Regs &r)
     {
-        if (!P.out.state_pre || !(r.alive && r.ctl)) return;
-        const size_t base = (size_t)env * CAP;
-        double *dst = P.out.state_pre + (base + t) * (size_t)((NNB + 1) * OBSW);
-        const double *own = P.out.obs_pre + (base + t) * OBSW;
+        int fresh = 0;
+        if (r.alive && r.ctl) {
+#pragma unroll
+            for (int q = 0; q < NNB; q++) {
+                const int x = r.kr[q];
+                fresh |= (x >= 0 && sh.ord[x < 0 ? 0 : x] < r.ord) ? (1 << q) : 0;
+            }
+        }
+        r.mmask = fresh;
+    }
+    template <class ROW, class OutT>
+    static PVE_HD void state_rows(const OutT &O, size_t base, int t, const Regs &r)
+    {
+        ROW *dst = (ROW *)O.state_pre + (base + t) * (size_t)((NNB + 1) * OBSW);
+        const ROW *pre = (const ROW *)O.obs_pre, *prev = (const ROW *)O.obs_prev_post;
+        const ROW *own = pre + (base + t) * OBSW;
         for (int k = 0; k < OBSW; k++) dst[k] = own[k];
         for (int q = 0; q < NNB; q++) {
             const int x = r.kr[q];
-            double *row = dst + (q + 1) * OBSW;
-            if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = 0.0; continue; }
-            const double *src = (sh.ord[x] < r.ord) ? (P.out.obs_pre + (base + x) * OBSW)
-                                                    : (P.out.obs_prev_post + (base + x) * OBSW);
+            ROW *row = dst + (q + 1) * OBSW;
+            if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = (ROW)0; continue; }
+            const ROW *src = ((r.mmask >> q) & 1) ? (pre + (base + x) * OBSW) : (prev + (base + x) * OBSW);
             for (int k = 0; k < OBSW; k++) row[k] = src[k];
         }
     }
+    template <class OutT>
+    static PVE_HD void ph_state(const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh, Regs &r)
+    {
+        if (!O.state_pre || !(r.alive && r.ctl)) return;
+        if (P.obs_f32) state_rows<float>(O, (size_t)env * CAP, t, r);
+        else state_rows<double>(O, (size_t)env * CAP, t, r);
+    }
+    static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r) { ph_state(P, P.out, env, t, sh, r); }
 };
 
 // ================================================================== reset / warm-up, ref :196-220

@@ -145,6 +145,7 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_effects(g, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_prefetch_arrival(P, env, t, sh, regs[t], g.lane_num);
         for (int t = 0; t < CAP; t++) B::ph_lock_slot(g.base, t, sh, regs[t]);
+        if (P.out.state_pre) for (int t = 0; t < CAP; t++) T::ph_state_order(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) B::ph_lock2_slot(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_final(g, P, env, t, sh, regs[t]);
         if (P.out.state_pre)
@@ -166,8 +167,12 @@ template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &
         SharedGeo<CAP> &sh = *shp;
         memset(&sh, 0, sizeof(sh));
         int pool_idx = R.pool_tick0;
+        const bool idt = R.source == 3;                      // PVE_SRC_TABLE: actions by (tick, vehicle id)
+        auto tab = [&](int row, int id) { return R.pool[(size_t)row * (size_t)R.table_ids + (id < 0 ? 0 : (id < R.table_ids ? id : R.table_ids - 1))]; };
+        std::vector<double> sp_act(CAP, 0.0);
         for (int t = 0; t < CAP; t++) T::ph_load(g, P, env, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_load_late(P, env, t, sh, regs[t]);
+        if (idt) for (int t = 0; t < CAP; t++) regs[t].act = regs[t].alive ? tab(pool_idx, regs[t].id) : 0.0;
         for (int k = 0; k < R.n_ticks; k++) {
             for (int w = 0; w < CAP / 64; w++) {     // the emulator's vote() ORs bits: start every tick from empty masks
                 sh.m_alive[w] = sh.m_ctl[w] = sh.m_del[w] = sh.m_fin[w] = sh.m_ctlnow[w] = sh.m_coll[w] = sh.m_lead[w] = sh.m_spawn[w] = 0;
@@ -195,19 +200,32 @@ template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &
             for (int t = 0; t < CAP; t++) T::ph_reward(g, t, sh, regs[t]);
             int nx = -1;
             if (k + 1 < R.n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
-            for (int t = 0; t < CAP; t++) B::ph_prefetch_action(P, R, env, t, nx, regs[t]);
+            if (idt) for (int t = 0; t < CAP; t++) regs[t].act_nx = (nx >= 0 && regs[t].alive) ? tab(nx, regs[t].id) : 0.0;
+            else for (int t = 0; t < CAP; t++) B::ph_prefetch_action(P, R, env, t, nx, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_effects(g, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_lists_clear(t, sh);
             for (int t = 0; t < CAP; t++) B::ph_prefetch_arrival(P, env, t, sh, regs[t], g.lane_num);
             for (int t = 0; t < CAP; t++) B::ph_lock_slot(g.base, t, sh, regs[t]);
+            const Outputs O = B::template tick_outputs<true>(P, R, k);
+            if (O.state_pre) for (int t = 0; t < CAP; t++) T::ph_state_order(t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) B::ph_lock2_slot(t, sh, regs[t]);
-            const Outputs O = B::template tick_outputs<false>(P, R, k);
-            for (int t = 0; t < CAP; t++) T::template ph_final<true>(g, P, O, env, t, sh, regs[t], fcs[t], k + 1 == R.n_ticks);
+            for (int t = 0; t < CAP; t++)
+                T::template ph_final<true>(g, P, O, env, t, sh, regs[t], fcs[t], k + 1 == R.n_ticks || O.state_pre != nullptr);
+            if (idt) {
+                for (int t = 0; t < CAP; t++) if (!fcs[t].still && fcs[t].new_slot >= 0) sh.p[fcs[t].new_slot] = regs[t].act_nx;
+                for (int t = 0; t < CAP; t++)
+                    sp_act[t] = (fcs[t].sp_slot >= 0 && nx >= 0) ? tab(nx, fcs[t].sp_id) : 0.0;
+            }
             if (fcs[0].still) {                       // (uniform) nobody moves: the registers carry over
                 for (int t = 0; t < CAP; t++) T::ph_carry_over(t, sh, regs[t], fcs[t]);
             } else {
+                if (O.state_pre) for (int t = 0; t < CAP; t++) T::ph_state(P, O, env, t, sh, regs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_stage(g, t, sh, regs[t], fcs[t]);
-                if (k + 1 < R.n_ticks) for (int t = 0; t < CAP; t++) T::ph_reload(t, sh, regs[t]);
+                if (idt) for (int t = 0; t < CAP; t++) if (fcs[t].sp_slot >= 0) sh.p[fcs[t].sp_slot] = sp_act[t];
+                if (k + 1 < R.n_ticks) {
+                    for (int t = 0; t < CAP; t++) T::ph_reload(t, sh, regs[t]);
+                    if (idt) for (int t = 0; t < CAP; t++) regs[t].act = sh.p[t];
+                }
             }
         }
         for (int t = 0; t < CAP; t++) B::ph_flush(P, env, t, sh);
@@ -259,13 +277,15 @@ struct Backend {
     }
     static int launch_rollout_geo(const GeoConst &g, const Params &P_in, const RolloutArgs &R, int cap, void *, std::string &)
     {
-        if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2 || P_in.out.obs_pre || P_in.out.state_pre) return 1;
+        const bool train = P_in.out.obs_pre || P_in.out.state_pre;
+        if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2 || R.queue || (train && R.source == 3)) return 1;
         Params P = P_in;
         RolloutArgs Rk = R;
         if (R.source == 1) {
             Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
+        if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
         if (cap == 64) emu_rollout_geo<64>(g, P, Rk); else emu_rollout_geo<128>(g, P, Rk);
         return 0;
     }

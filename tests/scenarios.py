@@ -579,7 +579,7 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
 
 
 def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chunks=(1, 7, 40, 3, 60), rate=None,
-                        trajectory_chunk=12, quantize=None):
+                        trajectory_chunk=12, quantize=None, source="pool"):
     """pve_step_many for the 4- / 8-lane layouts (k_rollout_geo: the general-geometry tick resident on the chip) == single
     pve_step_all ticks of k_tick_geo, bit for bit: persistent state, headers (incl. the spawn counter intention_re and
     the stale list heads), observation rows, last-tick outputs and, in trajectory mode, every tick's outputs."""
@@ -602,6 +602,17 @@ def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chun
         acts = np.round(acts / quantize) * quantize
     pool = torch.as_tensor(acts).to(one.device)
     many.set_action_pool(pool)
+    if source == "table":                                   # actions by (tick, vehicle id), gathered inside the resident kernel
+        tv = rng.uniform(-3, 3, size=(23, 150))
+        if quantize:
+            tv = np.round(tv / quantize) * quantize
+        table = torch.as_tensor(tv)
+        one.set_action_table(table); many.set_action_table(table)
+
+    def single():
+        if source == "table":
+            return one.step(one.actions_from_table())
+        return one.step(pool[one.ticks % n_pool])
 
     def same_outputs(o1, o2, what):
         f = _np(o1["flags"])
@@ -622,15 +633,15 @@ def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chun
 
     for n in chunks:
         for _ in range(n):
-            o1 = one.step(pool[one.ticks % n_pool])
-        o2 = many.step_many(n, source="pool", chunk=(0 if n < 6 else (n // 3 + 1)))
+            o1 = single()
+        o2 = many.step_many(n, source=source, chunk=(0 if n < 6 else (n // 3 + 1)))
         one.synchronize(); many.synchronize()
         batches_equal(one, many, "lane_num %d, chunk of %d" % (lane_num, n))
         same_outputs(o1, o2, "lane_num %d, chunk of %d" % (lane_num, n))
         same_headers("lane_num %d, chunk of %d" % (lane_num, n))
-    traj = many.step_many(trajectory_chunk, source="pool", trajectory=True, chunk=trajectory_chunk // 2 + 1)
+    traj = many.step_many(trajectory_chunk, source=source, trajectory=True, chunk=trajectory_chunk // 2 + 1)
     for k in range(trajectory_chunk):
-        o1 = one.step(pool[one.ticks % n_pool])
+        o1 = single()
         same_outputs(o1, {n: traj[n][k] for n in traj}, "trajectory tick %d" % k)
         post_ctl = (_np(one.state_field("meta")) & 1) != 0
         assert np.array_equal(_np(one.obs)[post_ctl], _np(traj["obs_post"][k])[post_ctl]), "trajectory obs, tick %d" % k
@@ -643,23 +654,33 @@ def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chun
     return m1
 
 
-def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=1100.0, calls=(40, 25, 60, 35), seed=81, n_pool=7,
-                               obs_dtype=torch.float64, chunk=0, source="pool", min_ctl_per_tick=5):
-    """Training outputs on the fast path: pve_step_many trajectory roll-outs with
-    state_pre -- the 7 x 28 states with fresh / stale neighbour rows (ref :1325-1337) and the 7-action vectors (column 2,
-    ref :290) -- compared with the oracle at EVERY tick of every env (ids, neighbours, rewards, row 0, full state), across
-    call boundaries (the first tick of a call reads the rows the previous call stored) and chunked launches.  float32
-    rows: the same within float32 round-off of the stored rows."""
+def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=None, calls=(40, 25, 60, 35), seed=81, n_pool=7,
+                               obs_dtype=torch.float64, chunk=0, source="pool", min_ctl_per_tick=5, lane_num=12):
+    """Training outputs on the fast path (lane_num 4 / 8: f3 x f4):
+    pve_step_many trajectory roll-outs with state_pre -- the 7 x 28 states with fresh / stale neighbour rows (ref
+    :1325-1337) and the 7-action vectors (column 2, ref :290) -- compared with the oracle at EVERY tick of every env (ids,
+    neighbours, rewards, row 0, full state), across call boundaries (the first tick of a call reads the rows the previous
+    call stored) and chunked launches.  float32 rows: the same within float32 round-off of the stored rows.  The 4- / 8-lane
+    layouts process (and list) the vehicles in (lane, intention, j) order (ref :233-275)."""
+    from pve_mcc_amd import _capi
+    from pve_mcc_amd.arrivals import synthetic_intentions
     rng = np.random.default_rng(seed)
     total = sum(calls)
-    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed)
+    rate = rate or {12: 1100.0, 8: 1500.0, 4: (1800.0 if capacity == 128 else 1200.0)}[lane_num]
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed, lane_num=lane_num)
+    ch = synthetic_intentions(n_envs, arr.shape[1], seed=seed, lane_num=lane_num) if lane_num == 8 else None
     outs = ("obs_post", "obs_pre", "state_pre", "reward", "flags", "nbr", "lanej", "env_out", "new_slot")
-    b = make_batch(arr, n_envs, capacity, backend, outputs=outs, obs_dtype=obs_dtype)
+    kw = dict(lane_num=lane_num, intentions=ch) if lane_num != 12 else {}
+    b = make_batch(arr, n_envs, capacity, backend, outputs=outs, obs_dtype=obs_dtype, **kw)
     b.reset()
     pool_np = rng.uniform(-3, 3, size=(n_pool, n_envs, capacity)).astype(np.float32).astype(np.float64)
     if source == "pool":
         b.set_action_pool(torch.as_tensor(pool_np))
-    oracles = [OracleEnv(arr[e]) for e in range(n_envs)]
+    if lane_num == 12:
+        oracles = [OracleEnv(arr[e]) for e in range(n_envs)]
+    else:
+        from oracle.oracle_geo import OracleGeoEnv
+        oracles = [OracleGeoEnv(arr[e], lane_num, choice=None if ch is None else ch[e]) for e in range(n_envs)]
     tol = 1e-9 if obs_dtype == torch.float64 else 2e-6          # float32 rows: relative round-off of the stored values
     t, n_ctl_total = 0, 0
     ring = [b.alloc_trajectory(max(calls)) for _ in range(2)]
@@ -674,9 +695,12 @@ def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=1100.0, cal
                 acts = np.where(ctlm != 0, pool_np[(t + k) % n_pool, e, :na], 0.0) if source == "pool" else np.zeros(na)
                 rec = o.tick(acts, want_state=True)
                 f = host["flags"][k, e, :na].astype(np.int64)
-                ctl = (f & 2) != 0
-                assert int(host["env_out"][k, e, 0]) == na and int(ctl.sum()) == len(rec["ids"]), "controlled set: tick %d env %d" % (t + k, e)
-                lj = host["lanej"][k, e, :na][ctl].astype(np.int64)
+                lja = host["lanej"][k, e, :na].astype(np.int64)
+                # controlled slots in PROCESSING order: (lane, intention, j); == slot order for lane_num 12
+                order = np.lexsort((lja & 0xFFFF, (f >> _capi.F_INTENT_SHIFT) & 3, lja >> 16)) if na else np.zeros(0, np.int64)
+                ctl = order[((f & 2) != 0)[order]]
+                assert int(host["env_out"][k, e, 0]) == na and len(ctl) == len(rec["ids"]), "controlled set: tick %d env %d" % (t + k, e)
+                lj = lja[ctl]
                 assert np.array_equal(np.stack([lj >> 16, lj & 0xFFFF], -1), rec["ids"]), "ids: tick %d env %d" % (t + k, e)
                 nb = host["nbr"][k, e, :na][ctl].astype(np.int64)
                 nb = np.stack([np.where(nb < 0, -1, nb >> 16), np.where(nb < 0, -1, nb & 0xFFFF)], -1)

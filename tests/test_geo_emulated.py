@@ -2,6 +2,7 @@
 the test emulator and compared with the golden vectors of the live reference and with the sequential oracle.
 The `-m gpu` twin (test_gpu_parity.py) runs the real kernel."""
 import pytest
+import torch
 
 from tests.parity_util import GEO_CASE_NAMES, GoldenCase, replay_case
 from tests.hip_adapter import SplitEnv, make_batch
@@ -79,3 +80,17 @@ def test_geo_symmetric_lanes_equal_distances(lane_num, gap):
     for scale, quant in ((0.0, None), (3.0, 3.0)):
         scenarios.check_geo_fuzz_vs_oracle(BACKEND, lane_num, n_envs=2, capacity=128, ticks=260, rate=0.0, seed=13,
                                            action_scale=scale, quantize=quant, arrivals=arr)
+
+
+@pytest.mark.parametrize("lane_num,cap,dtype,chunk", [(8, 128, torch.float64, 0), (4, 64, torch.float32, 7), (4, 128, torch.float64, 9)])
+def test_emulated_step_many_geo_emits_training_states(lane_num, cap, dtype, chunk):
+    """f3 x f4: obs_pre / state_pre / the 7-action vectors of every tick of pve_step_many trajectories for the 4- / 8-lane
+    layouts (k_rollout_geo<.., TRAIN>), float64 and float32 rows, against OracleGeoEnv."""
+    scenarios.check_step_many_state_rows(BACKEND, n_envs=2, capacity=cap, calls=(30, 12, 25), chunk=chunk, obs_dtype=dtype,
+                                         lane_num=lane_num, seed=85 + lane_num, min_ctl_per_tick=3)
+
+
+@pytest.mark.parametrize("lane_num,cap", [(8, 128), (4, 64)])
+def test_emulated_step_many_geo_table_source(lane_num, cap):
+    """PVE_SRC_TABLE for the 4- / 8-lane layouts (k_rollout_geo<.., IDT>) == single ticks with the table applied per tick."""
+    scenarios.check_step_many_geo(BACKEND, lane_num, n_envs=3, capacity=cap, chunks=(1, 7, 40, 3), trajectory_chunk=8, source="table")

@@ -355,6 +355,21 @@ def test_gpu_step_many_geo_equals_single_ticks(lane_num, cap, quant):
     assert m["overflow"] == 0 and m["ctl_steps"] > 5000
 
 
+@pytest.mark.parametrize("lane_num,cap,dtype,chunk", [(8, 128, torch.float64, 0), (4, 64, torch.float32, 13), (4, 128, torch.float64, 9),
+                                                      (8, 64, torch.float32, 0)])
+def test_gpu_step_many_geo_emits_full_state_rows(lane_num, cap, dtype, chunk):
+    """f3 x f4 on MI355X: k_rollout_geo<.., TRAIN> -- obs_pre / state_pre / 7-action vectors of every tick of pve_step_many
+    trajectories for lane_num 4 / 8, float64 and float32 rows, every tick of every env against OracleGeoEnv."""
+    scenarios.check_step_many_state_rows(BACKEND, n_envs=4, capacity=cap, calls=(40, 25, 60, 35), chunk=chunk, obs_dtype=dtype,
+                                         lane_num=lane_num, seed=85 + lane_num, min_ctl_per_tick=3)
+
+
+@pytest.mark.parametrize("lane_num,cap,quant", [(8, 128, None), (4, 64, 1.0), (4, 128, None)])
+def test_gpu_step_many_geo_table_source(lane_num, cap, quant):
+    """PVE_SRC_TABLE inside k_rollout_geo<.., IDT> (lane_num 4 / 8) == single ticks with the same table applied per tick."""
+    scenarios.check_step_many_geo(BACKEND, lane_num, n_envs=9, capacity=cap, quantize=quant, source="table")
+
+
 def test_gpu_step_many_actor_in_dense_traffic():
     """The closed loop inside k_rollout with more than 64 controlled vehicles per intersection (tiles 2 and 3: the second
     wave re-reads the rows of its own dense threads) and with one-wave workgroups (capacity 64: one wave runs every tile):
