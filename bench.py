@@ -334,7 +334,7 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
 
         def run(n):
             if n > 0:
-                env.step_many(n, actor=True, chunk=chunk)
+                env.step_many(n, actor=True, chunk=chunk, persistent=pers)
     else:
         pool_np = action_pool(n_envs, cap, seed=1234 + rank)
         env.set_action_pool(torch.as_tensor(pool_np, device=dev))
@@ -399,14 +399,17 @@ def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=
       12 lanes x 128 slots, pool / zero actions: ONE batch and ONE persistent launch per call whose workgroups pull
         (intersection, <= T ticks) items from a queue -- 618 us for 20 ticks (T = 6) against 671 us for two stream-pipelined
         sub-batches in launches of 5; 26.4 against 27.5 us per tick in a 1000-tick region (T = 10 / launches of 25);
-      12 lanes x 64 slots: every intersection is resident at once (16 one-wave workgroups per CU): one launch for a short call
-        (323 against 341 us for 20 ticks), the persistent queue with T = 10 for a long one (13.6 against 13.9 / 14.4 us);
+      12 lanes x 64 slots: every intersection is resident at once (16 one-wave workgroups per CU): ONE launch of all of them
+        for the whole call (323 against 341 us for 20 ticks with two sub-batches; 13.7 us per tick in a 1000-tick region, the
+        queue with T = 10: 13.6);
       closed loop, 4 / 8 lanes, small batches: two stream-pipelined sub-batches, one launch per chunk (their resident kernels
         have no queue form; a batch below twice the chip's resident workgroups gives the queue nothing to balance)."""
     if lane_num == 12 and not actor and n_envs >= 4096:     # (the queue balances a batch of >= 2x the workgroups the chip holds)
         if cap == 128:
             return 1, (10 if K >= 100 else 6), True
-        return (1, 10, True) if K >= 100 else (1, 0, False)
+        return 1, 0, False
+    if lane_num == 12 and actor and cap == 128 and n_envs >= 4096 and K >= 100:
+        return 1, 25, True          # closed loop, long call: 34.6 against 35.9 us per tick; 20 ticks: 42.9 against 43.2 (no gain: 2 streams)
     return 2, ((25 if K >= 100 else 5) if cap == 128 else 0), False
 
 
@@ -569,7 +572,7 @@ def main(argv=None, env_factory=None):
     d_sub, d_chunk, d_pers = launch_shape(cap, K, lane_num, args.actor, n_envs=n_envs)
     if not rollout_like:
         d_sub, d_chunk, d_pers = 2, 0, False
-    can_pers = lane_num == 12 and not args.actor and rollout_like and not emu
+    can_pers = lane_num == 12 and rollout_like and not emu
     pers = can_pers and args.chunk != 0 and \
         (bool(args.persistent) if args.persistent is not None else (d_pers and args.pipeline in (None, 1)))
     if args.pipeline is None:
@@ -652,7 +655,7 @@ def main(argv=None, env_factory=None):
                 ring_pos[1], ring_pos[2] = ring_pos[0], m
                 ring_pos[0] ^= 1
         elif mode == "rollout":
-            env.step_many(n, actor=args.actor, source=src, chunk=args.chunk)
+            env.step_many(n, actor=args.actor, source=src, chunk=args.chunk, **pers_kw)
         elif args.actor:
             for _ in range(n):
                 env.step_with_actor()

@@ -147,6 +147,13 @@ __device__ __forceinline__ void rollout_actor(const unsigned char *packed, const
 // Items of a shard are handed out chunk-major (all intersections' chunk c before any chunk c + 1) by a returning
 // atomic add, so whoever holds an item is a RUNNING workgroup and the item it may wait for was handed out earlier:
 // the oldest unfinished item never waits, whatever the grid size or whoever shares the chip.
+// diagnostics build only (make EXTRA=-DPVE_QUEUE_TRACE, tools/persistent_trace.py): per-item timestamps; compiled out of the
+// product library (the extra live values cost the one-wave variant 32 spilled registers)
+#ifdef PVE_QUEUE_TRACE
+#define Q_TRACE(R_) ((R_).q_trace)
+#else
+#define Q_TRACE(R_) ((unsigned long long *)nullptr)
+#endif
 __device__ __forceinline__ unsigned q_xcc_id()
 {
     return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xFu;      // HW_REG_XCC_ID[3:0] (gfx942 / gfx950)
@@ -212,7 +219,7 @@ template <int CAP, int WPE, bool PROF = false, bool ACT = false, bool TRAIN = fa
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout(const Const c_arg, const Params P_arg,
                                                                                                const RolloutArgs R_arg)
 {
-    static_assert(!PERS || (!PROF && !ACT && !TRAIN), "the persistent form exists for the pool / zero / table sources");
+    static_assert(!PERS || (!PROF && !TRAIN), "the persistent form has no diagnostics / training-output variant");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     __shared__ Shared<CAP> sh;
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     int t0_ = threadIdx.x;
     int env0_ = PERS ? 0 : blockIdx.x;
     int k_base_ = 0, chunk_ = 0;                     // PERS: first tick of the item within the call, its chunk number
+    bool aprm_staged = false;                        // PERS + ACT: the float parameters are in LDS (once per workgroup)
     // the first wave carries the dense-mapped phases (the critical chain of the workgroup), the second one mostly waits at
     // the barriers: the first wave gets the issue slots first (30.0 -> 29.6 us per tick; not in k_tick, where the closed
     // loop's actor kernel shares the chip and loses more than the tick gains)
@@ -256,14 +264,14 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             unsigned *done = R.queue + sizeof(RolloutQueue) / 4;
             if (t0_ == 0) {
                 int shard = q_word[2], probe = q_word[3], e, ch;
-                const unsigned long long tq0 = R.q_trace ? wall_clock64() : 0ull;
+                const unsigned long long tq0 = Q_TRACE(R) ? wall_clock64() : 0ull;
                 q_dequeue(Q, R.n_shards, P.n_envs, R.n_full + R.n_taper, q_xcc_id(), shard, probe, e, ch);
                 q_word[0] = e; q_word[1] = ch; q_word[2] = shard; q_word[3] = probe;
-                const unsigned long long tq1 = R.q_trace ? wall_clock64() : 0ull;
+                const unsigned long long tq1 = Q_TRACE(R) ? wall_clock64() : 0ull;
                 if (e >= 0)                           // the previous chunk of this intersection (another workgroup's item)
                     while ((int)(q_load(&done[e]) - (R.done_base + (unsigned)ch)) < 0) __builtin_amdgcn_s_sleep(8);
-                if (R.q_trace && e >= 0) {            // diagnostics: dequeue start, item known, predecessor done, who
-                    unsigned long long *row = R.q_trace + ((size_t)ch * P.n_envs + e) * 8;
+                if (Q_TRACE(R) && e >= 0) {            // diagnostics: dequeue start, item known, predecessor done, who
+                    unsigned long long *row = Q_TRACE(R) + ((size_t)ch * P.n_envs + e) * 8;
                     row[0] = tq0; row[1] = tq1; row[2] = wall_clock64();
                     row[6] = (unsigned long long)blockIdx.x | ((unsigned long long)q_xcc_id() << 32);
                 }
@@ -278,11 +286,20 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             if (R.source == 1 || R.source == 3) pool_idx = (R.pool_tick0 + k_base_) % R.n_pool;
             if (R.source == 1) act0 = R.pool + (size_t)pool_idx * (size_t)P.n_envs * CAP;
         }
-        if constexpr (ACT) {
+        // PERS + ACT: only the FIRST item of an intersection in a call computes its first actions from the caller's rows; every
+        // later item takes them from `actor_actions`, where the previous item left them (its last tick ran the actor too)
+        bool act_handed = false;
+        if constexpr (PERS && ACT) {
+            act_handed = chunk_ > 0;
+            if (act_handed) act0 = R.actor_actions;      // ([n_envs][CAP], like a pool entry: LOAD adds the intersection's offset)
+        }
+        if constexpr (ACT) if (!act_handed) {
             // the first tick's actions = actor(rows in HBM), before the state is loaded (nothing else is live): the controlled
             // slots are compacted into `adsts` as if they were dense threads (wave 1's ranks follow wave 0's count)
-            const float *gp = (const float *)(R.actor_packed + AP_PRM);
-            for (int n = t0_; n < PV_TOTAL; n += CAP) aprm[n] = gp[n];
+            if (!PERS || !aprm_staged) {
+                const float *gp = (const float *)(R.actor_packed + AP_PRM);
+                for (int n = t0_; n < PV_TOTAL; n += CAP) aprm[n] = gp[n];
+            }
             const int mt = P.i32[I_META][(size_t)env0_ * CAP + t0_];
             const bool cc = (mt & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
             vote<CAP / 64>(sh.m_ctl, t0_, cc);
@@ -294,11 +311,18 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             rollout_actor<CAP>(R.actor_packed, aprm, sh.act_next, adsts, nc, R.actor_obs, P.obs_f32 != 0, (size_t)env0_ * CAP, t0_);
             lds_barrier();
         }
+        if constexpr (PERS && ACT) {
+            if (!aprm_staged && act_handed) {            // (a workgroup whose first item is a later chunk: parameters for its ticks)
+                const float *gp = (const float *)(R.actor_packed + AP_PRM);
+                for (int n = t0_; n < PV_TOTAL; n += CAP) aprm[n] = gp[n];
+            }
+            aprm_staged = true;
+        }
         if constexpr (PERS) {
-            T::template ph_load<true>(c, P, env0_, t0_, sh, r, act0, true);
-            if (R.q_trace && t0_ == 0) R.q_trace[((size_t)chunk_ * P.n_envs + env0_) * 8 + 3] = wall_clock64();
+            T::template ph_load<true, ACT>(c, P, env0_, t0_, sh, r, act0, true);
+            if (Q_TRACE(R) && t0_ == 0) Q_TRACE(R)[((size_t)chunk_ * P.n_envs + env0_) * 8 + 3] = wall_clock64();
         } else T::ph_load(c, P, env0_, t0_, sh, r);     // P.actions = the first tick's actions
-        if constexpr (ACT) r.act = sh.act_next[t0_];    // (uncontrolled slots: whatever is there, masked in S1)
+        if constexpr (ACT) { if (!act_handed) r.act = sh.act_next[t0_]; }   // (uncontrolled slots: whatever is there, masked in S1)
         if constexpr (IDT) {                            // the first tick's action of the vehicle in this slot: table[row][id]
             const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
             r.act = r.alive ? R.pool[(size_t)pool_idx * (size_t)R.table_ids + idc] : 0.0;
@@ -389,9 +413,15 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 // next tick's actions: the vehicle lane t spawns gets the action of an all-zero row (ref :380, :420), the
                 // controlled vehicles that stay get actor(row)
                 if (fc.sp_slot >= 0) sh.act_next[fc.sp_slot] = (double)aprm[PV_A0];
-                if (k + 1 < n_ticks)
+                // (PERS: also on an item's last tick, unless it is the call's last: the next item starts from these actions)
+                const bool hand_on = PERS && k + 1 == n_ticks && chunk_ + 1 < R.n_full + R.n_taper;
+                if (k + 1 < n_ticks || hand_on)
                     rollout_actor<CAP>(R.actor_packed, aprm, sh.act_next, adsts, fc.n_ctl, O.obs_post, P.obs_f32 != 0,
                                        (size_t)env * CAP, t);
+                if (hand_on) {
+                    lds_barrier();                    // (every tile's actions are in act_next)
+                    R.actor_actions[(size_t)env * CAP + t] = sh.act_next[t];
+                }
             }
             lds_barrier();                            // B: the staging area is complete
             if (k + 1 < n_ticks) T::ph_reload(t, sh, r);
@@ -413,12 +443,12 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         // the count of completed items of this intersection goes up by one
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
-        const unsigned long long tf0 = (R.q_trace && t0_ == 0) ? wall_clock64() : 0ull;
+        const unsigned long long tf0 = (Q_TRACE(R) && t0_ == 0) ? wall_clock64() : 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         if (t0_ == 0) q_store(R.queue + sizeof(RolloutQueue) / 4 + env0_, R.done_base + (unsigned)chunk_ + 1u);
-        if (R.q_trace && t0_ == 0) {                  // diagnostics: state flushed (stores issued), handed on
-            unsigned long long *row = R.q_trace + ((size_t)chunk_ * P.n_envs + env0_) * 8;
+        if (Q_TRACE(R) && t0_ == 0) {                  // diagnostics: state flushed (stores issued), handed on
+            unsigned long long *row = Q_TRACE(R) + ((size_t)chunk_ * P.n_envs + env0_) * 8;
             row[4] = tf0; row[5] = wall_clock64();
         }
     } else break;
@@ -779,8 +809,8 @@ struct Backend {
         static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
         const bool train = P.out.obs_pre || P.out.state_pre;
         if (R.queue) {                                                        // persistent form (pve_rollout.persistent)
-            if (train || R.source == 2) return 1;
-            Rk.q_trace = P.phase_cycles;                                      // diagnostics: per-item timestamps instead of phase cycles
+            if (train || (R.source == 2 && (act_off || R.exact_f32 || !R.actor_actions))) return 1;
+            Rk.q_trace = P.phase_cycles;                                      // (read by -DPVE_QUEUE_TRACE builds only: per-item timestamps)
             // as many workgroups as the chip holds at once (the queue needs no more; fewer when the call has fewer items)
             static int wgs_per_cu[2] = {0, 0}, n_cu = 0;
             const int ci = cap == 64 ? 0 : 1;
@@ -800,7 +830,10 @@ struct Backend {
             long long grid = (long long)wgs_per_cu[ci] * n_cu;
             if (const char *g = getenv("PVE_PERSISTENT_GRID")) { const long long v = atoll(g); if (v > 0) grid = v; }   // A/B knob
             if (grid > items) grid = items;
-            if (R.source == 3) {                                               // PVE_SRC_TABLE (same register budget: same residency)
+            if (R.source == 2) {                                               // the closed loop: the actor inside the persistent kernel
+                if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true, false, false, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
+                else hipLaunchKernelGGL((k_rollout<128, 4, false, true, false, false, true>), dim3((unsigned)grid), dim3(128), 0, s, c, P, Rk);
+            } else if (R.source == 3) {                                        // PVE_SRC_TABLE (same register budget: same residency)
                 if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, true, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
                 else hipLaunchKernelGGL((k_rollout<128, 4, false, false, false, true, true>), dim3((unsigned)grid), dim3(128), 0, s, c, P, Rk);
             } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, false, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);

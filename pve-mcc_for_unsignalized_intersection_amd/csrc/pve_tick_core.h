@@ -612,7 +612,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // ============================================================== L: load
     // COH: the state may have been stored by another workgroup of this launch (persistent roll-out): coherent loads.
     // act0: the first tick's actions of this roll-out item ([n_envs][CAP], or null), instead of P.actions.
-    template <bool COH = false>
+    // COHA: the actions too (the persistent closed loop hands them from one item to the next; a pool is read-only input)
+    template <bool COH = false, bool COHA = false>
     static PVE_HD void ph_load(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r,
                                const double *act0 = nullptr, bool use_act0 = false)
     {
@@ -637,7 +638,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (t < 64 || t < N) {
             // what S1 - S3 need comes first; the fields that are merely carried to FIN (or first read in WALK) are requested
             // behind them and arrive under the step phases (the kernel's barriers do not wait for global loads)
-            if (acts) r.act = acts[g];                    // with the state loads: one latency, not a second one in S1
+            if (acts) r.act = gld<COHA>(acts + g);        // with the state loads: one latency, not a second one in S1
             r.p = gld<COH>(P.f64[F_P] + g); r.v = gld<COH>(P.f64[F_V] + g); r.a = gld<COH>(P.f64[F_A] + g);
             r.meta = gld<COH>(P.i32[I_META] + g); r.step = gld<COH>(P.i32[I_STEP] + g);
             r.jerk_sum = gld<COH>(P.f64[F_JERK_SUM] + g); r.vir_dis = gld<COH>(P.f64[F_VIR_DIS] + g);

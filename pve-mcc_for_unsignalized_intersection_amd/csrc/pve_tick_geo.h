@@ -627,9 +627,12 @@ template <int CAP> struct TickGeo {
             bool amb = false;
             if (fix) {
                 const int no = sh.ofill[d], eb = sh.lbase[d + 1] - 1;
+                // most opposing entries are farther away than the 6th winner: the insertion chain (~80 vector instructions
+                // per entry) only runs in waves where some lane's entry can enter the 6 -- at 4 waves per SIMD every vector
+                // instruction of this loop is 16 cycles of the SIMD
                 double dk[NNB];
-#pragma unroll
-                for (int k = 0; k < NNB; k++) dk[k] = r.kr[k] >= 0 ? fabs(r.kv[k] - me) : INFINITY;
+                bool have_dk = false;
+                double d5 = r.kr[NNB - 1] >= 0 ? fabs(r.kv[NNB - 1] - me) : INFINITY;
                 for (int q = 0; q < no; q++) {
                     const int x = sh.u_slot[eb - q];
                     const double vo = sh.u_vd[eb - q];
@@ -637,6 +640,16 @@ template <int CAP> struct TickGeo {
                     const bool before = vo < me || (vo == me && x < t);
                     if (before && (pr < 0 || vo > pvo || (vo == pvo && x > pr))) { pvo = vo; pr = x; pvd = vc; }
                     double cd = fabs(vc - me), cv = vc; int cs = x;
+#if PVE_DEVICE_CODE
+                    if (__builtin_amdgcn_ballot_w64(cd <= d5) == 0) continue;
+#else
+                    if (!(cd <= d5)) continue;
+#endif
+                    if (!have_dk) {
+#pragma unroll
+                        for (int k = 0; k < NNB; k++) dk[k] = r.kr[k] >= 0 ? fabs(r.kv[k] - me) : INFINITY;
+                        have_dk = true;
+                    }
                     bool ins = false;
 #pragma unroll
                     for (int k = 0; k < NNB; k++) {
@@ -647,6 +660,7 @@ template <int CAP> struct TickGeo {
                         dk[k] = sw ? cd : dk[k]; r.kv[k] = sw ? cv : r.kv[k]; r.kr[k] = sw ? cs : r.kr[k];
                         cd = td; cv = tv; cs = ts;
                     }
+                    d5 = dk[NNB - 1];
                 }
             }
             if (!amb) {

@@ -157,6 +157,7 @@ struct RolloutArgs {
     uint8_t taper[8];
     int32_t n_shards;            // env e belongs to shard e % n_shards; a shard is worked by ONE XCD
     uint32_t done_base;          // done[e] - done_base = items of intersection e completed in this call
+    double *actor_actions;       // persistent closed loop: [n_envs][cap] actions handed from one item of an intersection to the next
     unsigned long long *q_trace; // diagnostics (pve_debug_phase_cycles armed): [chunk][env][8] timestamps of every item, or null
 };
 

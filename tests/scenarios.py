@@ -916,7 +916,8 @@ def check_driver_shape_vs_oracle(backend, n_envs=4096, n_sub=2, capacity=128, ra
 
 
 def check_closed_loop_rollout_vs_two_launch(backend, n_envs=4096, n_sub=2, capacity=128, rate=1000.0, chunk=5, n_sample=16,
-                                            calls=(50, 50, 50, 50, 50, 50, 5, 25), seed=4243, obs_dtype=torch.float64):
+                                            calls=(50, 50, 50, 50, 50, 50, 5, 25), seed=4243, obs_dtype=torch.float64,
+                                            persistent=False):
     """BASELINE config 5 at full size through the product's fast path: PipelinedIntersections,
     `n_sub` sub-batches on their own streams, pve_step_many(PVE_SRC_ACTOR) -- the actor INSIDE the resident kernel
     (k_rollout<.., ACT>) -- in launches of `chunk` ticks, against `n_sample` of the same arrival streams stepped as ONE
@@ -942,7 +943,7 @@ def check_closed_loop_rollout_vs_two_launch(backend, n_envs=4096, n_sub=2, capac
         b.set_actor(w)
     t = 0
     for n in calls:
-        big.step_many(n, actor=True, chunk=chunk)
+        big.step_many(n, actor=True, chunk=chunk, persistent=persistent)
         for _ in range(n):
             small.step_with_actor()
         big.synchronize(); small.synchronize()

@@ -409,6 +409,8 @@ def test_gpu_persistent_step_many_equals_single_ticks(cap, n_envs, chunks, rate)
     scenarios.check_step_many(BACKEND, "zero", n_envs=max(9, n_envs // 8), capacity=cap, chunks=chunks, rate=rate, persistent=True, seed=5)
     scenarios.check_step_many(BACKEND, "table", n_envs=max(9, n_envs // 4), capacity=cap, chunks=chunks, rate=rate, persistent=True, seed=6,
                               trajectory_chunk=24)
+    scenarios.check_step_many(BACKEND, "actor", n_envs=max(9, n_envs // 4), capacity=cap, chunks=chunks, rate=min(rate, 1000.0),
+                              persistent=True, seed=7, trajectory_chunk=24)
 
 
 @pytest.mark.parametrize("chunk", [5, 2])
@@ -442,6 +444,14 @@ def test_gpu_full_size_actor_closed_loop_matches_small_batch():
     assert torch.equal(big.obs.index_select(0, idx), small.obs)
     m = big.metrics()
     assert m["overflow"] == 0 and m["alive_steps"] / m["ticks"] > 40
+
+
+def test_gpu_full_size_closed_loop_persistent_queue():
+    """Config 5 through the persistent launch: ONE batch of 4096 x 128, the actor inside k_rollout<.., ACT, PERS>, items of 6
+    ticks pulled from the queue (actions handed from item to item through `actor_actions`) == step_with_actor on a 16-env
+    sample batch, bit for bit after every call."""
+    m, worst = scenarios.check_closed_loop_rollout_vs_two_launch(BACKEND, n_sub=1, chunk=6, obs_dtype=torch.float32, persistent=True)
+    assert m["alive_steps"] / m["ticks"] > 40 and worst <= 5e-4
 
 
 @pytest.mark.parametrize("chunk,dtype", [(5, torch.float64), (25, torch.float32), (25, torch.float64), (5, torch.float32)])
