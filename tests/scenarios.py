@@ -414,8 +414,7 @@ def check_geo_overflow_and_empty(backend, lane_num):
 
 
 def check_obs_f32(backend, lane_num=12, n_envs=3, capacity=128, ticks=120, seed=41):
-    """PVE_CFG_OBS_F32: the float32 observation rows are exactly float32(float64 rows), the dynamics do not change,
-    the float64-only outputs are refused."""
+    """PVE_CFG_OBS_F32: the float32 observation rows are exactly float32(float64 rows), the dynamics do not change."""
     from pve_mcc_amd.arrivals import synthetic_intentions
     from pve_mcc_amd._capi import PveError
     rng = np.random.default_rng(seed)
@@ -437,26 +436,17 @@ def check_obs_f32(backend, lane_num=12, n_envs=3, capacity=128, ticks=120, seed=
         assert np.array_equal(x64.astype(np.float32), x32), "tick %d: float32 rows are not float32(float64 rows)" % t
     for k in STATE_F + STATE_I:
         assert np.array_equal(_np(b64.state_field(k)), _np(b32.state_field(k))), k
-    if lane_num == 12:
-        # the training outputs follow the row type (12-lane kernels): obs_pre == float32(float64 obs_pre)
-        p64 = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "flags"))
-        p32 = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "flags"), obs_dtype=torch.float32)
-        p64.reset(); p32.reset()
-        for t in range(60):
-            a = torch.as_tensor(rng.uniform(-2, 2, size=(n_envs, capacity))).to(b64.device)
-            o64, o32 = p64.step(a), p32.step(a)
-            ctl = (_np(o64["flags"]) & 2) != 0
-            assert o32["obs_pre"].dtype == torch.float32
-            assert np.array_equal(_np(o64["obs_pre"])[ctl].astype(np.float32), _np(o32["obs_pre"])[ctl]), "tick %d: obs_pre" % t
-    else:
-        try:
-            bad = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre"), lane_num=lane_num,
-                             intentions=ch, obs_dtype=torch.float32)
-            bad.reset()
-            bad.step(None)
-            raise AssertionError("obs_pre must be refused with float32 observations for lane_num 4 / 8")
-        except PveError:
-            pass
+    # the training outputs follow the row type (every layout since round 4): obs_pre == float32(float64 obs_pre)
+    kw = dict(lane_num=lane_num, intentions=ch)
+    p64 = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "flags"), **kw)
+    p32 = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "flags"), obs_dtype=torch.float32, **kw)
+    p64.reset(); p32.reset()
+    for t in range(60):
+        a = torch.as_tensor(rng.uniform(-2, 2, size=(n_envs, capacity))).to(b64.device)
+        o64, o32 = p64.step(a), p32.step(a)
+        ctl = (_np(o64["flags"]) & 2) != 0
+        assert o32["obs_pre"].dtype == torch.float32
+        assert np.array_equal(_np(o64["obs_pre"])[ctl].astype(np.float32), _np(o32["obs_pre"])[ctl]), "tick %d: obs_pre" % t
 
 
 def check_pipelined_equals_single(backend, n_envs=7, n_sub=3, capacity=128, ticks=150, seed=61, actor=False):

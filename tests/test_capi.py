@@ -122,15 +122,19 @@ def test_actor_and_rollout_argument_validation():
     o.state_pre, o.obs_pre, o.obs_prev_post = sp.data_ptr(), op.data_ptr(), torch.zeros(2, 64, 28, dtype=torch.float64).data_ptr()
     ro.source, ro.trajectory = _capi.SRC_ZERO, 0
     assert lib.pve_step_many(b._h, C.byref(ro), C.byref(o)) == -1 and b"trajectory" in lib.pve_last_error()
-    # the 4- / 8-lane layouts keep obs_pre / state_pre for single ticks
+    # the 4- / 8-lane layouts take obs_pre / state_pre in pve_step_many and float32 rows too (round 4: f3 x f4); the id-indexed
+    # table still excludes the training outputs
     arr8 = np.full((40, 8), np.inf)
     g = BatchedIntersections(2, 64, arr8, device="cpu", outputs=("obs_post", "obs_pre", "flags"), lane_num=8, _lib=lib)
     g.reset()
-    with pytest.raises(_capi.PveError):
-        g.step_many(2, source="zero")
+    g.step_many(2, source="zero")
     g.step(None)
+    g32 = BatchedIntersections(2, 64, arr8, device="cpu", outputs=("obs_post", "obs_pre"), lane_num=8, _lib=lib, obs_dtype=torch.float32)
+    g32.reset()
+    g32.step_many(2, source="zero")
+    g.set_action_table(torch.zeros(4, 8, dtype=torch.float64))
     with pytest.raises(_capi.PveError):
-        BatchedIntersections(2, 64, arr8, device="cpu", outputs=("obs_post", "obs_pre"), lane_num=8, _lib=lib, obs_dtype=torch.float32)
+        g.step_many(2, source="table")
     # |am| outside the range the reciprocal division of the brake test covers
     cfg = _capi.PveConfig()
     lib.pve_default_config(C.byref(cfg))
