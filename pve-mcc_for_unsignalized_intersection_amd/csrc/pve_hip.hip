@@ -222,9 +222,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     static_assert(!PERS || (!PROF && !TRAIN), "the persistent form has no diagnostics / training-output variant");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
-    // (the float32 key plane of RANK -- 3.4 KB -- does not fit beside the actor's parameters at 8 workgroups per CU)
-    typedef Shared<CAP, (CAP == 128), (CAP == 128) && !ACT && PVE_K32> ShT;
-    __shared__ ShT sh;
+    __shared__ Shared<CAP> sh;
     __shared__ __attribute__((aligned(64))) float aprm[ACT ? PV_TOTAL : 1];
     __shared__ uint8_t adsts[ACT ? CAP : 1];         // post-compaction slot of every dense thread's vehicle (255: gone)
     __shared__ int q_word[4];                       // PERS: item (env, chunk) of the workgroup + the dequeue state of lane 0
@@ -240,7 +238,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     KernargPtr kav_ = ka0_;
     Regs r;
     FinCarry fc;
-    typedef Tick<CAP, ShT> T;
+    typedef Tick<CAP> T;
     unsigned long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev_ = PROF ? wall_clock64() : 0ull;
     const unsigned long long sclk0_ = PROF ? clock64() : 0ull, wclk0_ = tprev_;   // shader clock vs the 100 MHz constant clock
@@ -808,6 +806,7 @@ struct Backend {
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
         if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
+        static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
         const bool train = P.out.obs_pre || P.out.state_pre;
         if (R.queue) {                                                        // persistent form (pve_rollout.persistent)
             if (train || (R.source == 2 && (act_off || R.exact_f32 || !R.actor_actions))) return 1;
@@ -861,6 +860,7 @@ struct Backend {
             if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
             else hipLaunchKernelGGL((k_rollout<128, 4, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
+        else if (w5) hipLaunchKernelGGL((k_rollout<128, 5>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         else hipLaunchKernelGGL((k_rollout<128, 4>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         return check_launch(err);
     }

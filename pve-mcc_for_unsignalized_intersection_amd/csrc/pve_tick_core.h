@@ -251,21 +251,10 @@ PVE_HD void block_sum_sparse(double *red, int t, bool has, double x)
 }
 
 // ------------------------------------------------------------------ shared (LDS) block of one env
-#ifndef PVE_K32
-#define PVE_K32 1                             // (A/B knob: make EXTRA=-DPVE_K32=0 builds RANK on the float64 distances everywhere)
-#endif
-template <int CAP, bool LJ = (CAP == 128), bool K32_ = (LJ && PVE_K32)> struct Shared {
+template <int CAP, bool LJ = (CAP == 128)> struct Shared {
     static constexpr int NW = CAP / 64;
     static constexpr bool PIN_READS = true;   // walk_window: keep the batched window reads from being sunk into guarded blocks
-    // K32 (k_rollout<128> without the actor; round 4): RANK counts on a plane of float32 KEYS, four per LDS instruction, instead
-    // of one float64 distance per instruction.  The float32 image of a distance is monotone, so distinct keys order exactly;
-    // entries whose keys are EQUAL get the same position and are filed in (float64 distance, slot) order by the claim
-    // protocol's fix-up (ph_rank).  Every list starts at a multiple of four entries (the gap behind its last entry holds
-    // +inf keys, which no compare counts): POOL grows by 3 entries per list.
-    static constexpr bool K32 = K32_ && (CAP == 128);
-    static constexpr int PAD = K32 ? 4 * NL : 0;
-    static constexpr int POOL = 5 * CAP + PAD;
-    static constexpr int KINF = POOL;         // K32: a vector of four +inf keys behind the plane (the reads beyond a list's last vector)
+    static constexpr int POOL = 5 * CAP;
     // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
     // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
     // CAP = 128: the entries sorted by (vd, slot) are an index array into u_vd / u_slot (no second copy of the
@@ -343,12 +332,11 @@ template <int CAP, bool LJ = (CAP == 128), bool K32_ = (LJ && PVE_K32)> struct S
         uint8_t mypos[CAP];          // position of each controlled vehicle inside its own lane's list (RANK .. WALK)
         uint8_t cyc_off[CAP];        // scratch offset of the dead-lock cycle led by slot t (LOCK .. FIN)
     };
-    alignas(16) float u_key[K32 ? POOL + 4 : 4];   // K32: float32 image of u_vd (BUILD .. RANK)
     uint8_t slot_of[CAP];            // dense mapping: slot of the c-th controlled vehicle (S2 .. FIN)
     int16_t cstart[NL + 1];          // controlled vehicles in the lanes below d = dense index of lane d's first one
                                      // (cstart[d + 1] - cstart[d] = controlled vehicles of lane d = the own segment of list d)
 #if !PVE_DEVICE_CODE
-    int emu_scan, emu_scan2;         // emulator-only accumulators of wave_incl_scan
+    int emu_scan;                    // emulator-only accumulator of wave_incl_scan
 #endif
     int16_t loff[NL + 1];            // list d occupies [loff[d], loff[d+1])
     union {
@@ -664,7 +652,6 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             sh.v[CAP] = 0; sh.a[CAP] = 0; sh.lane_of[CAP] = 0;
             if constexpr (Sh::HAS_LJ) sh.lj[CAP] = 0;
         }
-        if constexpr (Sh::K32) { if (t < 4) sh.u_key[Sh::KINF + t] = INFINITY; }
         if (t < 8) {
             sh.tabA[t >> 2][t & 3] = c.vdA[t >> 2][t & 3];
             sh.tabB[t >> 2][t & 3] = c.vdB[t >> 2][t & 3];
@@ -781,27 +768,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const int base = d ? sh.pref[5 * d - 1] : 0;
             const int mine = t ? sh.pref[t - 1] : 0;
             sh.segoff[d][k] = (int16_t)(mine - base);
-            if (k == 0) { if constexpr (!Sh::K32) sh.loff[d] = (int16_t)base; sh.nfin[d] = sh.pref[t] - base; }   // (own segment: all finite)
+            if (k == 0) { sh.loff[d] = (int16_t)base; sh.nfin[d] = sh.pref[t] - base; }   // (own segment: all finite)
         }
-        if constexpr (!Sh::K32) { if (t == NL * 5) sh.loff[NL] = sh.pref[NL * 5 - 1]; }
-        else {
-            // K32: every list starts at a multiple of four entries (RANK reads the keys four at a time); the gap behind its
-            // last entry gets +inf keys.  One more prefix sum, over the 12 padded list sizes (first wave; the others idle through it)
-            int sz = 0, padsz = 0;
-            if (t < NL) { sz = sh.pref[5 * t + 4] - (t ? sh.pref[5 * t - 1] : 0); padsz = (sz + 3) & ~3; }
-#if PVE_DEVICE_CODE
-            const int incl = wave_incl_scan(t, padsz, nullptr);
-#else
-            if (t == 0) sh.emu_scan2 = 0;
-            const int incl = wave_incl_scan(t, padsz, &sh.emu_scan2);
-#endif
-            if (t < NL) {
-                const int base = incl - padsz;
-                sh.loff[t] = (int16_t)base;
-                if (t == NL - 1) sh.loff[NL] = (int16_t)incl;
-                for (int q = sz; q < padsz; q++) sh.u_key[base + q] = INFINITY;
-            }
-        }
+        if (t == NL * 5) sh.loff[NL] = sh.pref[NL * 5 - 1];
     }
 
     // ============================================================== BUILD: every controlled vehicle files
@@ -825,7 +794,6 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         {
             const int e = sh.loff[lane] + q;                  // own lane: vd = p (ref :242-249)
             sh.u_vd[e] = p; sh.u_slot[e] = (uint8_t)sl; sh.u_list[e] = (uint8_t)lane;
-            if constexpr (Sh::K32) sh.u_key[e] = (float)p;
         }
         if (lane % 3 == 2) return;                            // right turns conflict with nobody (ref :156)
         // three batches of independent LDS reads (lane tables, distance tables + list offsets), then the writes: written
@@ -849,7 +817,6 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const double vd = (delta > 0) ? (tC[k] + delta) : INFINITY;        // our position inside lane2lane[d]); not chosen -> never sorted
             const int e = lo[k] + so[k] + q;
             sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)sl; sh.u_list[e] = (uint8_t)d[k];
-            if constexpr (Sh::K32) sh.u_key[e] = (float)vd;   // (+inf stays +inf; round-to-nearest is monotone)
             lds_add(&sh.nfin[d[k]], (delta > 0) ? 1 : 0);                       // (unconditional: no guarded block per entry)
         }
     }
@@ -865,51 +832,10 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // the whole run of equal distances in slot order (every later arrival rewrites the same values; the LDS executes
     // the operations of a wave in order, so the last fix-up is the last write).  A stale word that happens to carry the
     // stamp (left-over LDS contents) only sends an entry through the fix-up, which then files just itself.
-    struct alignas(16) Key4 { float x, y, z, w; };
     static PVE_HD void ph_rank(int t, Sh &sh, int salt = 0)
     {
         const int M = sh.loff[NL];
         const unsigned tag = Sh::DIRECT ? 0u : (((unsigned)sh.hd.ticks + (unsigned)salt * 0x9E37u) << 16);
-        if constexpr (Sh::K32) {
-            // float32 keys, four per LDS instruction, sixteen per round: position = number of SMALLER keys.  Equal keys (equal
-            // distances, or distances that round to the same float32) compute the same position and meet at the claim: the
-            // fix-up files the whole run of equal keys in (float64 distance, slot) order.  Gaps and unchosen entries hold +inf.
-            for (int e = t; e < M; e += CAP) {
-                const float kf = sh.u_key[e];
-                if (!(kf < INFINITY)) continue;
-                const int d = sh.u_list[e];
-                const int lo = sh.loff[d], nv = (sh.loff[d + 1] - lo) >> 2;
-                int pos = 0;
-                for (int v0 = 0; v0 < nv; v0 += 4) {
-                    Key4 w[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) w[k] = *(const Key4 *)&sh.u_key[(v0 + k < nv) ? lo + 4 * (v0 + k) : Sh::KINF];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) pos += (w[k].x < kf) + (w[k].y < kf) + (w[k].z < kf) + (w[k].w < kf);
-                }
-                const int myslot = sh.u_slot[e];
-                const int nown = sh.cstart[d + 1] - sh.cstart[d];                 // own-lane segment comes first
-                if (e - lo < nown) lds_store_relaxed(&sh.mypos[myslot], (uint8_t)pos);
-                const unsigned old = lds_xchg(&sh.s_idx[Sh::K32 ? lo + pos : 0], tag | (unsigned)e);
-                if ((old & 0xFFFF0000u) == tag) {         // an entry with the same key was here first (or a stale word)
-                    const int hi = lo + 4 * nv;
-                    for (int f = lo; f < hi; f++) {
-                        if (!(sh.u_key[f] == kf)) continue;
-                        const int sf = sh.u_slot[f];
-                        const double vf = sh.u_vd[f];
-                        int rk = 0;
-                        for (int g = lo; g < hi; g++) {
-                            if (!(sh.u_key[g] == kf)) continue;
-                            const double vg = sh.u_vd[g];
-                            rk += (vg < vf || (vg == vf && sh.u_slot[g] < sf)) ? 1 : 0;
-                        }
-                        lds_store_relaxed(&sh.s_idx[Sh::K32 ? lo + pos + rk : 0], tag | (unsigned)f);
-                        if (f - lo < nown) lds_store_relaxed(&sh.mypos[sf], (uint8_t)(pos + rk));
-                    }
-                }
-            }
-            return;
-        }
         for (int e = t; e < M; e += CAP) {
             const int d = sh.u_list[e];
             const double vd = sh.u_vd[e];
