@@ -806,7 +806,6 @@ struct Backend {
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
         if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
-        static const bool w5 = getenv("PVE_ROLLOUT_WPE5") != nullptr;         // A/B knob: 96-VGPR build, 10 workgroups per CU
         const bool train = P.out.obs_pre || P.out.state_pre;
         if (R.queue) {                                                        // persistent form (pve_rollout.persistent)
             if (train || (R.source == 2 && (act_off || R.exact_f32 || !R.actor_actions))) return 1;
@@ -860,7 +859,6 @@ struct Backend {
             if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
             else hipLaunchKernelGGL((k_rollout<128, 4, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
-        else if (w5) hipLaunchKernelGGL((k_rollout<128, 5>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         else hipLaunchKernelGGL((k_rollout<128, 4>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         return check_launch(err);
     }

@@ -51,7 +51,7 @@ for k in range(a.runs):
 print("%d runs: %d green, %d ended at a deferred spawn, 0 differences" % (a.runs, ok, stopped))
 # pve_step_many (k_rollout: still ticks, staged ticks, chunked launches, trajectory outputs) == single ticks, bit for bit
 for k in range(a.many):
-    kind = str(rng.choice(["k_rollout", "k_rollout", "actor", "geo", "geo", "state"]))
+    kind = str(rng.choice(["k_rollout", "k_rollout", "actor", "geo", "geo", "state", "persistent", "persistent", "geo_state", "geo_table"]))
     seed = int(rng.integers(1, 1 << 30))
     t0 = time.time()
     if kind in ("k_rollout", "actor"):
@@ -66,6 +66,33 @@ for k in range(a.many):
         scenarios.check_step_many(a.backend, src, n_envs=n_envs, capacity=cap, rate=rate, prefill=int(rng.choice([0, 150, 320])),
                                   chunks=chunks, trajectory_chunk=int(rng.integers(2, 30)), seed=seed)
         what = "cap %3d rate %6.0f %s chunks %s x %2d envs" % (cap, rate, src, chunks, n_envs)
+    elif kind == "persistent":                                  # the work-queue launch (round 4): intersections change hands inside the launch
+        cap = int(rng.choice([64, 128, 128]))
+        lo, hi = RATES[(12, cap)]
+        src = str(rng.choice(["pool", "zero", "table", "actor"]))
+        rate = float(rng.uniform(lo * 0.5, hi * (0.85 if src == "actor" else 1.1)))
+        n_envs = int(rng.choice([9, 40, 130, 300, 700]))
+        chunks = tuple(int(x) for x in rng.integers(1, 70, size=int(rng.integers(2, 5))))
+        scenarios.check_step_many(a.backend, src, n_envs=n_envs, capacity=cap, rate=rate, prefill=int(rng.choice([0, 150])),
+                                  chunks=chunks, trajectory_chunk=int(rng.integers(2, 30)), seed=seed, persistent=True)
+        what = "cap %3d rate %6.0f %s chunks %s x %3d envs (persistent)" % (cap, rate, src, chunks, n_envs)
+    elif kind in ("geo_state", "geo_table"):                    # f3 x f4 (round 4): training outputs / id-indexed table for 4 / 8 lanes
+        import torch
+        ln = int(rng.choice([4, 8]))
+        cap = int(rng.choice([64, 128]))
+        lo, hi = RATES[(ln, cap)]
+        rate = float(rng.uniform(lo, hi * 0.8))
+        if kind == "geo_state":
+            dt = torch.float32 if rng.random() < 0.5 else torch.float64
+            calls = tuple(int(x) for x in rng.integers(5, 60, size=int(rng.integers(2, 5))))
+            scenarios.check_step_many_state_rows(a.backend, n_envs=int(rng.choice([2, 5])), capacity=cap, calls=calls, rate=rate, seed=seed,
+                                                 obs_dtype=dt, chunk=int(rng.choice([0, 7, 16])), lane_num=ln, min_ctl_per_tick=0)
+            what = "%d lanes cap %3d state rows %s calls %s rate %6.0f" % (ln, cap, str(dt).split(".")[-1], calls, rate)
+        else:
+            chunks = tuple(int(x) for x in rng.integers(1, 70, size=int(rng.integers(2, 5))))
+            scenarios.check_step_many_geo(a.backend, ln, n_envs=int(rng.choice([3, 8, 12])), capacity=cap, chunks=chunks, rate=rate,
+                                          trajectory_chunk=int(rng.integers(2, 20)), seed=seed, source="table")
+            what = "%d lanes cap %3d rate %6.0f table chunks %s" % (ln, cap, rate, chunks)
     elif kind == "geo":                                         # k_rollout_geo == k_tick_geo ticks
         ln = int(rng.choice([4, 8]))
         cap = int(rng.choice([64, 128]))
