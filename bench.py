@@ -146,11 +146,12 @@ def _latest_profile(pattern):
     return max(files)[1] if files else None
 
 
-def pmc_traffic(envs_per_launch, cap, outputs, mode, ticks_per_launch, other):
+def pmc_traffic(envs_per_launch, cap, outputs, mode, ticks_per_launch, other, pkey=None):
     """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x gfx950 correction + WRITE_SIZE).
     Counters cannot be read from inside the process, so they come from the committed rocprofv3 passes of this very
     command (tools/collect_profiles.sh -> profiles/r*_traffic.json); null unless kernel sources, config and launch
-    shape are the profiled ones."""
+    shape are the profiled ones.  pkey: the profile of the persistent launch ("persist": items of 10 ticks, "persist_short":
+    the 20-tick call in items of 6), whose bytes scale with the ticks of the call."""
     default_outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
     sha = csrc_sha()
     if other or cap != 128 or tuple(outputs) != default_outputs or sha is None:
@@ -159,6 +160,12 @@ def pmc_traffic(envs_per_launch, cap, outputs, mode, ticks_per_launch, other):
     if not f:
         return None, None
     j = json.load(open(f))
+    if pkey:
+        t = j.get(pkey)
+        if not t or int(t.get("envs_per_launch", 0)) != envs_per_launch or t.get("csrc_sha") != sha:
+            return None, None
+        t = dict(t, hbm_bytes_per_launch=t["hbm_bytes_per_tick"] * ticks_per_launch, profiled_ticks_per_launch=t["ticks_per_launch"])
+        return t, os.path.relpath(f, ROOT)
     t = j.get("%s%d" % (mode, ticks_per_launch)) or j.get(mode)      # (a launch shape of its own, e.g. rollout5, else the mode's)
     if not t or int(t.get("envs_per_launch", 4096)) != envs_per_launch or t.get("csrc_sha") != sha \
             or int(t.get("ticks_per_launch", 1)) != ticks_per_launch:
@@ -166,7 +173,7 @@ def pmc_traffic(envs_per_launch, cap, outputs, mode, ticks_per_launch, other):
     return t, os.path.relpath(f, ROOT)
 
 
-def binding_profile(mode, ticks_per_launch, cap, other):
+def binding_profile(mode, ticks_per_launch, cap, other, pkey=None):
     """What actually binds the dominant kernel (it is not bandwidth): instruction counts per wave and tick, LDS bank
     conflicts and wait share from the committed SQ counter passes of this very build (profiles/r*_binding.json,
     tools/collect_profiles.sh); null unless the kernel sources are the profiled ones."""
@@ -177,8 +184,8 @@ def binding_profile(mode, ticks_per_launch, cap, other):
     if not f:
         return None, None
     j = json.load(open(f))
-    t = j.get("%s%d" % (mode, ticks_per_launch)) or j.get(mode)
-    if not t or t.get("csrc_sha") != sha or int(t.get("ticks_per_launch", 1)) != ticks_per_launch:
+    t = j.get(pkey) if pkey else (j.get("%s%d" % (mode, ticks_per_launch)) or j.get(mode))
+    if not t or t.get("csrc_sha") != sha or (not pkey and int(t.get("ticks_per_launch", 1)) != ticks_per_launch):
         return None, None
     return t, os.path.relpath(f, ROOT)
 
@@ -852,8 +859,9 @@ def main(argv=None, env_factory=None):
             kname += " persistent (PERS: work queue)"
         if args.actor:
             kname += " with the actor inside (ACT)" if mode == "rollout" else " + k_actor_h"
-        other = args.actor or lane_num != 12 or args.obs_f32 or traj_on or pers
-        tr, traffic_src = (None, None) if (emu or not steady) else pmc_traffic(int(envs_per_launch), cap, outputs, mode, tpl, other)
+        other = args.actor or lane_num != 12 or args.obs_f32 or traj_on
+        pkey = (("persist" if K >= 100 else "persist_short") if pers else None)
+        tr, traffic_src = (None, None) if (emu or not steady) else pmc_traffic(int(envs_per_launch), cap, outputs, mode, tpl, other, pkey)
         traffic = tr["hbm_bytes_per_launch"] if tr else None
         counter_rate = (traffic / tpl * n_sub / (wall / K) / 1e9) if traffic else None
         peak_meas = None if (emu or args.no_copy_peak) else measured_copy_peak(torch, dev)
@@ -861,9 +869,10 @@ def main(argv=None, env_factory=None):
         # ---- what binds: VALU issue (SQ counters of this build), not bandwidth
         std_out = tuple(outputs) == ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
         if args.actor and mode == "rollout" and lane_num == 12 and args.obs_f32 and not traj_on:
-            bp, bind_src = (None, None) if emu else binding_profile("actor_rollout", tpl, cap, not std_out)   # the closed loop's own SQ pass
+            bp, bind_src = (None, None) if emu else binding_profile("actor_rollout", tpl, cap, not std_out,
+                                                                    "actor_persist" if pers else None)   # the closed loop's own SQ pass
         else:
-            bp, bind_src = (None, None) if emu else binding_profile(mode, tpl, cap, other or not std_out)
+            bp, bind_src = (None, None) if emu else binding_profile(mode, tpl, cap, other or not std_out, pkey)
         binding = None
         if bp:
             waves_per_tick = n_envs * cap / 64.0
@@ -872,6 +881,7 @@ def main(argv=None, env_factory=None):
                        "valu_per_wave_tick": bp["valu_per_wave_tick"], "salu_per_wave_tick": bp["salu_per_wave_tick"],
                        "lds_per_wave_tick": bp["lds_per_wave_tick"],
                        "lds_bank_conflict_frac": bp["lds_bank_conflict_frac"], "wait_frac": bp["wait_frac"],
+                       "lds_bank_conflict_cycles_per_wave_tick": bp.get("lds_bank_conflict_cycles_per_wave_tick"),
                        "shader_clock_ghz": bp["shader_clock_ghz"], "profiled_in": bind_src,
                        "definition": "frac = (waves per tick x VALU instructions per wave and tick x 4 cycles / 1024 SIMDs / "
                                      "shader clock) / measured time per tick: the share of the tick during which the vector "

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PVE_ABI_VERSION 5
+#define PVE_ABI_VERSION 6
 #define PVE_LANES 12          /* physical lanes: lane_num = 4, 8 or 12 (arrays are padded to 12) */
 #define PVE_MAX_DIRS 16       /* virtual-lane lists (routes): 12 for lane_num 4 / 12, 16 for lane_num 8 (ref :86, :132, :167) */
 #define PVE_OBS_WIDTH 28      /* (o_agent_num + 1) * 4, ref :1295 */
@@ -275,6 +275,12 @@ int pve_synchronize(pve_handle h);
  * buffer of uint64 [n_envs * capacity/64][16] (column = phase: load, step1, step2, step3, build, rank,
  * walk, effects, lock, final, state); NULL disables. Used by tools/phase_profile.py; no effect on results. */
 int pve_debug_phase_cycles(pve_handle h, uint64_t *dev_counters16);
+
+/* Diagnostics: every later pve_step_all / pve_scene_update launch of the 12-lane kernel (k_tick) RETURNS behind phase n
+ * (0 load, 1 step1, 2 step2, 3 step3, 4 build, 5 rank, 6 walk + reward, 7 effects, 8 lock) without writing any state, so
+ * that hardware counters of truncated launches on one frozen state attribute instructions and LDS conflicts to phases
+ * (tools/phase_counters.sh); n < 0 restores the full tick.  The results of truncated launches are meaningless. */
+int pve_debug_stop_phase(pve_handle h, int n);
 
 /* Diagnostics: launch a kernel that performs exactly the tick's state-load pattern over every slot
  * (72 B per slot read: 6 x f64 + 6 x i32) and stores one int per env into dev_sink[n_envs]; a known byte

@@ -56,38 +56,47 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(CAP == 64 ?
     T::ph_load(c, P, env, t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(0)
+    if (P.stop_phase == 0) return;          // (diagnostics, uniform: pve_debug_stop_phase)
     T::ph_step1(c, P, env, t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(1)
+    if (P.stop_phase == 1) return;          // (diagnostics, uniform: pve_debug_stop_phase)
     T::ph_step2(c, t, sh, r);
     T::ph_lists_a(c, t, sh);
     lds_barrier();
     PVE_PHASE_MARK(2)
+    if (P.stop_phase == 2) return;          // (diagnostics, uniform: pve_debug_stop_phase)
     T::ph_step3(c, t, sh, r);
     T::ph_step3_publish(t, sh, r);
     T::ph_lists_b(t, sh);
     lds_barrier();
     PVE_PHASE_MARK(3)
+    if (P.stop_phase == 3) return;          // (diagnostics, uniform: pve_debug_stop_phase)
     T::ph_build(c, t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(4)
+    if (P.stop_phase == 4) return;          // (diagnostics, uniform: pve_debug_stop_phase)
     T::ph_rank(t, sh, env);
     lds_barrier();
     PVE_PHASE_MARK(5)
+    if (P.stop_phase == 5) return;          // (diagnostics, uniform: pve_debug_stop_phase)
     T::ph_scan(c, t, sh, r);
     PVE_PHASE_MARK(11)
     T::ph_reward(c, t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(6)
+    if (P.stop_phase == 6) return;          // (diagnostics, uniform: pve_debug_stop_phase)
     T::ph_effects(c, t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(7)
+    if (P.stop_phase == 7) return;          // (diagnostics, uniform: pve_debug_stop_phase)
     T::ph_prefetch_arrival(P, env, t, sh, r, NL);
     T::ph_lock(c, t, sh, r);
     lds_barrier();
     T::ph_lock2(t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(8)
+    if (P.stop_phase == 8) return;          // (diagnostics, uniform: pve_debug_stop_phase)
     T::ph_final(c, P, env, t, sh, r);
     PVE_PHASE_MARK(9)
     if (P.out.state_pre) {            // uniform branch: optional training output

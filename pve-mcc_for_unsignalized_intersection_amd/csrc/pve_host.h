@@ -232,5 +232,6 @@ struct pve_handle_s {
     long long ticks_since_reset;
     unsigned long long *phase_cycles;
     bool has_actor;                   // pve_set_actor installed an actor in the workspace
+    int stop_phase;                   // pve_debug_stop_phase (diagnostics), -1 = off
     unsigned q_done_base;             // persistent roll-out: items completed per intersection since pve_reset (cumulative)
 };

@@ -135,6 +135,7 @@ struct Params {
     const int32_t *choice;       // 8-lane: the randint(0,1) draws of ref :390, [rows][lane_num] per env, or null (all 0)
     long long choice_env_stride; // int32 elements between envs (0 = shared)
     unsigned long long *phase_cycles;   // diagnostics: 16 counters of wave-cycles per phase, or null
+    int32_t stop_phase;          // diagnostics (pve_debug_stop_phase): k_tick returns behind this phase; < 0: the full tick
     Outputs out;
 };
 

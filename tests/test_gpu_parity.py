@@ -413,6 +413,15 @@ def test_gpu_persistent_step_many_equals_single_ticks(cap, n_envs, chunks, rate)
                               persistent=True, seed=7, trajectory_chunk=24)
 
 
+def test_gpu_two_persistent_launches_share_the_chip():
+    """Two handles, each with its own persistent launch on its own stream (2 x 2048 envs, 2 x 2048 workgroups: twice what the
+    chip holds at once, so workgroups of both launches wait for slots while others spin on their hand-offs), and a batch of
+    3 envs (fewer intersections than shards): same results as the oracle / as single ticks."""
+    m, peak = scenarios.check_driver_shape_vs_oracle(BACKEND, n_sub=2, chunk=4, persistent=True, calls=(50, 50, 50, 50, 50, 50, 5, 20))
+    assert m["alive_steps"] / m["ticks"] > 50 and peak <= 128
+    scenarios.check_step_many(BACKEND, "pool", n_envs=3, capacity=128, chunks=(9, 40, 17), persistent=True, seed=11)
+
+
 @pytest.mark.parametrize("chunk", [5, 2])
 def test_gpu_persistent_driver_shape_vs_oracle(chunk):
     """The persistent launch at full size: ONE batch of 4096 x 128, calls of 50 / 5 / 20 ticks in items of `chunk` ticks

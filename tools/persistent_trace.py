@@ -17,7 +17,7 @@ from pve_mcc_amd.arrivals import synthetic_arrivals
 dev = torch.device("cuda", 0)
 n, cap = 4096, 128
 K = int(os.environ.get("TRACE_K", "20"))
-chunk = int(os.environ.get("TRACE_CHUNK", "5"))
+chunk = int(os.environ.get("TRACE_CHUNK", "6"))
 arr = synthetic_arrivals(n, rate=1100.0, horizon_s=400.0, seed=20250213)
 env = pve_mcc_amd.BatchedIntersections(n, cap, arr, device=dev)
 env.reset()

@@ -21,16 +21,19 @@ python3 - "$OUT" <<'PY' > "$REPO/gpurun_out/pmc_sq_$TAG.txt"
 import sys, glob, csv, collections
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
+for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True)):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0)))
+    for row in rows:
         k = row.get("Kernel_Name", "")
         if "k_tick" not in k and "k_actor" not in k and "k_rollout" not in k:
             continue
-        acc[k.split("(")[0][:40]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        acc[k.split("(")[0][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+# mean/launch: launches of equal length (k_tick, chunked k_rollout); last: the run's LAST launch of the kernel = the timed
+# --steps ticks of a persistent launch (its earlier launches are the prefill / warm-up calls, of other lengths)
 for k, d in acc.items():
     print(k)
     for c in sorted(d):
         v = d[c]
-        print("   %-28s mean/launch %.4g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+        print("   %-28s mean/launch %.4g  last %.4g  (n=%d)" % (c, sum(v) / len(v), v[-1], len(v)))
 PY
 cat "$REPO/gpurun_out/pmc_sq_$TAG.txt"
