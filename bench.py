@@ -938,13 +938,15 @@ def main(argv=None, env_factory=None):
                          "frac_of_peak_measured": (achieved / peak_meas) if peak_meas else None,
                          "binding": binding,
                          "kernel": kname, "kernel_ms": kern_s * 1e3,
+                         "launch_ms": (gpu_ms if pers else kern_s * 1e3 * tpl),     # duration of one launch of the dominant kernel (HIP events)
                          "envs_per_launch": int(envs_per_launch),
                          "concurrent_launches": n_sub, "per_launch_achieved": per_launch,
                          "definition": "achieved = algorithmic bytes the measured mode must move (step: 380 B per slot-step, "
                                        "SURVEY 8d; pve_step_many launch of T ticks: 380 - 124 (1 - 1/T), the persistent state "
                                        "crosses HBM once per launch -- once per queue ITEM of the persistent launch) x capacity x envs of the GPU, every slot counted / "
                                        "wall-clock per tick; per_launch_achieved = the bytes of one sub-batch / "
-                                       "its tick time on its own stream (HIP events), sub-batches overlap; "
+                                       "its tick time on its own stream (HIP events), sub-batches overlap; kernel_ms = launch_ms / ticks per "
+                                       "launch (a persistent launch = the whole timed call: rocprofv3's LAST dispatch of the kernel); "
                                        "achieved_counter_bytes = HBM bytes the PMC counters saw (traffic, profiled on this "
                                        "very build and config, else null) / wall-clock per tick; peak_measured = 1 GiB "
                                        "device copy, read + write; binding = the roofline that actually limits the kernel"},

@@ -33,6 +33,9 @@ run bench_lanes8_step.json $NB --lane-num 8 --steps 300 --pipeline 3 --mode step
 run bench_lanes4.json $B --lane-num 4 --capacity 64 --rate 1200 --steps 300
 run bench_lanes4_cap128.json $NB --lane-num 4 --steps 300
 run bench_lanes4_step.json $NB --lane-num 4 --capacity 64 --rate 1200 --steps 300 --mode step
+# (second pass after `make_profile_summaries.py` has written the counter profiles of this very build: ONLY_BENCH=1 re-runs just
+#  the bench lines, which then carry roofline.traffic / roofline.binding)
+[ "${ONLY_BENCH:-0}" = "1" ] && { ls $O; exit 0; }
 # ---- per-kernel durations (rocprofv3 --kernel-trace --stats), same commands
 st() { d=$1; shift; timeout 400 rocprofv3 --kernel-trace --stats -d $O/$d -o r -- $NB "$@" > /dev/null 2>&1; }
 st stats
@@ -73,4 +76,8 @@ AB_CAP=64 python tools/ab_launch_shapes.py 2>&1 | grep -v amdgpu.ids > $O/ab_lau
 # ---- per-item timeline of one persistent call (diagnostics build of the library: -DPVE_QUEUE_TRACE)
 make -s -C pve-mcc_for_unsignalized_intersection_amd/csrc trace > /dev/null 2>&1 && \
   PVE_LIBRARY_PATH=$(pwd)/build/libpveenv_trace.so python tools/persistent_trace.py 2>&1 | grep -v amdgpu.ids > $O/persistent_trace.txt
+# keep what comes back small (gpurun merges <= 64 MiB): only the rocpd databases of the raw rocprofv3 directories are needed
+find $O gpurun_out/pmc_sq_* gpurun_out/phase_counters -type f \( -name "*.csv" -o -name "*.json" -o -name "*.log" -o -name "*.txt" \) -path "*_p[0-9]*" -size +200k -delete 2>/dev/null
+rm -rf gpurun_out/pmc_sq_*/p*/ gpurun_out/phase_counters/s* 2>/dev/null
+du -sh gpurun_out $O 2>/dev/null
 ls $O

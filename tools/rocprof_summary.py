@@ -25,6 +25,13 @@ def main():
                                         "or name like '%k_actor%'")):
             d = [x[0] for x in cur.execute("select end-start from kernels where name=? order by start", (name,))][-tail:]
             print("%-70s n=%d avg_ns=%.1f min=%d max=%d" % (name[:70], len(d), sum(d) / len(d), min(d), max(d)))
+        # a persistent launch (k_rollout<.., PERS = true>) is ONE dispatch per call: the run's earlier dispatches are the prefill /
+        # warm-up calls (other lengths); the LAST one is the timed --steps ticks = bench.py's roofline.launch_ms
+        print("## last dispatch of each k_tick / k_rollout / k_actor kernel (a persistent launch: the timed call)")
+        for (name,) in list(cur.execute("select distinct name from kernels where name like '%k_tick%' or name like '%k_rollout%' "
+                                        "or name like '%k_actor%'")):
+            d = [x[0] for x in cur.execute("select end-start from kernels where name=? order by start", (name,))]
+            print("%-70s last_ns=%d (dispatch %d of %d)" % (name[:70], d[-1], len(d), len(d)))
     for r in cur.execute("select distinct name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x "
                          "from kernels where name like '%k_tick%' or name like '%k_rollout%' or name like '%k_actor%'"):
         # rocprofv3's vgpr_count field is NOT the per-lane allocation the occupancy follows (it reports 48 for a kernel the
