@@ -206,6 +206,63 @@ __device__ __forceinline__ void q_dequeue(RolloutQueue *Q, int n_shards, int n_e
     }
 }
 
+// The workgroup's next item: lane 0 pulls it and waits for the previous chunk of its intersection (another workgroup's item);
+// everybody learns it through q_word (LDS).  -> false when the call has no work left for this workgroup's XCD.
+// q_word[0..1] = (env, chunk), [2..3] = lane 0's dequeue state (shard, shards looked at).
+__device__ __forceinline__ bool q_take(const PVE_AS4 RolloutArgs &R, int n_envs, int t0, int *q_word, int &env, int &chunk, int &k_base,
+                                       int &n_ticks)
+{
+    RolloutQueue *Q = (RolloutQueue *)R.queue;
+    unsigned *done = R.queue + sizeof(RolloutQueue) / 4;
+    if (t0 == 0) {
+        int shard = q_word[2], probe = q_word[3], e, ch;
+        const unsigned long long tq0 = Q_TRACE(R) ? wall_clock64() : 0ull;
+        q_dequeue(Q, R.n_shards, n_envs, R.n_full + R.n_taper, q_xcc_id(), shard, probe, e, ch);
+        q_word[0] = e; q_word[1] = ch; q_word[2] = shard; q_word[3] = probe;
+        const unsigned long long tq1 = Q_TRACE(R) ? wall_clock64() : 0ull;
+        if (e >= 0)                                   // the previous chunk of this intersection (another workgroup's item)
+            while ((int)(q_load(&done[e]) - (R.done_base + (unsigned)ch)) < 0) __builtin_amdgcn_s_sleep(8);
+        if (Q_TRACE(R) && e >= 0) {                    // diagnostics: dequeue start, item known, predecessor done, who
+            unsigned long long *row = Q_TRACE(R) + ((size_t)ch * n_envs + e) * 8;
+            row[0] = tq0; row[1] = tq1; row[2] = wall_clock64();
+            row[6] = (unsigned long long)blockIdx.x | ((unsigned long long)q_xcc_id() << 32);
+        }
+    }
+    __syncthreads();
+    env = __builtin_amdgcn_readfirstlane(q_word[0]);
+    chunk = __builtin_amdgcn_readfirstlane(q_word[1]);
+    if (env < 0) return false;
+    k_base = (chunk < R.n_full ? chunk : R.n_full) * R.n_ticks;
+    for (int q = 0; q < chunk - R.n_full; q++) k_base += R.taper[q];                  // (uniform: scalar loop over <= 7 entries)
+    n_ticks = chunk < R.n_full ? R.n_ticks : (int)R.taper[chunk - R.n_full];
+    return true;
+}
+// hand the intersection on: every wave's stores (state, header, the ticks' output rows) have reached the L2, then the count of
+// completed items of this intersection goes up by one
+__device__ __forceinline__ void q_publish(const PVE_AS4 RolloutArgs &R, int n_envs, int t0, int env, int chunk)
+{
+    const unsigned long long tf0 = (Q_TRACE(R) && t0 == 0) ? wall_clock64() : 0ull;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t0 == 0) q_store(R.queue + sizeof(RolloutQueue) / 4 + env, R.done_base + (unsigned)chunk + 1u);
+    if (Q_TRACE(R) && t0 == 0) {                      // diagnostics: state flushed (stores issued), handed on
+        unsigned long long *row = Q_TRACE(R) + ((size_t)chunk * n_envs + env) * 8;
+        row[4] = tf0; row[5] = wall_clock64();
+    }
+}
+// the last workgroup to leave clears the queue words for the next launch (done[] stays: it is cumulative)
+__device__ __forceinline__ void q_leave(const PVE_AS4 RolloutArgs &R, int t0)
+{
+    RolloutQueue *Q = (RolloutQueue *)R.queue;
+    if (t0 == 0) {
+        const unsigned left = __hip_atomic_fetch_add(&Q->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left + 1u == gridDim.x) {
+            for (int k = 0; k < QUEUE_MAX_SHARDS; k++) { q_store(&Q->s[k].head, 0u); q_store(&Q->s[k].owner, 0u); }
+            q_store(&Q->exits, 0u);
+        }
+    }
+}
+
 // pve_step_many: R.n_ticks ticks of one intersection per workgroup, the state resident in registers / LDS between the
 // ticks (pve_tick_core.h, "k_rollout").  Per tick only the outputs go to HBM; the action of the next tick (pool) and
 // the next arrival times are prefetched under the tail of the current one.
@@ -269,29 +326,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         n_ticks = R.n_ticks;
         const double *act0 = nullptr;
         if constexpr (PERS) {
-            RolloutQueue *Q = (RolloutQueue *)R.queue;
-            unsigned *done = R.queue + sizeof(RolloutQueue) / 4;
-            if (t0_ == 0) {
-                int shard = q_word[2], probe = q_word[3], e, ch;
-                const unsigned long long tq0 = Q_TRACE(R) ? wall_clock64() : 0ull;
-                q_dequeue(Q, R.n_shards, P.n_envs, R.n_full + R.n_taper, q_xcc_id(), shard, probe, e, ch);
-                q_word[0] = e; q_word[1] = ch; q_word[2] = shard; q_word[3] = probe;
-                const unsigned long long tq1 = Q_TRACE(R) ? wall_clock64() : 0ull;
-                if (e >= 0)                           // the previous chunk of this intersection (another workgroup's item)
-                    while ((int)(q_load(&done[e]) - (R.done_base + (unsigned)ch)) < 0) __builtin_amdgcn_s_sleep(8);
-                if (Q_TRACE(R) && e >= 0) {            // diagnostics: dequeue start, item known, predecessor done, who
-                    unsigned long long *row = Q_TRACE(R) + ((size_t)ch * P.n_envs + e) * 8;
-                    row[0] = tq0; row[1] = tq1; row[2] = wall_clock64();
-                    row[6] = (unsigned long long)blockIdx.x | ((unsigned long long)q_xcc_id() << 32);
-                }
-            }
-            lds_barrier();
-            const int e = __builtin_amdgcn_readfirstlane(q_word[0]), ch = __builtin_amdgcn_readfirstlane(q_word[1]);
-            if (e < 0) break;
-            env0_ = e; chunk_ = ch;
-            k_base_ = (ch < R.n_full ? ch : R.n_full) * R.n_ticks;
-            for (int q = 0; q < ch - R.n_full; q++) k_base_ += R.taper[q];              // (uniform: scalar loop over <= 7 entries)
-            n_ticks = ch < R.n_full ? R.n_ticks : (int)R.taper[ch - R.n_full];
+            int e, ch, kb, nt;
+            if (!q_take(R, P.n_envs, t0_, q_word, e, ch, kb, nt)) break;
+            env0_ = e; chunk_ = ch; k_base_ = kb; n_ticks = nt;
             if (R.source == 1 || R.source == 3) pool_idx = (R.pool_tick0 + k_base_) % R.n_pool;
             if (R.source == 1) act0 = R.pool + (size_t)pool_idx * (size_t)P.n_envs * CAP;
         }
@@ -448,32 +485,12 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         }
     }
     if constexpr (PERS) {
-        // hand the intersection on: every wave's stores (state, header, the ticks' output rows) have reached the L2, then
-        // the count of completed items of this intersection goes up by one
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
-        const unsigned long long tf0 = (Q_TRACE(R) && t0_ == 0) ? wall_clock64() : 0ull;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
-        if (t0_ == 0) q_store(R.queue + sizeof(RolloutQueue) / 4 + env0_, R.done_base + (unsigned)chunk_ + 1u);
-        if (Q_TRACE(R) && t0_ == 0) {                  // diagnostics: state flushed (stores issued), handed on
-            unsigned long long *row = Q_TRACE(R) + ((size_t)chunk_ * P.n_envs + env0_) * 8;
-            row[4] = tf0; row[5] = wall_clock64();
-        }
+        q_publish(R, P.n_envs, t0_, env0_, chunk_);
     } else break;
   }
-    if constexpr (PERS) {
-        // the last workgroup to leave clears the queue words for the next launch (done[] stays: it is cumulative)
-        const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
-        RolloutQueue *Q = (RolloutQueue *)R.queue;
-        if (t0_ == 0) {
-            const unsigned left = __hip_atomic_fetch_add(&Q->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (left + 1u == gridDim.x) {
-                for (int k = 0; k < QUEUE_MAX_SHARDS; k++) { q_store(&Q->s[k].head, 0u); q_store(&Q->s[k].owner, 0u); }
-                q_store(&Q->exits, 0u);
-            }
-        }
-    }
+    if constexpr (PERS) q_leave(*(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R), t0_);
 }
 
 // General-geometry tick (lane_num 4 / 8): same workgroup-per-intersection structure, phases of
@@ -573,30 +590,50 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu((CAP == 64 
 // TRAIN: the training outputs (obs_pre, state_pre) per tick of a trajectory roll-out; IDT: PVE_SRC_TABLE (actions by (tick,
 // vehicle id), gathered by the vehicle's own thread and parked at its NEW slot in `p[]`, which is free between FIN and the next
 // S1) -- as in k_rollout, variants of their own so that the default kernel keeps its register allocation.
-template <int CAP, bool FIX4 = false, int WPE = 4, bool TRAIN = false, bool IDT = false>
+// PERS: the persistent work-queue form (k_rollout<.., PERS>: same queue, same hand-off), pool / zero sources.
+template <int CAP, bool FIX4 = false, int WPE = 4, bool TRAIN = false, bool IDT = false, bool PERS = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout_geo(const GeoConst g_arg, const Params P_arg,
                                                                                                 const RolloutArgs R_arg)
 {
+    static_assert(!PERS || (!TRAIN && !IDT), "the persistent form of the geometry kernel: pool / zero sources");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(GeoConst) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     __shared__ SharedGeo<CAP> sh;
+    __shared__ int q_word[4];
     int t0_ = threadIdx.x;
-    int env0_ = blockIdx.x;
+    int env0_ = PERS ? 0 : blockIdx.x;
+    int k_base_ = 0, chunk_ = 0;
     KernargPtr kav_ = ka0_;
     Regs r;
     FinCarry fc;
     typedef TickGeo<CAP> T;
     typedef Tick<CAP, SharedGeo<CAP>> B;
     int pool_idx, n_ticks;
+    if constexpr (PERS) { if (t0_ == 0) { q_word[2] = -1; q_word[3] = 0; } }
+  for (;;) {                                        // PERS: one pass per item; else exactly one pass
     {
         const PVE_AS4 GeoConst &g = *(const PVE_AS4 GeoConst *)ka0_;
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
         pool_idx = R.pool_tick0;
         n_ticks = R.n_ticks;
+        if constexpr (PERS) {
+            int e, ch, kb, nt;
+            if (!q_take(R, P.n_envs, t0_, q_word, e, ch, kb, nt)) break;
+            env0_ = e; chunk_ = ch; k_base_ = kb; n_ticks = nt;
+            const double *act0 = nullptr;
+            if (R.source == 1) {
+                pool_idx = (R.pool_tick0 + k_base_) % R.n_pool;
+                act0 = R.pool + (size_t)pool_idx * (size_t)P.n_envs * CAP;
+            }
+            T::template ph_load<true>(g, P, env0_, t0_, sh, r, act0, true);
+            lds_barrier();
+            T::template ph_load_late<true>(P, env0_, t0_, sh, r);
+        } else {
         T::ph_load(g, P, env0_, t0_, sh, r);            // P.actions = the first tick's actions
         lds_barrier();
         T::ph_load_late(P, env0_, t0_, sh, r);
+        }
         if constexpr (IDT) {                            // the first tick's action of the vehicle in this slot: table[row][id]
             const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
             r.act = r.alive ? R.pool[(size_t)pool_idx * (size_t)R.table_ids + idc] : 0.0;
@@ -605,6 +642,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     double sp_act = 0;                                  // IDT: the action of the vehicle this lane spawns
     for (int k = 0; k < n_ticks; k++) {
         // (the same opaque re-definitions as in k_rollout: nothing derived from the arguments is hoisted out of the loop)
+        if constexpr (PERS) env0_ = __builtin_amdgcn_readfirstlane(env0_);
         asm volatile("" : "+s"(kav_), "+v"(t0_), "+s"(env0_));
         const KernargPtr ka = kav_;
         const int t = t0_, env = env0_;
@@ -650,7 +688,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         lds_barrier();
         B::ph_prefetch_arrival(P, env, t, sh, r, g.lane_num);
         B::ph_lock_slot(g.base, t, sh, r);
-        const Outputs O = B::template tick_outputs<TRAIN>(P, R, k);
+        const Outputs O = B::template tick_outputs<TRAIN>(P, R, k_base_ + k);
         if (TRAIN && O.state_pre) T::ph_state_order(t, sh, r);    // (uniform; `ord` is staging storage from FIN on)
         lds_barrier();
         B::ph_lock2_slot(t, sh, r);
@@ -682,6 +720,13 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
         B::ph_flush(P, env0_, t0_, sh);
     }
+    if constexpr (PERS) {
+        const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
+        const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka0_ + OFF_P);
+        q_publish(R, P.n_envs, t0_, env0_, chunk_);
+    } else break;
+  }
+    if constexpr (PERS) q_leave(*(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R), t0_);
 }
 
 template <int CAP>
@@ -875,7 +920,8 @@ struct Backend {
     {
         static const bool off = getenv("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
         const bool train = P_in.out.obs_pre || P_in.out.state_pre;
-        if (off || R.source == 2 /* the actor reads 12-lane rows */ || P_in.phase_cycles || R.queue || (train && R.source == 3)) return 1;
+        if (off || R.source == 2 /* the actor reads 12-lane rows */ || P_in.phase_cycles || (train && R.source == 3)) return 1;
+        if (R.queue && (train || R.source == 3)) return 1;                    // (the queue form: pool / zero sources)
         hipStream_t s = (hipStream_t)stream;
         Params P = P_in;
         RolloutArgs Rk = R;
@@ -884,7 +930,35 @@ struct Backend {
             P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
         } else P.actions = nullptr;
         if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
-        const dim3 grid(P.n_envs);
+        dim3 grid(P.n_envs);
+        if (R.queue) {
+            // the persistent form: as many workgroups as the chip holds at once (the variants share their register budget and LDS
+            // block: one occupancy query per capacity)
+            static int wgs_per_cu[2] = {0, 0}, n_cu = 0;
+            const int ci = cap == 64 ? 0 : 1;
+            if (!wgs_per_cu[ci]) {
+                int nb = 0, dev = 0;
+                hipDeviceProp_t prop;
+                hipError_t e = (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout_geo<64, true, 4, false, false, true>, 64, 0)
+                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout_geo<128, true, 4, false, false, true>, 128, 0);
+                if (e != hipSuccess || nb <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+                    err = hip_err("occupancy query of the persistent roll-out", e);
+                    return -1;
+                }
+                n_cu = prop.multiProcessorCount;
+                wgs_per_cu[ci] = nb;
+            }
+            const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
+            long long gq = (long long)wgs_per_cu[ci] * n_cu;
+            if (gq > items) gq = items;
+            grid = dim3((unsigned)gq);
+            if (g.lane_num == 4) {
+                if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, true, 4, false, false, true>), grid, dim3(64), 0, s, g, P, Rk);
+                else hipLaunchKernelGGL((k_rollout_geo<128, true, 4, false, false, true>), grid, dim3(128), 0, s, g, P, Rk);
+            } else if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, false, 4, false, false, true>), grid, dim3(64), 0, s, g, P, Rk);
+            else hipLaunchKernelGGL((k_rollout_geo<128, false, 4, false, false, true>), grid, dim3(128), 0, s, g, P, Rk);
+            return check_launch(err);
+        }
         // (variant = layout x capacity x {default, training outputs, id-indexed table})
 #define PVE_LAUNCH_GEO(CAP_, FIX_)                                                                                              \
         do {                                                                                                                    \

@@ -164,7 +164,11 @@ template <int CAP> struct TickGeo {
     static constexpr int NW = CAP / 64;
 
     // ============================================================== L: load
-    static PVE_HD void ph_load(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
+    // COH (persistent roll-out): the state may have been stored by another workgroup of this launch -> coherent loads
+    // (Tick::ph_load); act0: the first tick's actions of the item ([n_envs][CAP] or null) instead of P.actions
+    template <bool COH = false>
+    static PVE_HD void ph_load(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r,
+                               const double *act0 = nullptr, bool use_act0 = false)
     {
         // the lookup tables first (they are written to LDS, so their loads must be waited for before the first barrier;
         // everything issued behind them may still be in flight then)
@@ -177,21 +181,22 @@ template <int CAP> struct TickGeo {
         {
             const int *src = (const int *)&gh;
             int *dst = (int *)&sh.hd;
-            for (int w = t + 2; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];
+            for (int w = t + 2; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = gld<COH>(src + w);
         }
-        if (t == 0) sh.hd.current_time = gh.current_time + g.base.deltaT;       // ref :223
-        const int N = gh.n_alive;
+        if (t == 0) sh.hd.current_time = gld<COH>(&gh.current_time) + g.base.deltaT;       // ref :223
+        const int N = gld<COH>(&gh.n_alive);
         const size_t gi = (size_t)env * CAP + t;
         r.alive = t < N;
         r.jerk = 0;
         r.act = 0;
         r.p = r.v = r.a = r.jerk_sum = r.vir_dis = r.closer_p = 0;
         r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
+        const double *acts = use_act0 ? act0 : P.actions;
         if (t < 64 || t < N) {                    // first wave unconditionally (no dependence on n_alive), later waves live slots only
-            if (P.actions) r.act = P.actions[gi];
-            r.p = P.f64[F_P][gi]; r.v = P.f64[F_V][gi]; r.a = P.f64[F_A][gi];
-            r.meta = P.i32[I_META][gi]; r.step = P.i32[I_STEP][gi];
-            r.seq = P.i32[I_SEQ][gi]; r.vnum = P.i32[I_VNUM][gi]; r.count = P.i32[I_COUNT][gi];
+            if (acts) r.act = acts[gi];
+            r.p = gld<COH>(P.f64[F_P] + gi); r.v = gld<COH>(P.f64[F_V] + gi); r.a = gld<COH>(P.f64[F_A] + gi);
+            r.meta = gld<COH>(P.i32[I_META] + gi); r.step = gld<COH>(P.i32[I_STEP] + gi);
+            r.seq = gld<COH>(P.i32[I_SEQ] + gi); r.vnum = gld<COH>(P.i32[I_VNUM] + gi); r.count = gld<COH>(P.i32[I_COUNT] + gi);
         }
         sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
         if (t == 0) {
@@ -204,12 +209,14 @@ template <int CAP> struct TickGeo {
     // jerk_sum, closer_p and vir_dis are first touched in WALK / REWARD (ref :302, :321, :1348), the id only by FIN: their
     // loads are issued behind the list phases, not with the rest of the state -- seven registers less to carry through
     // the register peak of PAIRS (four were spilled; which fields move was settled by the compiler's spill count)
+    template <bool COH = false>
     static PVE_HD void ph_load_late(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
         if (t < 64 || t < sh.hd.n_alive) {
             const size_t gi = (size_t)env * CAP + t;
-            r.jerk_sum = P.f64[F_JERK_SUM][gi]; r.closer_p = P.f64[F_CLOSER_P][gi]; r.vir_dis = P.f64[F_VIR_DIS][gi];
-            r.id = P.i32[I_ID][gi];                       // (FIN only, for a vehicle that moves)
+            r.jerk_sum = gld<COH>(P.f64[F_JERK_SUM] + gi); r.closer_p = gld<COH>(P.f64[F_CLOSER_P] + gi);
+            r.vir_dis = gld<COH>(P.f64[F_VIR_DIS] + gi);
+            r.id = gld<COH>(P.i32[I_ID] + gi);            // (FIN only, for a vehicle that moves)
         }
     }
 

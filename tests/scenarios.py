@@ -569,7 +569,7 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
 
 
 def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chunks=(1, 7, 40, 3, 60), rate=None,
-                        trajectory_chunk=12, quantize=None, source="pool"):
+                        trajectory_chunk=12, quantize=None, source="pool", persistent=False):
     """pve_step_many for the 4- / 8-lane layouts (k_rollout_geo: the general-geometry tick resident on the chip) == single
     pve_step_all ticks of k_tick_geo, bit for bit: persistent state, headers (incl. the spawn counter intention_re and
     the stale list heads), observation rows, last-tick outputs and, in trajectory mode, every tick's outputs."""
@@ -624,12 +624,12 @@ def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chun
     for n in chunks:
         for _ in range(n):
             o1 = single()
-        o2 = many.step_many(n, source=source, chunk=(0 if n < 6 else (n // 3 + 1)))
+        o2 = many.step_many(n, source=source, chunk=(0 if n < 6 else (n // 3 + 1)), persistent=persistent)
         one.synchronize(); many.synchronize()
         batches_equal(one, many, "lane_num %d, chunk of %d" % (lane_num, n))
         same_outputs(o1, o2, "lane_num %d, chunk of %d" % (lane_num, n))
         same_headers("lane_num %d, chunk of %d" % (lane_num, n))
-    traj = many.step_many(trajectory_chunk, source=source, trajectory=True, chunk=trajectory_chunk // 2 + 1)
+    traj = many.step_many(trajectory_chunk, source=source, trajectory=True, chunk=trajectory_chunk // 2 + 1, persistent=persistent)
     for k in range(trajectory_chunk):
         o1 = single()
         same_outputs(o1, {n: traj[n][k] for n in traj}, "trajectory tick %d" % k)

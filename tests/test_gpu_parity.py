@@ -413,6 +413,13 @@ def test_gpu_persistent_step_many_equals_single_ticks(cap, n_envs, chunks, rate)
                               persistent=True, seed=7, trajectory_chunk=24)
 
 
+@pytest.mark.parametrize("lane_num,cap,n_envs,quant", [(8, 128, 300, None), (4, 64, 600, 1.0), (4, 128, 40, None), (8, 64, 9, 1.0)])
+def test_gpu_persistent_step_many_geo_equals_single_ticks(lane_num, cap, n_envs, quant):
+    """The persistent work-queue launch of the general-geometry kernel (k_rollout_geo<.., PERS>) == k_tick_geo ticks."""
+    scenarios.check_step_many_geo(BACKEND, lane_num, n_envs=n_envs, capacity=cap, quantize=quant, persistent=True, chunks=(1, 7, 40, 25),
+                                  trajectory_chunk=16)
+
+
 def test_gpu_two_persistent_launches_share_the_chip():
     """Two handles, each with its own persistent launch on its own stream (2 x 2048 envs, 2 x 2048 workgroups: twice what the
     chip holds at once, so workgroups of both launches wait for slots while others spin on their hand-offs), and a batch of
