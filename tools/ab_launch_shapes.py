@@ -35,6 +35,8 @@ variants = [("2 streams, launches of 5", two, dict(chunk=5), None),
             ("persistent 6,6,5 + 3", one, dict(chunk=6, persistent=True), "3"),
             ("persistent 8,7 + 3,2", one, dict(chunk=8, persistent=True), "3,2"),
             ("persistent 6,6,6 + 2", one, dict(chunk=6, persistent=True), "2"),
+            ("persistent 9,8 + 3", one, dict(chunk=9, persistent=True), "3"),
+            ("persistent 6,6,4 + 4", one, dict(chunk=6, persistent=True), "4"),
             ("one launch of 4096 x 20", one, dict(chunk=0), None)]
 calls = {}
 
