@@ -404,8 +404,8 @@ def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=
     """Default launch shape of a roll-out of K ticks: (sub-batches, ticks per launch or queue item, persistent).
     Measured on MI355X with 4096 envs (tools/ab_launch_shapes.py, same process, medians):
       12 lanes x 128 slots, pool / zero actions: ONE batch and ONE persistent launch per call whose workgroups pull
-        (intersection, <= T ticks) items from a queue -- 618 us for 20 ticks (T = 6) against 671 us for two stream-pipelined
-        sub-batches in launches of 5; 26.4 against 27.5 us per tick in a 1000-tick region (T = 10 / launches of 25);
+        (intersection, <= 10 ticks) items from a queue -- 621 us for 20 ticks (items of 9, 8, 3; 6, 6, 5, 3: 627) against 669 us for two
+        stream-pipelined sub-batches in launches of 5; 26.4 against 27.5 us per tick in a 1000-tick region (launches of 25);
       12 lanes x 64 slots: every intersection is resident at once (16 one-wave workgroups per CU): ONE launch of all of them
         for the whole call (323 against 341 us for 20 ticks with two sub-batches; 13.7 us per tick in a 1000-tick region, the
         queue with T = 10: 13.6);
@@ -414,7 +414,7 @@ def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=
         gives the queue nothing to balance)."""
     if lane_num == 12 and not actor and n_envs >= 4096:     # (the queue balances a batch of >= 2x the workgroups the chip holds)
         if cap == 128:
-            return 1, (10 if K >= 100 else 6), True
+            return 1, 10, True           # (a 20-tick call becomes items of 9, 8 and 3 ticks)
         return 1, 0, False
     if lane_num == 12 and actor and cap == 128 and n_envs >= 4096 and K >= 100:
         return 1, 25, True          # closed loop, long call: 34.6 against 35.9 us per tick; 20 ticks: 42.9 against 43.2 (no gain: 2 streams)

@@ -657,25 +657,15 @@ template <int CAP> struct TickGeo {
                         for (int k = 0; k < NNB; k++) dk[k] = r.kr[k] >= 0 ? fabs(r.kv[k] - me) : INFINITY;
                         have_dk = true;
                     }
-                    // insertion from the BACK with a wave-level early exit: an opposing entry usually enters near the end of the six,
-                    // so one or two places move instead of a six-place chain for every lane of the wave.  Equal distances (the
-                    // stable sort would need list positions) are met exactly where the entry stops.
-                    bool active = cd < dk[NNB - 1];
-                    amb = amb | (cd == dk[NNB - 1]);
+                    bool ins = false;
 #pragma unroll
-                    for (int k = NNB - 1; k >= 0; k--) {
-#if PVE_DEVICE_CODE
-                        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-#else
-                        if (!active) break;
-#endif
-                        const double pd = k > 0 ? dk[k > 0 ? k - 1 : 0] : -INFINITY;
-                        const bool further = active & (cd < pd);                  // belongs in front of place k - 1 as well
-                        amb = amb | (active & (cd == pd));
-                        const double nd = further ? pd : cd, nv = further ? r.kv[k > 0 ? k - 1 : 0] : cv;
-                        const int ns = further ? r.kr[k > 0 ? k - 1 : 0] : cs;
-                        dk[k] = active ? nd : dk[k]; r.kv[k] = active ? nv : r.kv[k]; r.kr[k] = active ? ns : r.kr[k];
-                        active = further;
+                    for (int k = 0; k < NNB; k++) {
+                        amb = amb | (cd == dk[k]);
+                        const bool sw = ins | (cd < dk[k]);
+                        ins = sw;
+                        const double td = sw ? dk[k] : cd, tv = sw ? r.kv[k] : cv; const int ts = sw ? r.kr[k] : cs;
+                        dk[k] = sw ? cd : dk[k]; r.kv[k] = sw ? cv : r.kv[k]; r.kr[k] = sw ? cs : r.kr[k];
+                        cd = td; cv = tv; cs = ts;
                     }
                     d5 = dk[NNB - 1];
                 }
