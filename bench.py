@@ -409,15 +409,15 @@ def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=
       12 lanes x 64 slots: every intersection is resident at once (16 one-wave workgroups per CU): ONE launch of all of them
         for the whole call (323 against 341 us for 20 ticks with two sub-batches; 13.7 us per tick in a 1000-tick region, the
         queue with T = 10: 13.6);
-      closed loop and 4 / 8 lanes x 128 slots: the queue for long calls only (34.6 vs 35.9, 37.0 vs 38.2, 36.5 vs 41.7 us per tick;
-        no gain for 20 ticks); small batches: two stream-pipelined sub-batches (a batch below twice the chip's resident workgroups
+      closed loop: the queue (34.6 vs 35.9 us per tick in a long call, 41.7 vs 43.6 for 20 ticks); 4 / 8 lanes x 128 slots: the queue
+        for long calls only (37.0 vs 38.2, 36.5 vs 41.7 us per tick; no gain for 20 ticks); small batches: two stream-pipelined sub-batches (a batch below twice the chip's resident workgroups
         gives the queue nothing to balance)."""
     if lane_num == 12 and not actor and n_envs >= 4096:     # (the queue balances a batch of >= 2x the workgroups the chip holds)
         if cap == 128:
             return 1, 10, True           # (a 20-tick call becomes items of 9, 8 and 3 ticks)
         return 1, 0, False
-    if lane_num == 12 and actor and cap == 128 and n_envs >= 4096 and K >= 100:
-        return 1, 25, True          # closed loop, long call: 34.6 against 35.9 us per tick; 20 ticks: 42.9 against 43.2 (no gain: 2 streams)
+    if lane_num == 12 and actor and cap == 128 and n_envs >= 4096:
+        return 1, (25 if K >= 100 else 10), True     # closed loop: 34.6 against 35.9 us per tick (long call), 41.7 against 43.6 (20 ticks)
     if lane_num != 12 and cap == 128 and not actor and not table and n_envs >= 4096 and K >= 100:
         return 1, 10, True          # 8 lanes: 37.0 against 38.2 us per tick, 4 lanes x 128: 36.5 against 41.7; 20 ticks: no gain (2 streams)
     return 2, ((25 if K >= 100 else 5) if cap == 128 else 0), False
