@@ -250,6 +250,30 @@ PVE_HD void block_sum_sparse(double *red, int t, bool has, double x)
     block_sum(red, t, has ? x : 0.0);
 }
 
+// min / max of two finite doubles as ONE instruction each (v_min_f64 / v_max_f64; the host build: fmin / fmax).  Equal to
+// the compare-and-select forms they replace for everything but NaN operands (never produced here) and the sign of a zero
+// result when both operands are zeros of different sign (the bounds are am / aM / vm / vM / +-20; -0.0 is never produced)
+#ifdef PVE_SELECT_CLAMPS                           // A/B build knob: the compare-and-select forms
+PVE_HD double dmax(double a, double b) { return (a > b) ? a : b; }
+PVE_HD double dmin(double a, double b) { return (a < b) ? a : b; }
+#else
+PVE_HD double dmax(double a, double b) { return __builtin_fmax(a, b); }
+PVE_HD double dmin(double a, double b) { return __builtin_fmin(a, b); }
+#endif
+
+// Element `idx` of intersection `env`'s block of PER elements in a per-tick output array: a UNIFORM 64-bit base (scalar
+// arithmetic) plus a 32-bit lane offset, which is the address form a global store takes as it is (`saddr` + `voffset`); the
+// plain `base[(size_t)env * PER + idx]` is a 64-bit multiply-add per lane and store (quarter-rate v_mad_u64_u32 / two-pass
+// v_lshl_add_u64: 24 of them in FIN).  idx is a slot or a slot-derived index (< 2^22).
+#ifdef PVE_WIDE_INDEX                              // A/B build knob: the plain 64-bit form
+template <int PER, class T> PVE_HD T *env_at(T *base, int env, int idx) { return base + ((size_t)env * PER + (size_t)idx); }
+#else
+template <int PER, class T> PVE_HD T *env_at(T *base, int env, int idx)
+{   // (the byte offset is formed in 32 bits: idx < 2^22 elements of <= 8 bytes)
+    return (T *)((char *)(base + (size_t)env * PER) + (unsigned)(idx * (int)sizeof(T)));
+}
+#endif
+
 // ------------------------------------------------------------------ shared (LDS) block of one env
 template <int CAP, bool LJ = (CAP == 128)> struct Shared {
     static constexpr int NW = CAP / 64;
@@ -489,13 +513,23 @@ PVE_HD void get_xy(const PVE_AS4 Const &c, double p, int lane, double &X, double
 }
 
 // single-precision position for the collision PRE-FILTER only (never for a decision): |error| < 1e-3 m
+// 1 / x to ~1 ulp in ONE instruction (v_rcp_f32) for the single-precision pre-filters, which never decide anything (an IEEE
+// float division is ten instructions)
+PVE_HD float frcp(float x)
+{
+#if PVE_DEVICE_CODE
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
 PVE_HD void get_xy_f32(const PVE_AS4 Const &c, double pd, int lane, float &X, float &Y)
 {
     const float cw = (float)c.cw, p = (float)pd;
     const int m = lane % 3;
     const float Lb = (float)sel2(c.inbox[0], c.inbox[2], m == 2);
     const bool before = p > Lb, inside = !before && p > 0.f;
-    float ra = (m != 1 && inside) ? ((Lb - p) / Lb * 1.5707965f) : 0.f;     // 3.141593 / 2
+    float ra = (m != 1 && inside) ? ((Lb - p) * (1.5707965f * frcp(Lb))) : 0.f;     // (Lb - p) / Lb * 3.141593 / 2 (pre-filter: no exact division)
     const bool fold = ra > 0.78539816f;
     const float y0 = fold ? (1.5707964f - ra) : ra, z = y0 * y0;
     const float s1 = y0 + y0 * z * (-1.6666667e-1f + z * (8.3333338e-3f + z * (-1.9841270e-4f + z * 2.7557319e-6f)));
@@ -638,13 +672,13 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (t < 64 || t < N) {
             // what S1 - S3 need comes first; the fields that are merely carried to FIN (or first read in WALK) are requested
             // behind them and arrive under the step phases (the kernel's barriers do not wait for global loads)
-            if (acts) r.act = gld<COHA>(acts + g);        // with the state loads: one latency, not a second one in S1
-            r.p = gld<COH>(P.f64[F_P] + g); r.v = gld<COH>(P.f64[F_V] + g); r.a = gld<COH>(P.f64[F_A] + g);
-            r.meta = gld<COH>(P.i32[I_META] + g); r.step = gld<COH>(P.i32[I_STEP] + g);
-            r.jerk_sum = gld<COH>(P.f64[F_JERK_SUM] + g); r.vir_dis = gld<COH>(P.f64[F_VIR_DIS] + g);
-            r.closer_p = gld<COH>(P.f64[F_CLOSER_P] + g);
-            r.id = gld<COH>(P.i32[I_ID] + g); r.seq = gld<COH>(P.i32[I_SEQ] + g); r.vnum = gld<COH>(P.i32[I_VNUM] + g);
-            r.count = gld<COH>(P.i32[I_COUNT] + g);
+            if (acts) r.act = gld<COHA>(env_at<CAP>(acts, env, t));        // with the state loads: one latency, not a second one in S1
+            r.p = gld<COH>(env_at<CAP>(P.f64[F_P], env, t)); r.v = gld<COH>(env_at<CAP>(P.f64[F_V], env, t)); r.a = gld<COH>(env_at<CAP>(P.f64[F_A], env, t));
+            r.meta = gld<COH>(env_at<CAP>(P.i32[I_META], env, t)); r.step = gld<COH>(env_at<CAP>(P.i32[I_STEP], env, t));
+            r.jerk_sum = gld<COH>(env_at<CAP>(P.f64[F_JERK_SUM], env, t)); r.vir_dis = gld<COH>(env_at<CAP>(P.f64[F_VIR_DIS], env, t));
+            r.closer_p = gld<COH>(env_at<CAP>(P.f64[F_CLOSER_P], env, t));
+            r.id = gld<COH>(env_at<CAP>(P.i32[I_ID], env, t)); r.seq = gld<COH>(env_at<CAP>(P.i32[I_SEQ], env, t)); r.vnum = gld<COH>(env_at<CAP>(P.i32[I_VNUM], env, t));
+            r.count = gld<COH>(env_at<CAP>(P.i32[I_COUNT], env, t));
         }
         sh.cnt[t] = 0;                                    // (rew_ovr / hdr share storage with S2-S3 arrays: BUILD)
         if (t == 0) {
@@ -667,15 +701,13 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void outcome(const PVE_AS4 Const &c, double p, double v, double a, bool ctl, double &pn, double &vn)
     {   // ref :1528-1535
         pn = p - v * c.deltaT - 0.5 * a * c.dt2;
-        double x = v + a * c.deltaT;
-        x = (c.vm > x) ? c.vm : x;
-        vn = (x < c.vM) ? x : c.vM;
+        const double x = v + a * c.deltaT;
+        vn = dmin(dmax(c.vm, x), c.vM);                  // (v_max_f64 / v_min_f64: a compare + two selects each otherwise)
         if (!ctl) vn = c.v0;
     }
     static PVE_HD double clip_a(const PVE_AS4 Const &c, double x)
     {   // min(aM, max(am, x)), ref :1502, 1521
-        double y = (x > c.am) ? x : c.am;
-        return (c.aM < y) ? c.aM : y;
+        return dmin(c.aM, dmax(x, c.am));
     }
     static PVE_HD void ph_step1(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
@@ -1169,8 +1201,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             r_ += reward_log_term(q2 * q2 * q1 + 0.00001);
         }
         r_ += (myv - c.vm) * c.inv_span * 2.0;
-        r_ = (r_ > -20) ? r_ : -20;
-        r.reward = (r_ < 20) ? r_ : 20;
+        r.reward = dmin(dmax(r_, -20.0), 20.0);
         // ref :322-334
         // pre-filter in single precision: the exact FP64 positions (two divisions + polynomials each) are only
         // evaluated when the pair is within 5 cm of the threshold band -- the decision itself is always FP64
@@ -1375,17 +1406,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // cannot have changed: with_ids = false skips the immutable fields (id, seq_in_lane, id_info[1]); with_carry = false
     // (it was not controlled this tick either) also skips jerk_sum / vir_dis / closer_p / count, which only the
     // controlled branch of scene_update touches (ref :292, :302, :321, :1348-1354).
-    template <class R> static PVE_HD void store_slot(const PVE_AS4 Params &P, size_t g, const R &r, int meta, int hdr_word,
+    template <class R> static PVE_HD void store_slot(const PVE_AS4 Params &P, int env, int slot, const R &r, int meta, int hdr_word,
                                                      bool with_ids = true, bool with_carry = true)
     {
-        P.f64[F_P][g] = r.p; P.f64[F_V][g] = r.v; P.f64[F_A][g] = r.a; P.f64[F_JERK][g] = r.jerk;
+        *env_at<CAP>(P.f64[F_P], env, slot) = r.p; *env_at<CAP>(P.f64[F_V], env, slot) = r.v; *env_at<CAP>(P.f64[F_A], env, slot) = r.a; *env_at<CAP>(P.f64[F_JERK], env, slot) = r.jerk;
         if (with_carry) {
-            P.f64[F_JERK_SUM][g] = r.jerk_sum; P.f64[F_VIR_DIS][g] = r.vir_dis; P.f64[F_CLOSER_P][g] = r.closer_p;
-            P.i32[I_COUNT][g] = r.count;
+            *env_at<CAP>(P.f64[F_JERK_SUM], env, slot) = r.jerk_sum; *env_at<CAP>(P.f64[F_VIR_DIS], env, slot) = r.vir_dis; *env_at<CAP>(P.f64[F_CLOSER_P], env, slot) = r.closer_p;
+            *env_at<CAP>(P.i32[I_COUNT], env, slot) = r.count;
         }
-        if (with_ids) { P.i32[I_ID][g] = r.id; P.i32[I_SEQ][g] = r.seq; P.i32[I_VNUM][g] = r.vnum; }
-        P.i32[I_STEP][g] = r.step; P.i32[I_META][g] = meta;
-        P.i32[I_HDR][g] = hdr_word;
+        if (with_ids) { *env_at<CAP>(P.i32[I_ID], env, slot) = r.id; *env_at<CAP>(P.i32[I_SEQ], env, slot) = r.seq; *env_at<CAP>(P.i32[I_VNUM], env, slot) = r.vnum; }
+        *env_at<CAP>(P.i32[I_STEP], env, slot) = r.step; *env_at<CAP>(P.i32[I_META], env, slot) = meta;
+        *env_at<CAP>(P.i32[I_HDR], env, slot) = hdr_word;
     }
     static PVE_HD int pack_lanej(const Sh &sh, int slot)
     {
@@ -1460,7 +1491,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             if (mask_test(keep, t)) {
                 new_slot = mask_rank<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
                 if (!RES)
-                    store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
+                    store_slot(P, env, new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
                 else if (!still) {         // EARLY staging: these registers die here, as in the single-tick kernel
                     const int s = new_slot;
                     sh.template stf<Sh::SF_JERK>()[s] = r.jerk; sh.template stf<Sh::SF_JERK_SUM>()[s] = r.jerk_sum;
@@ -1498,8 +1529,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 nv.seq = sh.hd.veh_rec[t];
                 nv.vnum = nvnum;
                 nv.step = 0; nv.count = 0;
-                size_t gs = (size_t)env * CAP + slot;
-                store_slot(P, gs, nv, M_CONTROL | M_ALIVE | (t << M_LANE_SHIFT), -1);
+                store_slot(P, env, slot, nv, M_CONTROL | M_ALIVE | (t << M_LANE_SHIFT), -1);
                 const int rec1 = sh.hd.veh_rec[t] + 1;
                 gh.veh_rec[t] = rec1;
                 gh.next_arr[t] = r.next_arr;
@@ -1512,8 +1542,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 const int l = __builtin_ctz(rem);
                 const int slot = mask_below<NW>(keep, sh.hd.lane_start[l + 1]) + __builtin_popcount(sp & ((1u << l) - 1u));
                 if (t < OBSW) {
-                    if (P.obs_f32) ((float *)O.obs_post)[((size_t)env * CAP + slot) * OBSW + t] = 0.0f;
-                    else O.obs_post[((size_t)env * CAP + slot) * OBSW + t] = 0.0;
+                    if (P.obs_f32) *env_at<CAP * OBSW>((float *)O.obs_post, env, slot * OBSW + t) = 0.0f;
+                    else *env_at<CAP * OBSW>(O.obs_post, env, slot * OBSW + t) = 0.0;
                 }
             }
         }
@@ -1564,21 +1594,20 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 f = 0x01 | (r.ctl ? 0x02 : 0) | ((r.meta & M_DONE) ? 0x04 : 0) | (r.del ? 0x08 : 0) |
                     (r.fin ? 0x10 : 0) | (lockf ? 0x20 : 0) | (r.ctl ? (r.coll_seen << 8) : 0);
             }
-            O.flags[gpre] = f;
+            *env_at<CAP>(O.flags, env, t) = f;
         }
         // per-slot outputs other than `flags` are written for the slots that held a vehicle only (`flags` = 0 marks
         // the rest): 36 B x ~43 empty slots per env are 6 MB per launch, i.e. ~0.8 us of store burst
-        if (O.reward && r.alive && !r.ctl) O.reward[gpre] = 0.0;
-        if (O.lanej && r.alive) O.lanej[gpre] = (r.lane << 16) | r.j;
-        if (O.new_slot && r.alive) O.new_slot[gpre] = new_slot;
+        if (O.reward && r.alive && !r.ctl) *env_at<CAP>(O.reward, env, t) = 0.0;
+        if (O.lanej && r.alive) *env_at<CAP>(O.lanej, env, t) = (r.lane << 16) | r.j;
+        if (O.new_slot && r.alive) *env_at<CAP>(O.new_slot, env, t) = new_slot;
         // ---- dense mapping: what the t-th controlled vehicle (slot ds) puts out
         if (r.dctl) {
             const int sl = r.ds;
-            const size_t gd = (size_t)env * CAP + sl;                 // pre-compaction indexing, as above
             int ns = -1;
             if (mask_test(keep, sl))
                 ns = (RES ? (int)sh.keep_pre()[sl] : mask_below<NW>(keep, sl)) + __builtin_popcount(sp & ((1u << r.dlane) - 1u));
-            if (O.reward) O.reward[gd] = r.reward;
+            if (O.reward) *env_at<CAP>(O.reward, env, sl) = r.reward;      // pre-compaction indexing, as above
             if (adst) *adst = ns;
             // the 6 neighbours' speed, acceleration, lane and lane start: two batches of unconditional LDS gathers on clamped
             // slots (one guarded block per neighbour = six serial round trips), shared by the neighbour ids and the row
@@ -1600,7 +1629,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 for (int k = 0; k < NNB; k++) nln[k] = nlj[k] >> 16;
             }
             if (O.nbr) {                               // controlled vehicles only (PVE_F_CTL in flags)
-                int *nb = O.nbr + gd * NNB;
+                int *nb = env_at<CAP * NNB>(O.nbr, env, sl * NNB);
 #pragma unroll
                 for (int k = 0; k < NNB; k++) nb[k] = r.kr[k] < 0 ? -1 : nlj[k];
             }
@@ -1619,22 +1648,22 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 }
                 if (O.obs_pre) {
                     if (P.obs_f32) {                    // (12-lane kernels: obs_pre / state_pre follow the row type)
-                        float *o = (float *)O.obs_pre + gd * OBSW;
+                        float *o = env_at<CAP * OBSW>((float *)O.obs_pre, env, sl * OBSW);
 #pragma unroll
                         for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
                     } else {
-                        double *o = O.obs_pre + gd * OBSW;
+                        double *o = env_at<CAP * OBSW>(O.obs_pre, env, sl * OBSW);
 #pragma unroll
                         for (int k = 0; k < OBSW; k++) o[k] = row[k];
                     }
                 }
                 if (O.obs_post && ns >= 0) {
                     if (P.obs_f32) {                    // uniform: float32 rows (half the bytes of the largest output)
-                        float *o = (float *)O.obs_post + ((size_t)env * CAP + ns) * OBSW;
+                        float *o = env_at<CAP * OBSW>((float *)O.obs_post, env, ns * OBSW);
 #pragma unroll
                         for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
                     } else {
-                        double *o = O.obs_post + ((size_t)env * CAP + ns) * OBSW;
+                        double *o = env_at<CAP * OBSW>(O.obs_post, env, ns * OBSW);
 #pragma unroll
                         for (int k = 0; k < OBSW; k++) o[k] = row[k];
                     }
@@ -1687,7 +1716,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     {
         r.act_nx = 0;
         if (R.source == 1 /* PVE_SRC_POOL */ && pool_idx >= 0)
-            r.act_nx = R.pool[((size_t)pool_idx * P.n_envs + env) * CAP + t];
+            r.act_nx = *env_at<CAP>(R.pool + (size_t)pool_idx * P.n_envs * CAP, env, t);
     }
     static PVE_HD void ph_park_action(int t, Sh &sh, Regs &r) { sh.act_next[t] = r.act_nx; }   // xy32 is dead after REWARD
     // STAGE (after barrier A: nobody reads this tick's work arrays any more): every kept vehicle moves to its new slot,
@@ -1766,17 +1795,16 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_flush(const PVE_AS4 Params &P, int env, int t, Sh &sh)
     {
         const int N = sh.hd.n_alive;
-        const size_t g = (size_t)env * CAP + t;
         if (t < N) {
-            P.f64[F_P][g] = sh.template stf<Sh::SF_P>()[t]; P.f64[F_V][g] = sh.template stf<Sh::SF_V>()[t];
-            P.f64[F_A][g] = sh.template stf<Sh::SF_A>()[t]; P.f64[F_JERK][g] = sh.template stf<Sh::SF_JERK>()[t];
-            P.f64[F_JERK_SUM][g] = sh.template stf<Sh::SF_JERK_SUM>()[t]; P.f64[F_VIR_DIS][g] = sh.template stf<Sh::SF_VIR_DIS>()[t];
-            P.f64[F_CLOSER_P][g] = sh.template stf<Sh::SF_CLOSER_P>()[t];
-            P.i32[I_ID][g] = sh.template sti<I_ID>()[t]; P.i32[I_SEQ][g] = sh.template sti<I_SEQ>()[t];
-            P.i32[I_VNUM][g] = sh.template sti<I_VNUM>()[t]; P.i32[I_STEP][g] = sh.template sti<I_STEP>()[t];
-            P.i32[I_COUNT][g] = sh.template sti<I_COUNT>()[t]; P.i32[I_META][g] = sh.template sti<I_META>()[t];
-            P.i32[I_HDR][g] = sh.template sti<I_HDR>()[t];
-        } else { P.i32[I_META][g] = 0; P.i32[I_ID][g] = -1; }                     // stale slots never look alive
+            *env_at<CAP>(P.f64[F_P], env, t) = sh.template stf<Sh::SF_P>()[t]; *env_at<CAP>(P.f64[F_V], env, t) = sh.template stf<Sh::SF_V>()[t];
+            *env_at<CAP>(P.f64[F_A], env, t) = sh.template stf<Sh::SF_A>()[t]; *env_at<CAP>(P.f64[F_JERK], env, t) = sh.template stf<Sh::SF_JERK>()[t];
+            *env_at<CAP>(P.f64[F_JERK_SUM], env, t) = sh.template stf<Sh::SF_JERK_SUM>()[t]; *env_at<CAP>(P.f64[F_VIR_DIS], env, t) = sh.template stf<Sh::SF_VIR_DIS>()[t];
+            *env_at<CAP>(P.f64[F_CLOSER_P], env, t) = sh.template stf<Sh::SF_CLOSER_P>()[t];
+            *env_at<CAP>(P.i32[I_ID], env, t) = sh.template sti<I_ID>()[t]; *env_at<CAP>(P.i32[I_SEQ], env, t) = sh.template sti<I_SEQ>()[t];
+            *env_at<CAP>(P.i32[I_VNUM], env, t) = sh.template sti<I_VNUM>()[t]; *env_at<CAP>(P.i32[I_STEP], env, t) = sh.template sti<I_STEP>()[t];
+            *env_at<CAP>(P.i32[I_COUNT], env, t) = sh.template sti<I_COUNT>()[t]; *env_at<CAP>(P.i32[I_META], env, t) = sh.template sti<I_META>()[t];
+            *env_at<CAP>(P.i32[I_HDR], env, t) = sh.template sti<I_HDR>()[t];
+        } else { *env_at<CAP>(P.i32[I_META], env, t) = 0; *env_at<CAP>(P.i32[I_ID], env, t) = -1; }                     // stale slots never look alive
         int *dst = (int *)&P.headers[env];
         const int *src = (const int *)&sh.hd;
         for (int w = t; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];
@@ -1846,7 +1874,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             int ns = mask_below<NW>(sh.m_keep, t);
             size_t g = (size_t)env * CAP + ns;
             if (ns != t) {                            // a vehicle that keeps its slot keeps everything
-                store_slot(P, g, r, r.meta, r.hdr_word);
+                store_slot(P, env, ns, r, r.meta, r.hdr_word);
                 if (P.out.obs_post) {
                     double *o = P.out.obs_post + g * OBSW;
                     for (int k = 0; k < OBSW; k++) o[k] = r.obsrow[k];

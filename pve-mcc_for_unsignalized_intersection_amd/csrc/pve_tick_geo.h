@@ -136,7 +136,7 @@ PVE_HD void geo_xy_f32(const PVE_AS4 GeoConst &g, double pd, int lane, int m, fl
     const float Lb = (float)sel2(g.base.inbox[0], g.base.inbox[2], m == 2);
     const float rl = (float)g.RL;
     const bool before = p > Lb, inside = !before && p > 0.f;
-    const float ra = (inside && m != 1) ? ((m == 0) ? p / (rl * cw) : p / cw) : 0.f;
+    const float ra = (inside && m != 1) ? p * frcp((m == 0) ? rl * cw : cw) : 0.f;
     const bool fold = ra > 0.78539816f;
     const float y0 = fold ? (1.5707964f - ra) : ra, z = y0 * y0;
     const float s1 = y0 + y0 * z * (-1.6666667e-1f + z * (8.3333338e-3f + z * (-1.9841270e-4f + z * 2.7557319e-6f)));
@@ -194,9 +194,9 @@ template <int CAP> struct TickGeo {
         const double *acts = use_act0 ? act0 : P.actions;
         if (t < 64 || t < N) {                    // first wave unconditionally (no dependence on n_alive), later waves live slots only
             if (acts) r.act = acts[gi];
-            r.p = gld<COH>(P.f64[F_P] + gi); r.v = gld<COH>(P.f64[F_V] + gi); r.a = gld<COH>(P.f64[F_A] + gi);
-            r.meta = gld<COH>(P.i32[I_META] + gi); r.step = gld<COH>(P.i32[I_STEP] + gi);
-            r.seq = gld<COH>(P.i32[I_SEQ] + gi); r.vnum = gld<COH>(P.i32[I_VNUM] + gi); r.count = gld<COH>(P.i32[I_COUNT] + gi);
+            r.p = gld<COH>(env_at<CAP>(P.f64[F_P], env, t)); r.v = gld<COH>(env_at<CAP>(P.f64[F_V], env, t)); r.a = gld<COH>(env_at<CAP>(P.f64[F_A], env, t));
+            r.meta = gld<COH>(env_at<CAP>(P.i32[I_META], env, t)); r.step = gld<COH>(env_at<CAP>(P.i32[I_STEP], env, t));
+            r.seq = gld<COH>(env_at<CAP>(P.i32[I_SEQ], env, t)); r.vnum = gld<COH>(env_at<CAP>(P.i32[I_VNUM], env, t)); r.count = gld<COH>(env_at<CAP>(P.i32[I_COUNT], env, t));
         }
         sh.cnt[t] = 0; sh.rew_ovr[t] = 0; sh.hdr[t] = -1;
         if (t == 0) {
@@ -214,9 +214,9 @@ template <int CAP> struct TickGeo {
     {
         if (t < 64 || t < sh.hd.n_alive) {
             const size_t gi = (size_t)env * CAP + t;
-            r.jerk_sum = gld<COH>(P.f64[F_JERK_SUM] + gi); r.closer_p = gld<COH>(P.f64[F_CLOSER_P] + gi);
-            r.vir_dis = gld<COH>(P.f64[F_VIR_DIS] + gi);
-            r.id = gld<COH>(P.i32[I_ID] + gi);            // (FIN only, for a vehicle that moves)
+            r.jerk_sum = gld<COH>(env_at<CAP>(P.f64[F_JERK_SUM], env, t)); r.closer_p = gld<COH>(env_at<CAP>(P.f64[F_CLOSER_P], env, t));
+            r.vir_dis = gld<COH>(env_at<CAP>(P.f64[F_VIR_DIS], env, t));
+            r.id = gld<COH>(env_at<CAP>(P.i32[I_ID], env, t));            // (FIN only, for a vehicle that moves)
         }
     }
 
@@ -742,8 +742,7 @@ template <int CAP> struct TickGeo {
             r_ += reward_log_term(q2 * q2 * q1 + 0.00001);
         }
         r_ += (r.v - c.vm) * c.inv_span * 2.0;
-        r_ = (r_ > -20) ? r_ : -20;
-        r.reward = (r_ < 20) ? r_ : 20;
+        r.reward = dmin(dmax(r_, -20.0), 20.0);
         r.jerk_sum += fabs(jd);
         // pre-filter in single precision: the exact FP64 positions (divisions + polynomials) are only evaluated when the
         // pair is within 5 cm of the threshold band -- the decision itself is always FP64
@@ -859,7 +858,7 @@ template <int CAP> struct TickGeo {
             hdr_word = pack_lanej(sh, r.hdr);
             if (mask_test(keep, t)) {
                 new_slot = mask_below<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
-                if (!RES) Base::store_slot(P, (size_t)env * CAP + new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
+                if (!RES) Base::store_slot(P, env, new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
                 else if (!still) {         // EARLY staging (these registers die here)
                     const int s = new_slot;
                     sh.template stf<Sh::SF_JERK>()[s] = r.jerk; sh.template stf<Sh::SF_JERK_SUM>()[s] = r.jerk_sum;
@@ -898,7 +897,7 @@ template <int CAP> struct TickGeo {
                 nv.seq = sh.hd.veh_rec[t];
                 nv.vnum = sh.hd.lane_start[t + 1] - sh.hd.lane_start[t];
                 nv.step = 0; nv.count = 0;
-                Base::store_slot(P, (size_t)env * CAP + slot, nv,
+                Base::store_slot(P, env, slot, nv,
                                  M_CONTROL | M_ALIVE | (t << M_LANE_SHIFT) | (LN == 12 ? 0 : (intention << M_INT_SHIFT)), -1);   // 12-lane: lane % 3, not stored
             }
             if (O.obs_post) {                                                          // ref :380, :420
@@ -956,11 +955,11 @@ template <int CAP> struct TickGeo {
                 f = 0x01 | (r.ctl ? 0x02 : 0) | ((r.meta & M_DONE) ? 0x04 : 0) | (r.del ? 0x08 : 0) |
                     (r.fin ? 0x10 : 0) | (lockf ? 0x20 : 0) | (r.intent << 6) | (r.ctl ? (r.coll_seen << 8) : 0);
             }
-            O.flags[gpre] = f;
+            *env_at<CAP>(O.flags, env, t) = f;
         }
-        if (O.reward && r.alive) O.reward[gpre] = r.ctl ? r.reward : 0.0;
-        if (O.lanej && r.alive) O.lanej[gpre] = (r.lane << 16) | r.j;
-        if (O.new_slot && r.alive) O.new_slot[gpre] = new_slot;
+        if (O.reward && r.alive) *env_at<CAP>(O.reward, env, t) = r.ctl ? r.reward : 0.0;
+        if (O.lanej && r.alive) *env_at<CAP>(O.lanej, env, t) = (r.lane << 16) | r.j;
+        if (O.new_slot && r.alive) *env_at<CAP>(O.new_slot, env, t) = new_slot;
         if (r.alive && r.ctl && (O.nbr || O.obs_pre || (O.obs_post && new_slot >= 0))) {
             // the 6 neighbours' speed, acceleration, lane and route, then their lane starts: two batches of unconditional LDS
             // gathers on clamped slots (a guarded block per neighbour is a chain of six round trips), shared by the ids and the row
@@ -979,7 +978,7 @@ template <int CAP> struct TickGeo {
 #pragma unroll
             for (int k = 0; k < NNB; k++) PVE_PIN(nls[k]);
             if (O.nbr) {                               // controlled vehicles only (PVE_F_CTL in flags)
-                int *nb = O.nbr + gpre * NNB;
+                int *nb = env_at<CAP * NNB>(O.nbr, env, t * NNB);
 #pragma unroll
                 for (int k = 0; k < NNB; k++) nb[k] = r.kr[k] < 0 ? -1 : ((nln[k] << 16) | (xc[k] - nls[k]));
             }
@@ -995,22 +994,22 @@ template <int CAP> struct TickGeo {
             }
             if (O.obs_pre) {
                 if (P.obs_f32) {                        // (obs_pre / state_pre follow the row type, as in the 12-lane kernels)
-                    float *o = (float *)O.obs_pre + gpre * OBSW;
+                    float *o = env_at<CAP * OBSW>((float *)O.obs_pre, env, t * OBSW);
 #pragma unroll
                     for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
                 } else {
-                    double *o = O.obs_pre + gpre * OBSW;
+                    double *o = env_at<CAP * OBSW>(O.obs_pre, env, t * OBSW);
 #pragma unroll
                     for (int k = 0; k < OBSW; k++) o[k] = row[k];
                 }
             }
             if (O.obs_post && new_slot >= 0) {
                 if (P.obs_f32) {
-                    float *o = (float *)O.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+                    float *o = env_at<CAP * OBSW>((float *)O.obs_post, env, new_slot * OBSW);
 #pragma unroll
                     for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
                 } else {
-                    double *o = O.obs_post + ((size_t)env * CAP + new_slot) * OBSW;
+                    double *o = env_at<CAP * OBSW>(O.obs_post, env, new_slot * OBSW);
 #pragma unroll
                     for (int k = 0; k < OBSW; k++) o[k] = row[k];
                 }
