@@ -399,15 +399,22 @@ __device__ __forceinline__ void actor_ln_relu32(pve_v16f (&v)[2], const float *g
 // registers and 38.1 instead of 36.6 us per closed-loop step.  The opaque offset `o` pins every request to its place:
 // without it the compiler hoists all 24 operand loads to the top (96 registers) and spills.  Unit tiles are processed one
 // after the other, all K-blocks of the input are split into half pairs up front.
-__device__ __forceinline__ pve_v8h actor_a_operand(const pve_v8h *A1, const pve_v8h *A2, int s, int hl, int idx)
+// (ob = the lane's BYTE offset inside a block, 16 x lane, as an unsigned 32-bit value: uniform base + 32-bit lane offset +
+//  immediate is the address form of a global load; an `int` element index is a sign extension and a 64-bit add per request)
+__device__ __forceinline__ pve_v8h actor_a_operand(const pve_v8h *A1, const pve_v8h *A2, int s, int hl, unsigned ob)
 {   // block s: 0..3 = layer 1 (m = s >> 1, kb = s & 1), 4..11 = layer 2 (m2 = (s - 4) >> 2, kb = (s - 4) & 3)
-    return s < 4 ? A1[((hl * 2 + (s >> 1)) * 2 + (s & 1)) * 64 + idx] : A2[((hl * 2 + ((s - 4) >> 2)) * 4 + ((s - 4) & 3)) * 64 + idx];
+    const pve_v8h *blk = s < 4 ? A1 + ((hl * 2 + (s >> 1)) * 2 + (s & 1)) * 64 : A2 + ((hl * 2 + ((s - 4) >> 2)) * 4 + ((s - 4) & 3)) * 64;
+#ifdef PVE_WIDE_INDEX                              // A/B build knob: element index, 64-bit address per request
+    return blk[(int)(ob >> 4)];
+#else
+    return *(const pve_v8h *)((const char *)blk + ob);
+#endif
 }
 __device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *A2, const float *prm, const float (&x)[16],
                                               int lane)
 {
     const int hf = lane >> 5;
-    int o = lane;
+    unsigned o = (unsigned)lane * 16u;
     asm volatile("" : "+v"(o));
     pve_v8h ah[2], al[2];                                     // operand ring
     ah[0] = actor_a_operand(A1, A2, 0, 0, o); al[0] = actor_a_operand(A1, A2, 0, 1, o);
@@ -475,6 +482,15 @@ template <typename OBS_T>
 __device__ __forceinline__ void actor_fetch(const OBS_T *rows, size_t row, int hf, float (&x)[16])
 {
     const OBS_T *src = rows + row * OBSW + 8 * hf;
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = (c < 12 || !hf) ? (float)src[actor_feature(c, 0)] : 0.f;
+}
+// the same from the rows of ONE intersection (k_rollout's actor pass)
+template <typename OBS_T>
+__device__ __forceinline__ void actor_fetch_env(const OBS_T *env_rows, int slot, int hf, float (&x)[16])
+{
+    // (env_rows: the intersection's first row, uniform; the lane's part as a 32-bit byte offset: cf. actor_a_operand)
+    const OBS_T *src = (const OBS_T *)((const char *)env_rows + (unsigned)((slot * OBSW + 8 * hf) * (int)sizeof(OBS_T)));
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = (c < 12 || !hf) ? (float)src[actor_feature(c, 0)] : 0.f;
 }

@@ -127,10 +127,10 @@ __device__ __forceinline__ void rollout_actor(const unsigned char *packed, const
     const int lane = t & 63, hf = lane >> 5, j = lane & 31;
     for (int tile = t >> 6; 32 * tile < n_ctl; tile += CAP / 64) {          // (uniform per wave)
         const int slot = adsts[32 * tile + j];
-        const size_t row = base + (slot == 255 ? 0 : slot);
+        const int srow = slot == 255 ? 0 : slot;
         float x[16];
-        if (obs_f32) actor_fetch((const float *)rows, row, hf, x);
-        else actor_fetch((const double *)rows, row, hf, x);
+        if (obs_f32) actor_fetch_env((const float *)rows + base * OBSW, srow, hf, x);
+        else actor_fetch_env((const double *)rows + base * OBSW, srow, hf, x);
         const float a = actor_tile32(A1, A2, aprm, x, lane);
         if (lane < 32 && slot != 255) act[slot] = (double)a;
     }
