@@ -659,7 +659,6 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
         if (t == 0) sh.hd.current_time = gld<COH>(&gh.current_time) + c.deltaT;      // ref :223 (repeated +=, not tick*dt)
         const int N = gld<COH>(&gh.n_alive);
-        const size_t g = (size_t)env * CAP + t;
         r.alive = t < N;
         r.jerk = 0;
         r.p = r.v = r.a = r.jerk_sum = r.vir_dis = r.closer_p = 0;

@@ -185,7 +185,6 @@ template <int CAP> struct TickGeo {
         }
         if (t == 0) sh.hd.current_time = gld<COH>(&gh.current_time) + g.base.deltaT;       // ref :223
         const int N = gld<COH>(&gh.n_alive);
-        const size_t gi = (size_t)env * CAP + t;
         r.alive = t < N;
         r.jerk = 0;
         r.act = 0;
@@ -193,7 +192,7 @@ template <int CAP> struct TickGeo {
         r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
         const double *acts = use_act0 ? act0 : P.actions;
         if (t < 64 || t < N) {                    // first wave unconditionally (no dependence on n_alive), later waves live slots only
-            if (acts) r.act = acts[gi];
+            if (acts) r.act = *env_at<CAP>(acts, env, t);
             r.p = gld<COH>(env_at<CAP>(P.f64[F_P], env, t)); r.v = gld<COH>(env_at<CAP>(P.f64[F_V], env, t)); r.a = gld<COH>(env_at<CAP>(P.f64[F_A], env, t));
             r.meta = gld<COH>(env_at<CAP>(P.i32[I_META], env, t)); r.step = gld<COH>(env_at<CAP>(P.i32[I_STEP], env, t));
             r.seq = gld<COH>(env_at<CAP>(P.i32[I_SEQ], env, t)); r.vnum = gld<COH>(env_at<CAP>(P.i32[I_VNUM], env, t)); r.count = gld<COH>(env_at<CAP>(P.i32[I_COUNT], env, t));
@@ -213,7 +212,6 @@ template <int CAP> struct TickGeo {
     static PVE_HD void ph_load_late(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
         if (t < 64 || t < sh.hd.n_alive) {
-            const size_t gi = (size_t)env * CAP + t;
             r.jerk_sum = gld<COH>(env_at<CAP>(P.f64[F_JERK_SUM], env, t)); r.closer_p = gld<COH>(env_at<CAP>(P.f64[F_CLOSER_P], env, t));
             r.vir_dis = gld<COH>(env_at<CAP>(P.f64[F_VIR_DIS], env, t));
             r.id = gld<COH>(env_at<CAP>(P.i32[I_ID], env, t));            // (FIN only, for a vehicle that moves)
@@ -901,8 +899,8 @@ template <int CAP> struct TickGeo {
                                  M_CONTROL | M_ALIVE | (t << M_LANE_SHIFT) | (LN == 12 ? 0 : (intention << M_INT_SHIFT)), -1);   // 12-lane: lane % 3, not stored
             }
             if (O.obs_post) {                                                          // ref :380, :420
-                if (P.obs_f32) { float *o = (float *)O.obs_post + ((size_t)env * CAP + slot) * OBSW; for (int k = 0; k < OBSW; k++) o[k] = 0.0f; }
-                else { double *o = O.obs_post + ((size_t)env * CAP + slot) * OBSW; for (int k = 0; k < OBSW; k++) o[k] = 0.0; }
+                if (P.obs_f32) { float *o = env_at<CAP * OBSW>((float *)O.obs_post, env, slot * OBSW); for (int k = 0; k < OBSW; k++) o[k] = 0.0f; }
+                else { double *o = env_at<CAP * OBSW>(O.obs_post, env, slot * OBSW); for (int k = 0; k < OBSW; k++) o[k] = 0.0; }
             }
             if (!RES) {
                 const int rec1 = sh.hd.veh_rec[t] + 1;
