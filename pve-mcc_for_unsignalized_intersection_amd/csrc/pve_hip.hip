@@ -385,6 +385,13 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         asm volatile("" : "+s"(kav_), "+v"(t0_), "+s"(env0_));
         const KernargPtr ka = kav_;
         const int t = t0_, env = env0_;
+#ifndef PVE_NO_RANGE_ASSUME                        // (A/B build knob)
+        // the opaque copy hides the range of t: with it the index arithmetic stays in 24 / 32 bits
+#ifdef PVE_ASSUME_ONE_WAVE_ONLY                    // (A/B build knob)
+        if constexpr (CAP == 64)
+#endif
+        __builtin_assume(t >= 0 && t < CAP);
+#endif
         const PVE_AS4 Const &c = *(const PVE_AS4 Const *)ka;
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka + OFF_P);
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka + OFF_R);
@@ -646,6 +653,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         asm volatile("" : "+s"(kav_), "+v"(t0_), "+s"(env0_));
         const KernargPtr ka = kav_;
         const int t = t0_, env = env0_;
+#ifndef PVE_NO_RANGE_ASSUME                        // (A/B build knob)
+        __builtin_assume(t >= 0 && t < CAP);          // (the opaque copy hides the range: index arithmetic stays in 24 / 32 bits)
+#endif
         const PVE_AS4 GeoConst &g = *(const PVE_AS4 GeoConst *)ka;
         const PVE_AS4 Params &P = *(const PVE_AS4 Params *)(ka + OFF_P);
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka + OFF_R);

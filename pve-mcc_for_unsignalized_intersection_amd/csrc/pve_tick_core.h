@@ -274,6 +274,25 @@ template <int PER, class T> PVE_HD T *env_at(T *base, int env, int idx)
 }
 #endif
 
+// products of small non-negative integers (counts, ranks, slots: < 2^23) as the full-rate 24-bit multiply (v_mul_i32_i24 /
+// v_mad_i32_i24) instead of the quarter-rate 32-bit one the compiler must pick when it cannot see the range
+PVE_HD int mul24(int a, int b)
+{
+#if PVE_DEVICE_CODE && !defined(PVE_NO_RANGE_ASSUME)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
+PVE_HD int mad24(int a, int b, int c)
+{
+#if PVE_DEVICE_CODE && !defined(PVE_NO_RANGE_ASSUME)
+    return __mul24(a, b) + c;                      // (the compiler fuses the add: v_mad_i32_i24)
+#else
+    return a * b + c;
+#endif
+}
+
 // ------------------------------------------------------------------ shared (LDS) block of one env
 template <int CAP, bool LJ = (CAP == 128)> struct Shared {
     static constexpr int NW = CAP / 64;
@@ -659,6 +678,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
         if (t == 0) sh.hd.current_time = gld<COH>(&gh.current_time) + c.deltaT;      // ref :223 (repeated +=, not tick*dt)
         const int N = gld<COH>(&gh.n_alive);
+        const size_t g = (size_t)env * CAP + t;        // (LOAD / FLUSH keep the plain 64-bit index: once per item, and with env_at
+                                                       //  the persistent kernel's allocation tips over into 8-10 spilled registers)
         r.alive = t < N;
         r.jerk = 0;
         r.p = r.v = r.a = r.jerk_sum = r.vir_dis = r.closer_p = 0;
@@ -671,13 +692,13 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (t < 64 || t < N) {
             // what S1 - S3 need comes first; the fields that are merely carried to FIN (or first read in WALK) are requested
             // behind them and arrive under the step phases (the kernel's barriers do not wait for global loads)
-            if (acts) r.act = gld<COHA>(env_at<CAP>(acts, env, t));        // with the state loads: one latency, not a second one in S1
-            r.p = gld<COH>(env_at<CAP>(P.f64[F_P], env, t)); r.v = gld<COH>(env_at<CAP>(P.f64[F_V], env, t)); r.a = gld<COH>(env_at<CAP>(P.f64[F_A], env, t));
-            r.meta = gld<COH>(env_at<CAP>(P.i32[I_META], env, t)); r.step = gld<COH>(env_at<CAP>(P.i32[I_STEP], env, t));
-            r.jerk_sum = gld<COH>(env_at<CAP>(P.f64[F_JERK_SUM], env, t)); r.vir_dis = gld<COH>(env_at<CAP>(P.f64[F_VIR_DIS], env, t));
-            r.closer_p = gld<COH>(env_at<CAP>(P.f64[F_CLOSER_P], env, t));
-            r.id = gld<COH>(env_at<CAP>(P.i32[I_ID], env, t)); r.seq = gld<COH>(env_at<CAP>(P.i32[I_SEQ], env, t)); r.vnum = gld<COH>(env_at<CAP>(P.i32[I_VNUM], env, t));
-            r.count = gld<COH>(env_at<CAP>(P.i32[I_COUNT], env, t));
+            if (acts) r.act = gld<COHA>(acts + g);        // with the state loads: one latency, not a second one in S1
+            r.p = gld<COH>(P.f64[F_P] + g); r.v = gld<COH>(P.f64[F_V] + g); r.a = gld<COH>(P.f64[F_A] + g);
+            r.meta = gld<COH>(P.i32[I_META] + g); r.step = gld<COH>(P.i32[I_STEP] + g);
+            r.jerk_sum = gld<COH>(P.f64[F_JERK_SUM] + g); r.vir_dis = gld<COH>(P.f64[F_VIR_DIS] + g);
+            r.closer_p = gld<COH>(P.f64[F_CLOSER_P] + g);
+            r.id = gld<COH>(P.i32[I_ID] + g); r.seq = gld<COH>(P.i32[I_SEQ] + g); r.vnum = gld<COH>(P.i32[I_VNUM] + g);
+            r.count = gld<COH>(P.i32[I_COUNT] + g);
         }
         sh.cnt[t] = 0;                                    // (rew_ovr / hdr share storage with S2-S3 arrays: BUILD)
         if (t == 0) {
@@ -1794,16 +1815,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_flush(const PVE_AS4 Params &P, int env, int t, Sh &sh)
     {
         const int N = sh.hd.n_alive;
+        const size_t g = (size_t)env * CAP + t;
         if (t < N) {
-            *env_at<CAP>(P.f64[F_P], env, t) = sh.template stf<Sh::SF_P>()[t]; *env_at<CAP>(P.f64[F_V], env, t) = sh.template stf<Sh::SF_V>()[t];
-            *env_at<CAP>(P.f64[F_A], env, t) = sh.template stf<Sh::SF_A>()[t]; *env_at<CAP>(P.f64[F_JERK], env, t) = sh.template stf<Sh::SF_JERK>()[t];
-            *env_at<CAP>(P.f64[F_JERK_SUM], env, t) = sh.template stf<Sh::SF_JERK_SUM>()[t]; *env_at<CAP>(P.f64[F_VIR_DIS], env, t) = sh.template stf<Sh::SF_VIR_DIS>()[t];
-            *env_at<CAP>(P.f64[F_CLOSER_P], env, t) = sh.template stf<Sh::SF_CLOSER_P>()[t];
-            *env_at<CAP>(P.i32[I_ID], env, t) = sh.template sti<I_ID>()[t]; *env_at<CAP>(P.i32[I_SEQ], env, t) = sh.template sti<I_SEQ>()[t];
-            *env_at<CAP>(P.i32[I_VNUM], env, t) = sh.template sti<I_VNUM>()[t]; *env_at<CAP>(P.i32[I_STEP], env, t) = sh.template sti<I_STEP>()[t];
-            *env_at<CAP>(P.i32[I_COUNT], env, t) = sh.template sti<I_COUNT>()[t]; *env_at<CAP>(P.i32[I_META], env, t) = sh.template sti<I_META>()[t];
-            *env_at<CAP>(P.i32[I_HDR], env, t) = sh.template sti<I_HDR>()[t];
-        } else { *env_at<CAP>(P.i32[I_META], env, t) = 0; *env_at<CAP>(P.i32[I_ID], env, t) = -1; }                     // stale slots never look alive
+            P.f64[F_P][g] = sh.template stf<Sh::SF_P>()[t]; P.f64[F_V][g] = sh.template stf<Sh::SF_V>()[t];
+            P.f64[F_A][g] = sh.template stf<Sh::SF_A>()[t]; P.f64[F_JERK][g] = sh.template stf<Sh::SF_JERK>()[t];
+            P.f64[F_JERK_SUM][g] = sh.template stf<Sh::SF_JERK_SUM>()[t]; P.f64[F_VIR_DIS][g] = sh.template stf<Sh::SF_VIR_DIS>()[t];
+            P.f64[F_CLOSER_P][g] = sh.template stf<Sh::SF_CLOSER_P>()[t];
+            P.i32[I_ID][g] = sh.template sti<I_ID>()[t]; P.i32[I_SEQ][g] = sh.template sti<I_SEQ>()[t];
+            P.i32[I_VNUM][g] = sh.template sti<I_VNUM>()[t]; P.i32[I_STEP][g] = sh.template sti<I_STEP>()[t];
+            P.i32[I_COUNT][g] = sh.template sti<I_COUNT>()[t]; P.i32[I_META][g] = sh.template sti<I_META>()[t];
+            P.i32[I_HDR][g] = sh.template sti<I_HDR>()[t];
+        } else { P.i32[I_META][g] = 0; P.i32[I_ID][g] = -1; }                     // stale slots never look alive
         int *dst = (int *)&P.headers[env];
         const int *src = (const int *)&sh.hd;
         for (int w = t; w < (int)(sizeof(EnvHeader) / 4); w += CAP) dst[w] = src[w];

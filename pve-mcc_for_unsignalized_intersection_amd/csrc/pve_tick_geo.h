@@ -251,9 +251,9 @@ template <int CAP> struct TickGeo {
             if (t < ND) {
                 const unsigned mr = sh.tab.mroutes[t];
 #pragma unroll
-                for (int rt = 0; rt < ND; rt++) cap += (int)((mr >> rt) & 1u) * sh.rc[rt];      // (bit extract + multiply-add)
+                for (int rt = 0; rt < ND; rt++) cap = mad24((int)((mr >> rt) & 1u), sh.rc[rt], cap);   // (bit extract + 24-bit multiply-add)
                 rcv = sh.rc[t];
-                prs = rcv * sh.tab.nl[t];
+                prs = mul24(rcv, sh.tab.nl[t]);
             }
 #if PVE_DEVICE_CODE
             const int i1 = wave_incl_scan(t, cap, nullptr), i2 = wave_incl_scan(t, rcv, nullptr), i3 = wave_incl_scan(t, prs, nullptr);
@@ -322,7 +322,7 @@ template <int CAP> struct TickGeo {
             // chain of guarded ones), both outcomes are computed and selected
             const int off = q - sh.pbase[rt], n = sh.tab.nl[rt], ni = (int)sh.tab.ninv[rt], rb = sh.rbase[rt];
             const int lx = sh.tab.dir_lane[rt], ix = sh.tab.dir_index[rt];
-            const int i = (off * ni) >> 15, k = off - i * n;                            // off / n, off % n (exact: off < 2048, n <= 10)
+            const int i = mul24(off, ni) >> 15, k = off - mul24(i, n);                  // off / n, off % n (exact: off < 2048, n <= 10)
             const int x = sh.ctl_by_route[rb + i], d = sh.tab.lst[rt][k];
             const double px = sh.p[x];
             const int li = sh.tab.dir_lane[d], m = sh.tab.dir_index[d], kk = sh.tab.pos[d][rt], ty = sh.tab.dty[d];
@@ -373,7 +373,7 @@ template <int CAP> struct TickGeo {
         double vc;
         if (!member(g, sh, d, li, m, t, vc)) return;          // not in list d: its row is never read
         const int ls = sh.hd.lane_start[li], le = sh.hd.lane_start[li + 1];
-        double *row = sh.u_vd + sh.tstart + sh.tbase[d / 3] + (int)sh.rk[t] * sh.rc[d];
+        double *row = sh.u_vd + sh.tstart + sh.tbase[d / 3] + mul24((int)sh.rk[t], sh.rc[d]);
         int i = 0;
         for (int w2 = 0; w2 < NW; w2++) {
             u64 eb = sh.m_ctl[w2] & sh.m_int[m][w2] & below_sel(le - w2 * 64) & ~below_sel(ls - w2 * 64);
@@ -576,7 +576,7 @@ template <int CAP> struct TickGeo {
         }
         const int tcols = sh.rc[d];
         auto adj = [&](int x, double vo) -> double {
-            return tabf ? sh.u_vd[tcol + (int)sh.rk[x] * tcols] : adjusted(g, sh, m, ls, le, t, vo);
+            return tabf ? sh.u_vd[mad24((int)sh.rk[x], tcols, tcol)] : adjusted(g, sh, m, ls, le, t, vo);
         };
         double bvo = -INFINITY, bvc = 0; int bslot = -1;
         // the 6 nearest so far, sorted by |vd - vd_self|: only (distance, slot) travel through the insertion chain;
