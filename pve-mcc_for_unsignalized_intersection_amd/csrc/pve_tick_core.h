@@ -339,6 +339,9 @@ template <int CAP, bool LJ = (CAP == 128)> struct Shared {
     // FX -> LOCK: what FX decided about the reward of the vehicle in slot t (0 = keep, 1 = -10, 2 = +5), for the dense
     // thread that holds the reward; u_list[CAP ..) is free between RANK and the EARLY staging of FIN
     PVE_HD uint8_t *fxcode() { return u_list + CAP; }
+    // FX -> LOCK: the virtual-header pointers as a byte chain for the dead-lock walk: chain[s] = header of slot s, CAP = none;
+    // chain[CAP] = CAP (sentinel).  u_slot is free between REWARD and FIN's staging
+    PVE_HD uint8_t *chain() { return u_slot; }
     template <int K> PVE_HD int *sti()   // K = I_ID .. I_HDR
     {
         if (DIRECT) return (int *)s_vd + K * CAP;
@@ -1288,6 +1291,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             }
         }
         sh.fxcode()[t] = (uint8_t)code;
+        {                                                 // (after this thread's own resets of hdr[t] above)
+            const int h = sh.hdr[t];
+            sh.chain()[t] = (uint8_t)(h < 0 ? CAP : h);
+            if (t == 0) sh.chain()[CAP] = (uint8_t)CAP;
+        }
         vote<NW>(sh.m_del, t, r.del);
         vote<NW>(sh.m_fin, t, r.fin);
         vote<NW>(sh.m_ctlnow, t, r.alive && !r.del && (r.meta & M_CONTROL));
@@ -1326,11 +1334,24 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (r.dctl && mask_test(sh.m_ctlnow, r.ds)) {
             const int s0 = r.ds;
             int cur = s0, len = 0;
+#ifdef PVE_BRANCHY_LOCK_WALK                       // A/B build knob: the guarded form (a block of its own per hop)
             for (int hop = 0; hop < 10; hop++) {                                  // ref :1470-1478
                 cur = sh.hdr[cur];
                 if (cur < 0) break;
                 if (cur == s0) { len = hop + 1; break; }
             }
+#else
+            // straight-line: the chain table (FX) maps "no header" and the sentinel to the sentinel, so ten unconditional
+            // byte reads never leave it; the first return to s0 sets len and parks the walk on the sentinel
+            const uint8_t *ch = sh.chain();
+#pragma unroll
+            for (int hop = 0; hop < 10; hop++) {                                  // ref :1470-1478
+                cur = ch[cur];
+                const bool back = cur == s0;
+                len = back ? hop + 1 : len;
+                cur = back ? CAP : cur;
+            }
+#endif
             if (len) {
                 const double dv = sh.virdis[s0];
                 int mn = s0, rank = 0;
