@@ -1492,9 +1492,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         const bool fused = RES || (P.mode == MODE_FUSED);
         // ---- spawn set (ref :361, :378-433); a full env defers the spawn (cursor not advanced)
         const unsigned want = (unsigned)(sh.m_spawn[0] & 0xFFFull);
-        unsigned sp = 0; int room = CAP - N;
+        unsigned sp = want; int room = CAP - N;
+        if (__builtin_popcount(want) > room) {            // (uniform, rare: a full intersection defers the spawns of the higher lanes)
+            sp = 0;
 #pragma unroll
-        for (int l = 0; l < NL; l++) if ((want >> l) & 1) { if (room > 0) { sp |= 1u << l; room--; } }
+            for (int l = 0; l < NL; l++) if ((want >> l) & 1) { if (room > 0) { sp |= 1u << l; room--; } }
+        }
         const int n_over = __builtin_popcount(want) - __builtin_popcount(sp);
         // ---- keep mask: FUSED drops delete_veh now, SCENE keeps everybody (marked M_DEL)
         u64 keep[NW];
@@ -1593,12 +1596,14 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         // ---- header
         if (!RES && t < NL) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
         const int n_ctl = mask_count<NW>(sh.m_ctl);
-        const int n_lock = mask_count<NW>(sh.m_lead);
-        const int n_fin = mask_count<NW>(sh.m_fin);
-        const int n_del = mask_count<NW>(sh.m_del);
-        fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp); fc.n_over = n_over; fc.n_fin = n_fin; fc.n_ctl = n_ctl;
-        fc.n_lock = n_lock; fc.n_coll = mask_count<NW>(sh.m_coll); fc.n_pre = N; fc.sr = 0; fc.sj = 0;
+        // (the counters of the header / env_out are thread 0's business: the other wave does not count four masks for nothing)
+        fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp); fc.n_over = n_over; fc.n_fin = 0; fc.n_ctl = n_ctl;
+        fc.n_lock = 0; fc.n_coll = 0; fc.n_pre = N; fc.sr = 0; fc.sj = 0;
         if (t == 0) {
+            const int n_lock = mask_count<NW>(sh.m_lead);
+            const int n_fin = mask_count<NW>(sh.m_fin);
+            const int n_del = mask_count<NW>(sh.m_del);
+            fc.n_fin = n_fin; fc.n_lock = n_lock; fc.n_coll = mask_count<NW>(sh.m_coll);
             double sr = 0, sj = 0;
 #if PVE_DEVICE_CODE
             for (int k = 0; k < NW; k++) { sr += sh.red_reward[k]; sj += sh.red_jerk[k]; }

@@ -822,9 +822,12 @@ template <int CAP> struct TickGeo {
         const bool fused = RES || (P.mode == MODE_FUSED);
         fc.meta = 0;
         const unsigned want = (unsigned)(sh.m_spawn[0] & 0xFFFull);
-        unsigned sp = 0; int room = CAP - N;
+        unsigned sp = want; int room = CAP - N;
+        if (__builtin_popcount(want) > room) {            // (uniform, rare: a full intersection defers the spawns of the higher lanes)
+            sp = 0;
 #pragma unroll
-        for (int l = 0; l < NL; l++) if ((want >> l) & 1) { if (room > 0) { sp |= 1u << l; room--; } }
+            for (int l = 0; l < NL; l++) if ((want >> l) & 1) { if (room > 0) { sp |= 1u << l; room--; } }
+        }
         const int n_over = __builtin_popcount(want) - __builtin_popcount(sp);
         u64 keep[NW];
 #pragma unroll
