@@ -50,6 +50,22 @@ template <int NW> PVE_HD void vote(u64 *m, int t, bool f)
     if (f) m[t >> 6] |= 1ull << (t & 63);   // emulator: masks are zeroed per env
 #endif
 }
+// several votes of one phase: all the ballots, then ONE guarded block in which the wave's first lane stores them (a vote() each
+// is a block of its own: exec mask, branch, store, restore)
+template <int NW, int N> PVE_HD void vote_many(u64 *const (&m)[N], int t, const bool (&f)[N])
+{
+#if PVE_DEVICE_CODE
+    u64 b[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) b[k] = __ballot(f[k]);
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k++) m[k][t >> 6] = b[k];
+    }
+#else
+    for (int k = 0; k < N; k++) if (f[k]) m[k][t >> 6] |= 1ull << (t & 63);
+#endif
+}
 PVE_HD bool mask_test(const u64 *m, int t) { return (m[t >> 6] >> (t & 63)) & 1ull; }
 // The mask helpers read every word UNCONDITIONALLY (one broadcast LDS read each) and select with arithmetic: a word read
 // under `if (t >= ...)` is a guarded basic block of its own (read, wait), and a tick calls these helpers dozens of times.
@@ -756,8 +772,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             outcome(c, r.p, r.v, r.a0, r.ctl, pn, vn); sh.p[t] = pn; sh.v[t] = vn;
             outcome(c, r.p, r.v, r.a1, r.ctl, pn, vn); sh.p1[t] = pn; sh.v1[t] = vn;
         }
-        vote<NW>(sh.m_alive, t, r.alive);
-        vote<NW>(sh.m_ctl, t, r.alive && r.ctl);
+        {
+            u64 *const ms[2] = {sh.m_alive, sh.m_ctl};
+            const bool fs[2] = {r.alive != 0, r.alive && r.ctl};
+            vote_many<NW>(ms, t, fs);
+        }
     }
 
     // ============================================================== S2: brake decision per front outcome
@@ -1296,11 +1315,13 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             sh.chain()[t] = (uint8_t)(h < 0 ? CAP : h);
             if (t == 0) sh.chain()[CAP] = (uint8_t)CAP;
         }
-        vote<NW>(sh.m_del, t, r.del);
-        vote<NW>(sh.m_fin, t, r.fin);
-        vote<NW>(sh.m_ctlnow, t, r.alive && !r.del && (r.meta & M_CONTROL));
-        vote<NW>(sh.m_coll, t, r.alive && r.ctl && r.coll_seen > 0);              // main.py:410-412
-        vote<NW>(sh.m_spawn, t, t < NL && sh.hd.current_time >= sh.hd.next_arr[t < NL ? t : 0]);   // ref :379
+        {
+            u64 *const ms[5] = {sh.m_del, sh.m_fin, sh.m_ctlnow, sh.m_coll, sh.m_spawn};
+            const bool fs[5] = {r.del != 0, r.fin != 0, r.alive && !r.del && (r.meta & M_CONTROL),
+                                r.alive && r.ctl && r.coll_seen > 0,                                      // main.py:410-412
+                                t < NL && sh.hd.current_time >= sh.hd.next_arr[t < NL ? t : 0]};        // ref :379
+            vote_many<NW>(ms, t, fs);
+        }
     }
 
     // ============================================================== LOCK: dead-lock scan + reductions
@@ -1547,11 +1568,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             }
         }
         // ---- new lane starts
-        int n_post;
-        {
-            int ls12 = (RES ? (int)sh.keep_pre()[sh.hd.lane_start[NL]] : mask_below<NW>(keep, sh.hd.lane_start[NL])) + __builtin_popcount(sp);
-            n_post = ls12;
-        }
+        int n_post = 0;                                   // (RES: thread 0's business, below)
+        if (!RES) n_post = mask_below<NW>(keep, sh.hd.lane_start[NL]) + __builtin_popcount(sp);
         fc.new_slot = new_slot;
         fc.ls = 0; fc.sp_slot = -1; fc.sp_id = 0; fc.sp_vnum = 0;
         if (t <= NL) {
@@ -1600,6 +1618,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp); fc.n_over = n_over; fc.n_fin = 0; fc.n_ctl = n_ctl;
         fc.n_lock = 0; fc.n_coll = 0; fc.n_pre = N; fc.sr = 0; fc.sj = 0;
         if (t == 0) {
+            if (RES) { n_post = (int)sh.keep_pre()[sh.hd.lane_start[NL]] + __builtin_popcount(sp); fc.n_post = n_post; }
             const int n_lock = mask_count<NW>(sh.m_lead);
             const int n_fin = mask_count<NW>(sh.m_fin);
             const int n_del = mask_count<NW>(sh.m_del);
