@@ -1428,10 +1428,15 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             // cycles are rare: the first walk only chases pointers (one read per hop); a member walks its cycle again for
             // the smallest slot and its rank in the sorted record list
             int cur = t, len = 0, mn = t, rank = 0;
-            for (int hop = 0; hop < 10; hop++) {                                  // ref :1470-1478
-                cur = sh.hdr[cur];
-                if (cur < 0) break;
-                if (cur == t) { len = hop + 1; break; }
+            {                                             // straight-line over the byte chain written in FX (cf. ph_lock)
+                const uint8_t *ch = sh.chain();
+#pragma unroll
+                for (int hop = 0; hop < 10; hop++) {                              // ref :1470-1478
+                    cur = ch[cur];
+                    const bool back = cur == t;
+                    len = back ? hop + 1 : len;
+                    cur = back ? CAP : cur;
+                }
             }
             const bool found = len > 0;
             if (found) {

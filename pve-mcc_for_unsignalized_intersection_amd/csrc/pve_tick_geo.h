@@ -54,6 +54,7 @@ template <int CAP> struct SharedGeo {
     double s_vd[1];
     alignas(8) unsigned s_idx[PE];          // sorted position -> entry | tick tag << 16 (cf. Shared<128>, Tick::ph_rank)
     alignas(8) uint8_t u_slot[PE], u_list[PE];
+    PVE_HD uint8_t *chain() { return u_slot; }   // FX -> LOCK: the virtual headers as a byte chain with a sentinel (Tick::ph_lock_slot); u_slot is free then
     alignas(8) uint8_t s_slot[PE];          // (k_rollout_geo's staging storage: sti<4>)
     // k_rollout_geo keeps the state on the chip between two ticks (cf. Shared<CAP>): every persistent field of every vehicle
     // moves to its new slot through storage that is dead by FIN -- the entry pool beyond the dead-lock records, virdis, the
@@ -795,6 +796,11 @@ template <int CAP> struct TickGeo {
                 r.reward = 5;
                 lds_add(&sh.acc_passed_steps, r.step);
             }
+        }
+        {                                                 // (after this thread's own resets of hdr[t] above)
+            const int h = r.hdr;                          // (= hdr[t]: -1 since the top of SCAN unless SCAN set it)
+            sh.chain()[t] = (uint8_t)(h < 0 ? CAP : h);
+            if (t == 0) sh.chain()[CAP] = (uint8_t)CAP;
         }
         vote<NW>(sh.m_del, t, r.del);
         vote<NW>(sh.m_fin, t, r.fin);
