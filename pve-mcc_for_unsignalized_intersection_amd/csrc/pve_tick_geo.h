@@ -920,12 +920,14 @@ template <int CAP> struct TickGeo {
         if (!RES && t >= n_post && t < N) { P.i32[I_META][gpre] = 0; P.i32[I_ID][gpre] = -1; }
         if (!RES && t < ND) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
         const int n_ctl = mask_count<NW>(sh.m_ctl);
-        const int n_lock = mask_count<NW>(sh.m_lead);
-        const int n_fin = mask_count<NW>(sh.m_fin);
-        const int n_del = mask_count<NW>(sh.m_del);
-        fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp); fc.n_over = n_over; fc.n_fin = n_fin; fc.n_ctl = n_ctl;
-        fc.n_lock = n_lock; fc.n_coll = mask_count<NW>(sh.m_coll); fc.n_pre = N; fc.sr = 0; fc.sj = 0;
+        // (the header's counters are thread 0's business: cf. Tick::ph_final)
+        fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp); fc.n_over = n_over; fc.n_fin = 0; fc.n_ctl = n_ctl;
+        fc.n_lock = 0; fc.n_coll = 0; fc.n_pre = N; fc.sr = 0; fc.sj = 0;
         if (t == 0) {
+            const int n_lock = mask_count<NW>(sh.m_lead);
+            const int n_fin = mask_count<NW>(sh.m_fin);
+            const int n_del = mask_count<NW>(sh.m_del);
+            fc.n_fin = n_fin; fc.n_lock = n_lock; fc.n_coll = mask_count<NW>(sh.m_coll);
             double sr = 0, sj = 0;
 #if PVE_DEVICE_CODE
             for (int k = 0; k < NW; k++) { sr += sh.red_reward[k]; sj += sh.red_jerk[k]; }
