@@ -126,3 +126,111 @@ def check_split_actor_long_horizon(backend, ticks=1000, n_envs=16, seed=9):
     assert rel["passed"] <= 0.01 and rel["passed_steps"] <= 0.01 and rel["alive_steps"] <= 0.01 and rel["sum_reward"] <= 0.02, rel
     rel["collided_split"], rel["collided_exact"], rel["spawned"] = ms["collided"], me["collided"], ms["spawned"]
     return first, worst_a, rel
+
+
+# ------------------------------------------------------------------ the graph-level pin (round 5)
+def load_graph_golden():
+    """tests/golden/actor_graph.npz: (row, action) vectors produced by evaluating the reference's OWN MetaGraphDef
+    (model_data/baseline/66.cptk.meta) op by op -- tests/golden/gen_actor_golden.py.  Returns (rows f32 [N,28], kinds,
+    actions_f32, actions_f64, meta dict, well) where `well` masks out the constant non-zero rows: there the graph's
+    x*inv - mean*inv form cancels two numbers of magnitude 1e6 in float32 (result good to ~0.1 only, in ANY float32
+    evaluation order; such rows cannot occur: a row holds a position, a speed and a route)."""
+    import json
+    z = np.load(os.path.join(GOLDEN_DIR, "actor_graph.npz"))
+    rows = z["rows"]
+    const_nonzero = (np.ptp(rows, axis=1) == 0) & (rows[:, 0] != 0)
+    return rows, z["kinds"], z["actions_f32"], z["actions_f64"], json.loads(str(z["meta"])), ~const_nonzero
+
+
+def planted_batch(backend, n_envs, ticks=150, rate=1000.0, seed=31, **cfg):
+    """A batch in a filled state (closed loop with the installed actor for `ticks` ticks) whose controlled slots the
+    callers overwrite with golden rows.  Returns (batch, [(env, slot)] of the controlled slots)."""
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=ticks * 0.1 + 40, seed=seed)
+    b = make_batch(arr, n_envs, 128, backend, outputs=("obs_post", "reward", "flags", "env_out", "new_slot"), **cfg)
+    b.reset()
+    b.set_actor(flat_weights(load_weights()))
+    for _ in range(ticks):
+        b.step_with_actor()
+    ctl = _np(b.control_mask())
+    return b, np.argwhere(ctl)
+
+
+def actions_of_planted_rows(b, slots, rows):
+    """Feed `rows` through the batch's actor entry point (pve_actor_forward), len(slots) rows per call, each row in the
+    observation cell of a controlled slot; returns the actions in row order."""
+    out = np.zeros(len(rows))
+    for lo in range(0, len(rows), len(slots)):
+        part = rows[lo:lo + len(slots)]
+        sl = slots[:len(part)]
+        obs = np.zeros((b.n_envs, b.capacity, 28), np.float32)
+        obs[sl[:, 0], sl[:, 1]] = part
+        b.obs.copy_(torch.as_tensor(obs).to(b.obs.dtype).to(b.device))
+        a = _np(b.act())
+        ctl = np.zeros(a.shape, bool)
+        ctl[slots[:, 0], slots[:, 1]] = True
+        assert np.all(a[~ctl] == 0), "uncontrolled slots must get 0 (main.py:401)"
+        out[lo:lo + len(part)] = a[sl[:, 0], sl[:, 1]]
+    return out
+
+
+def check_actor_entry_point_vs_graph(backend, n_envs=8, **cfg):
+    """pve_actor_forward (k_actor_h by default, k_actor_t with actor_f32=True, `actor_canonical` in the emulator) on the
+    golden rows against the actions of the reference's graph: |a - a_graph_f32| and |a - a_graph_f64| <= ACTION_TOL."""
+    rows, kinds, a32, a64, meta, well = load_graph_golden()
+    b, slots = planted_batch(backend, n_envs, **cfg)
+    assert len(slots) >= 20 * n_envs, len(slots)
+    a = actions_of_planted_rows(b, slots, rows)
+    e32, e64 = np.abs(a - a32), np.abs(a - a64)
+    worst = {}
+    for k in np.unique(kinds):
+        m = (kinds == k) & well
+        worst[str(k)] = (float(e32[m].max()), float(e64[m].max()))
+    bad = np.flatnonzero(well & ((e32 > ACTION_TOL) | (e64 > ACTION_TOL)))
+    assert len(bad) == 0, "rows %s: %s vs graph %s" % (bad[:8], a[bad[:8]], a32[bad[:8]])
+    assert np.all(np.abs(a[~well] - a64[~well]) <= 0.2)        # the ill-conditioned constant rows: sane, not pinned
+    zero = np.flatnonzero((np.abs(rows).max(axis=1) == 0))
+    assert len(zero) >= 1 and e32[zero].max() <= 1e-5, "the all-zero row of a fresh vehicle (ref :380, :420)"
+    return worst
+
+
+def check_fused_rollout_actor_vs_graph(backend, n_envs=64, **cfg):
+    """The actor INSIDE the resident kernel (k_rollout<.., ACT>, pve_step_many(PVE_SRC_ACTOR)) held to the graph's actions:
+    two batches in the same state; batch G takes one plain tick with the graph's float32 actions as the tape, batch R
+    gets the golden ROWS planted in its observation buffer and takes the same tick through step_many(1, source="actor").
+    The accelerations the step applied must agree to ACTION_TOL (clip is 1-Lipschitz, the overrides of ref :1503-1520 do
+    not depend on the action), everything discrete must be identical."""
+    rows, kinds, a32, a64, meta, well = load_graph_golden()
+    g, slots = planted_batch(backend, n_envs, **cfg)
+    r, slots_r = planted_batch(backend, n_envs, **cfg)
+    assert np.array_equal(slots, slots_r) and len(slots) >= len(rows), (len(slots), len(rows))
+    for k in ("p", "v", "a", "id", "meta"):
+        assert np.array_equal(_np(g.state_field(k)), _np(r.state_field(k))), k
+    use = np.flatnonzero(well)
+    sl = slots[:len(use)]
+    obs = np.zeros((n_envs, 128, 28), np.float32)
+    obs[sl[:, 0], sl[:, 1]] = rows[use]
+    tape = np.zeros((n_envs, 128))
+    tape[sl[:, 0], sl[:, 1]] = a32[use].astype(np.float64)
+    # controlled slots beyond the golden rows: the action of the all-zero row (what the planted zero rows yield)
+    zero_a = float(a32[np.flatnonzero(np.abs(rows).max(axis=1) == 0)[0]])
+    rest = slots[len(use):]
+    tape[rest[:, 0], rest[:, 1]] = zero_a
+    a_before = _np(g.state_field("a")).copy()
+    out_g = g.step(torch.as_tensor(tape).to(g.device))
+    new_slot = _np(out_g["new_slot"]).copy()
+    r.obs.copy_(torch.as_tensor(obs).to(r.obs.dtype).to(r.device))
+    r.step_many(1, source="actor")
+    for k in ("id", "meta", "step", "count"):
+        assert np.array_equal(_np(g.state_field(k)), _np(r.state_field(k))), k
+    a_g, a_r = _np(g.state_field("a")), _np(r.state_field("a"))
+    worst = float(np.abs(a_g - a_r).max())
+    assert worst <= ACTION_TOL, worst
+    # how many of the planted actions the comparison actually saw (no override, no deletion)
+    ns = new_slot[sl[:, 0], sl[:, 1]]
+    alive = ns >= 0
+    applied = a_g[sl[alive, 0], ns[alive]]
+    seen = int((applied == np.clip(a32[use][alive].astype(np.float64), -3, 3)).sum())
+    assert seen >= 0.5 * len(use), (seen, len(use))
+    del a_before
+    return worst, seen

@@ -520,3 +520,25 @@ def test_gpu_geo_list_path_equals_scan_fallback(lane_num, rate, quant):
     membership-scan fallback (PVE_CFG_GEO_SCAN), bit for bit."""
     m = scenarios.check_geo_lists_equal_scan(BACKEND, lane_num, n_envs=12, ticks=300, rate=rate, quantize=quant)
     assert m["ctl_steps"] > 20000
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_gpu_actor_kernels_vs_reference_graph(exact):
+    """f1, graph-level pin: k_actor_h (default, split-half f16 matrix instructions) and k_actor_t (PVE_CFG_ACTOR_F32) on
+    the golden rows against the actions of the reference's OWN graph (model_data/baseline/66.cptk.meta decoded and
+    evaluated op by op, tests/golden/gen_actor_golden.py): |a - a_graph| <= 5e-4 against both the float32 and the
+    float64 evaluation, on closed-loop states, random rows of scale 1 / 30 / 150 and the rows where the variance
+    epsilon 1e-12 decides (the all-zero row of a fresh vehicle to 1e-5)."""
+    from tests import actor_scenarios as A
+    worst = A.check_actor_entry_point_vs_graph(BACKEND, n_envs=16, actor_f32=exact)
+    print("actor (exact=%s) vs graph, max (|a - f32|, |a - f64|) per kind: %s" % (exact, worst))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_gpu_fused_rollout_actor_vs_reference_graph(dtype):
+    """The actor inside the resident kernel (k_rollout<.., ACT>) applies the reference graph's actions: golden rows
+    planted in the observation buffer, one tick through pve_step_many(PVE_SRC_ACTOR) == one plain tick with the graph's
+    actions as the tape, accelerations to 5e-4, everything discrete identical."""
+    from tests import actor_scenarios as A
+    worst, seen = A.check_fused_rollout_actor_vs_graph(BACKEND, n_envs=72, obs_dtype=dtype)
+    print("k_rollout<ACT> vs graph (%s rows): max |da| = %.3e over %d planted actions seen unclipped" % (dtype, worst, seen))
