@@ -2,12 +2,12 @@
 
 model_agent_maddpg.py:23-49: x(28) -> LayerNorm -> Dense64 -> LayerNorm -> ReLU -> Dense64 -> LayerNorm -> ReLU
 -> Dense1 -> 3*tanh, all float32 (placeholder dtype, :15).  `tc.layers.layer_norm(center=True, scale=True)`
-normalises over the last axis with the biased variance and variance_epsilon = 1e-12 (TF 1.12 source).
+normalises over the last axis with the biased variance and variance_epsilon = 1e-12 (the Const nodes of the graph).
 
-Parity status: TensorFlow is not installable here, so the TF graph itself cannot be run; the restatement is
-pinned instead by the closed-loop known answers of SURVEY.md App. D (1000 stream, 1000 ticks: 323 spawned,
-281 passed, 0 collisions, 548 locks, 72 416 alive-steps, 37 295 controlled-steps, pT-m 12.294 s), which a wrong
-weight layout / epsilon / activation would not reproduce (tests/test_actor.py)."""
+Parity status: PINNED against the reference's own graph (model_data/baseline/66.cptk.meta, a MetaGraphDef decoded and
+evaluated op by op by tests/golden/gen_actor_golden.py): tests/test_actor_graph.py holds this restatement to <= 2 ulp of the
+graph's float32 evaluation on 2 743 rows, and asserts the op chain / reduction axes / variance_epsilon (float32(1e-12)) from
+the decoded file.  The closed-loop known answers of SURVEY.md App. D (tests/test_actor.py) are a second, indirect pin."""
 import os
 
 import numpy as np
