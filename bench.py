@@ -114,6 +114,7 @@ def cpu_baseline(arr, pool, cap, lane_num=12, choice=None, id_sin=False):
                        "workload and action pool, %d threads, %.2f s wall" % (n, CPU_TICKS, CPU_WARM, min(cores, n), dt))
 
 
+# (launch-shape knobs exist in the `make knobs` build of the library only; a run with one of them set measures another kernel)
 KNOBS = ("PVE_NO_ROLLOUT_KERNEL", "PVE_NO_ROLLOUT_ACTOR", "PVE_ROLLOUT_GEO_WPE5", "PVE_ACTOR_GRID",
          "PVE_LIBRARY_PATH", "PVE_NO_PERSISTENT", "PVE_TAPER_TAIL", "PVE_PERSISTENT_GRID")
 

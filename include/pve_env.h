@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PVE_ABI_VERSION 6
+#define PVE_ABI_VERSION 7
 #define PVE_LANES 12          /* physical lanes: lane_num = 4, 8 or 12 (arrays are padded to 12) */
 #define PVE_MAX_DIRS 16       /* virtual-lane lists (routes): 12 for lane_num 4 / 12, 16 for lane_num 8 (ref :86, :132, :167) */
 #define PVE_OBS_WIDTH 28      /* (o_agent_num + 1) * 4, ref :1295 */
@@ -56,7 +56,7 @@ enum {
                                       the per-route lists; results are identical (tested) */
 #define PVE_CFG_ACTOR_F32    0x8   /* flags: run the actor as an exact float32 FMA chain (v_mfma_f32_16x16x4_f32, the evaluation order
                                       of csrc/pve_actor.h `actor_canonical`) instead of the default split-half form (every operand
-                                      x = hi + lo in float16, three v_mfma_f32_16x16x32_f16 per block, float32 accumulation:
+                                      x = hi + lo in float16, three v_mfma_f32_32x32x16_f16 per block, float32 accumulation:
                                       ~1e-6 relative per dot product, 5x less matrix-core time) */
 typedef struct pve_config {
     double deltaT;          /* 0.1 */
@@ -246,12 +246,20 @@ typedef struct pve_rollout {
                                      launch lasts as long as its slowest intersection: with several handles stepped on their
                                      own streams, shorter launches let the other handles' workgroups fill the slots that the
                                      fast intersections free (bench.py --chunk). */
-    int32_t persistent;           /* 1 (with chunk_ticks > 0, PVE_SRC_ZERO / PVE_SRC_POOL, lane_num 12, no obs_pre / state_pre): the
-                                     whole call is ONE launch of as many workgroups as the chip holds at once; they pull
-                                     (intersection, chunk) items from a queue in the handle's workspace, so nothing waits in
-                                     launch order for the slowest intersection of a chunk (the reference's episode loop
-                                     main.py:397-441 has no such boundary either).  Same results as persistent = 0; ignored
-                                     (chunked launches as above) where the configuration has no such kernel. */
+    int32_t persistent;           /* 1 (with 0 < chunk_ticks < n_ticks, chunk_ticks <= 255): the whole call is ONE launch of as many
+                                     workgroups as the chip holds at once; they pull (intersection, chunk) items from a queue in the
+                                     handle's workspace, so nothing waits in launch order for the slowest intersection of a chunk
+                                     (the reference's episode loop main.py:397-441 has no such boundary either).  Same results as
+                                     persistent = 0.  Eligible: lane_num 12 with every source (ZERO / POOL / TABLE / ACTOR unless
+                                     PVE_CFG_ACTOR_F32), with or without trajectory = 1, with or without the training outputs
+                                     obs_pre / state_pre; lane_num 4 / 8 with ZERO / POOL and without the training outputs.
+                                     Anything else is run as chunked launches (pve_debug_last_launch tells which).
+                                     PVE_SRC_ACTOR: `actor_actions` is the hand-off buffer between the items of an intersection
+                                     (every item's last tick stores the next actions there, the next item reads them): it must
+                                     not alias any other buffer of the call.
+                                     A persistent call must run to completion ONCE: its hand-off counters live partly in the
+                                     handle (host) and partly in the workspace (device), so it must not be captured into a HIP
+                                     graph or replayed; after a failed launch / stream error both sides are reset. */
 } pve_rollout;
 int pve_step_many(pve_handle h, const pve_rollout *ro, const pve_outputs *out);
 
@@ -275,6 +283,11 @@ int pve_synchronize(pve_handle h);
  * buffer of uint64 [n_envs * capacity/64][16] (column = phase: load, step1, step2, step3, build, rank,
  * walk, effects, lock, final, state); NULL disables. Used by tools/phase_profile.py; no effect on results. */
 int pve_debug_phase_cycles(pve_handle h, uint64_t *dev_counters16);
+
+/* Diagnostics: what the last stepping call on this handle launched. */
+enum { PVE_LAUNCH_NONE = 0, PVE_LAUNCH_TICK = 1 /* one launch per tick */, PVE_LAUNCH_RESIDENT = 2 /* one k_rollout launch per chunk */,
+       PVE_LAUNCH_PERSISTENT = 3 /* ONE launch for the call, items pulled from the work queue */ };
+int pve_debug_last_launch(pve_handle h);
 
 /* Diagnostics: every later pve_step_all / pve_scene_update launch of the 12-lane kernel (k_tick) RETURNS behind phase n
  * (0 load, 1 step1, 2 step2, 3 step3, 4 build, 5 rank, 6 walk + reward, 7 effects, 8 lock) without writing any state, so

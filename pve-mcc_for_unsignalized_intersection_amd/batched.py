@@ -330,9 +330,12 @@ class BatchedIntersections:
         trajectory=<dict from alloc_trajectory(m), m >= n_ticks>: the same into the caller's buffers (blocks 0 .. n_ticks-1).
         update_views=False (trajectory roll-outs only): skip the copy of the last tick into the handle's single-tick views
         (`obs`, `out`) -- not with source="actor", whose next call reads `obs`.
-        persistent=True (with chunk > 0; pool / zero sources, lane_num 12): the call is ONE launch whose workgroups pull
-        (intersection, chunk) items from a queue -- for a batch of at least twice as many intersections as the chip holds
-        workgroups (4096 x 128 slots on one MI355X); same results."""
+        persistent=True (with 0 < chunk < n_ticks): the call is ONE launch whose workgroups pull (intersection, chunk) items
+        from a queue -- for a batch of at least twice as many intersections as the chip holds workgroups (4096 x 128 slots on
+        one MI355X); same results.  Eligible: lane_num 12 with every source (not the exact-float32 actor), trajectory
+        roll-outs and the training outputs included; lane_num 4 / 8 with pool / zero and without the training outputs;
+        anything else runs as chunked launches (last_launch() tells which).  With source="actor" the handle's
+        `_actor_actions` scratch is the hand-off buffer between the items of an intersection."""
         n_ticks = int(n_ticks)
         if source is None:
             source = "actor" if actor else ("pool" if getattr(self, "_pool", None) is not None else "zero")
@@ -466,6 +469,11 @@ class BatchedIntersections:
 
     def synchronize(self):
         check(self.lib, self.lib.pve_synchronize(self._h), "pve_synchronize")
+
+    def last_launch(self):
+        """What the last stepping call launched: "tick" (one launch per tick), "resident" (one k_rollout launch per chunk),
+        "persistent" (one launch for the call, items pulled from the work queue) or "none" (pve_debug_last_launch)."""
+        return ("none", "tick", "resident", "persistent")[self.lib.pve_debug_last_launch(self._h)]
 
     # ------------------------------------------------------------------ host read-back
     def read_env(self, env=0):

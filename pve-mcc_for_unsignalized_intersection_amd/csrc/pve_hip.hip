@@ -11,6 +11,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction: the discrete
 // decisions of the reference sit on margins down to 4e-16).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <new>
 
 #include "pve_host.h"
@@ -19,6 +20,15 @@
 #include "pve_actor.h"
 
 using namespace pve;
+
+// A/B knobs of the measurement tooling (tools/ab_launch_shapes.py, tools/gpu.sh): environment variables that switch launch
+// shapes.  Compiled in only with -DPVE_AB_KNOBS (`make knobs` -> build/libpveenv_knobs.so); the product library reads no
+// environment variable on its launch path.
+#ifdef PVE_AB_KNOBS
+#define PVE_KNOB(name_) getenv(name_)
+#else
+#define PVE_KNOB(name_) ((const char *)nullptr)
+#endif
 
 typedef __attribute__((address_space(4))) const char *KernargPtr;
 // diagnostics (pve_debug_phase_cycles): every wave keeps the clock ticks it spent in each phase (incl. the
@@ -232,9 +242,7 @@ __device__ __forceinline__ bool q_take(const PVE_AS4 RolloutArgs &R, int n_envs,
     env = __builtin_amdgcn_readfirstlane(q_word[0]);
     chunk = __builtin_amdgcn_readfirstlane(q_word[1]);
     if (env < 0) return false;
-    k_base = (chunk < R.n_full ? chunk : R.n_full) * R.n_ticks;
-    for (int q = 0; q < chunk - R.n_full; q++) k_base += R.taper[q];                  // (uniform: scalar loop over <= 7 entries)
-    n_ticks = chunk < R.n_full ? R.n_ticks : (int)R.taper[chunk - R.n_full];
+    rollout_item(R, chunk, k_base, n_ticks);
     return true;
 }
 // hand the intersection on: every wave's stores (state, header, the ticks' output rows) have reached the L2, then the count of
@@ -792,6 +800,39 @@ static std::string hip_err(const char *what, hipError_t e)
     return std::string(what) + ": " + hipGetErrorString(e);
 }
 
+// Resident workgroups of the persistent roll-out kernels, per DEVICE (a process may hold handles on several GPUs, and they
+// need not be the same part): [device][kernel family (12-lane / general geometry)][capacity 64 / 128] workgroups per CU + the
+// CU count, filled by the first persistent launch on that device.
+struct OccCache {
+    static constexpr int MAX_DEV = 64;
+    std::mutex mu;
+    int wgs[MAX_DEV][2][2] = {};
+    int n_cu[MAX_DEV] = {};
+    // -> workgroups the device holds at once for (family, cap), or -1 (err set); `query` = the occupancy call of the variant
+    template <typename Q>
+    long long resident(int family, int cap, Q query, std::string &err)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { err = "hipGetDevice failed"; return -1; }
+        const int ci = cap == 64 ? 0 : 1;
+        std::lock_guard<std::mutex> lock(mu);
+        const bool cached = dev >= 0 && dev < MAX_DEV && wgs[dev][family][ci] > 0;
+        int nb = cached ? wgs[dev][family][ci] : 0, cus = cached ? n_cu[dev] : 0;
+        if (!cached) {
+            hipDeviceProp_t prop;
+            const hipError_t e = query(&nb);
+            if (e != hipSuccess || nb <= 0 || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+                err = std::string("occupancy query of the persistent roll-out: ") + hipGetErrorString(e);
+                return -1;
+            }
+            cus = prop.multiProcessorCount;
+            if (dev >= 0 && dev < MAX_DEV) { wgs[dev][family][ci] = nb; n_cu[dev] = cus; }
+        }
+        return (long long)nb * cus;
+    }
+};
+static OccCache g_occ;
+
 struct Backend {
     static int set_device(int dev, std::string &err)
     {
@@ -859,8 +900,8 @@ struct Backend {
     }
     static int launch_rollout(const Const &c, const Params &P_in, const RolloutArgs &R, int cap, void *stream, std::string &err)
     {
-        static const bool off = getenv("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
-        static const bool act_off = getenv("PVE_NO_ROLLOUT_ACTOR") != nullptr;   // A/B knob: actor + tick launches instead
+        static const bool off = PVE_KNOB("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
+        static const bool act_off = PVE_KNOB("PVE_NO_ROLLOUT_ACTOR") != nullptr;   // A/B knob: actor + tick launches instead
         if (off || (R.source == 2 /* PVE_SRC_ACTOR */ && (act_off || R.exact_f32 || P_in.phase_cycles))) return 1;
         hipStream_t s = (hipStream_t)stream;
         Params P = P_in;
@@ -873,25 +914,18 @@ struct Backend {
         const bool train = P.out.obs_pre || P.out.state_pre;
         if (R.queue) {                                                        // persistent form (pve_rollout.persistent)
             if (train || (R.source == 2 && (act_off || R.exact_f32 || !R.actor_actions))) return 1;
-            Rk.q_trace = P.phase_cycles;                                      // (read by -DPVE_QUEUE_TRACE builds only: per-item timestamps)
+#ifdef PVE_QUEUE_TRACE
+            Rk.q_trace = P.phase_cycles;                                      // (per-item timestamps: make trace)
+#else
+            if (P.phase_cycles) return 1;       // pve_debug_phase_cycles armed: the chunked launches record the cycles (as the geo path does)
+#endif
             // as many workgroups as the chip holds at once (the queue needs no more; fewer when the call has fewer items)
-            static int wgs_per_cu[2] = {0, 0}, n_cu = 0;
-            const int ci = cap == 64 ? 0 : 1;
-            if (!wgs_per_cu[ci]) {
-                int nb = 0, dev = 0;
-                hipDeviceProp_t prop;
-                hipError_t e = (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout<64, 4, false, false, false, false, true>, 64, 0)
-                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout<128, 4, false, false, false, false, true>, 128, 0);
-                if (e != hipSuccess || nb <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-                    err = hip_err("occupancy query of the persistent roll-out", e);
-                    return -1;
-                }
-                n_cu = prop.multiProcessorCount;
-                wgs_per_cu[ci] = nb;
-            }
+            long long grid = g_occ.resident(0, cap, [&](int *nb) {
+                return (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout<64, 4, false, false, false, false, true>, 64, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout<128, 4, false, false, false, false, true>, 128, 0); }, err);
+            if (grid < 0) return -1;
             const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
-            long long grid = (long long)wgs_per_cu[ci] * n_cu;
-            if (const char *g = getenv("PVE_PERSISTENT_GRID")) { const long long v = atoll(g); if (v > 0) grid = v; }   // A/B knob
+            if (const char *g = PVE_KNOB("PVE_PERSISTENT_GRID")) { const long long v = atoll(g); if (v > 0) grid = v; }   // A/B knob
             if (grid > items) grid = items;
             if (R.source == 2) {                                               // the closed loop: the actor inside the persistent kernel
                 if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true, false, false, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
@@ -928,7 +962,7 @@ struct Backend {
     }
     static int launch_rollout_geo(const GeoConst &g, const Params &P_in, const RolloutArgs &R, int cap, void *stream, std::string &err)
     {
-        static const bool off = getenv("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
+        static const bool off = PVE_KNOB("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
         const bool train = P_in.out.obs_pre || P_in.out.state_pre;
         if (off || R.source == 2 /* the actor reads 12-lane rows */ || P_in.phase_cycles || (train && R.source == 3)) return 1;
         if (R.queue && (train || R.source == 3)) return 1;                    // (the queue form: pool / zero sources)
@@ -944,22 +978,11 @@ struct Backend {
         if (R.queue) {
             // the persistent form: as many workgroups as the chip holds at once (the variants share their register budget and LDS
             // block: one occupancy query per capacity)
-            static int wgs_per_cu[2] = {0, 0}, n_cu = 0;
-            const int ci = cap == 64 ? 0 : 1;
-            if (!wgs_per_cu[ci]) {
-                int nb = 0, dev = 0;
-                hipDeviceProp_t prop;
-                hipError_t e = (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout_geo<64, true, 4, false, false, true>, 64, 0)
-                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout_geo<128, true, 4, false, false, true>, 128, 0);
-                if (e != hipSuccess || nb <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-                    err = hip_err("occupancy query of the persistent roll-out", e);
-                    return -1;
-                }
-                n_cu = prop.multiProcessorCount;
-                wgs_per_cu[ci] = nb;
-            }
+            long long gq = g_occ.resident(1, cap, [&](int *nb) {
+                return (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<64, true, 4, false, false, true>, 64, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<128, true, 4, false, false, true>, 128, 0); }, err);
+            if (gq < 0) return -1;
             const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
-            long long gq = (long long)wgs_per_cu[ci] * n_cu;
             if (gq > items) gq = items;
             grid = dim3((unsigned)gq);
             if (g.lane_num == 4) {
@@ -980,9 +1003,12 @@ struct Backend {
             if (cap == 64) PVE_LAUNCH_GEO(64, true); else PVE_LAUNCH_GEO(128, true);
         } else if (cap == 64) PVE_LAUNCH_GEO(64, false);
         else {
-            static const bool w5 = getenv("PVE_ROLLOUT_GEO_WPE5") != nullptr;     // A/B knob: 96-VGPR build, 10 workgroups per CU
+#ifdef PVE_AB_KNOBS
+            static const bool w5 = getenv("PVE_ROLLOUT_GEO_WPE5") != nullptr;     // A/B knob: 96-VGPR build, 10 workgroups per CU (414 spills)
             if (w5 && !train && R.source != 3) hipLaunchKernelGGL((k_rollout_geo<128, false, 5>), grid, dim3(128), 0, s, g, P, Rk);
-            else PVE_LAUNCH_GEO(128, false);
+            else
+#endif
+            PVE_LAUNCH_GEO(128, false);
         }
 #undef PVE_LAUNCH_GEO
         return check_launch(err);
@@ -1033,7 +1059,7 @@ struct Backend {
     {
         // persistent workgroups of 4 waves (the parameters are staged in LDS once per workgroup): 4 per CU, one wave
         // per intersection at a time
-        static const int wgs = [] { const char *g = getenv("PVE_ACTOR_GRID"); const int v = g ? atoi(g) : 0; return v > 0 ? v : 1024; }();
+        static const int wgs = [] { const char *g = PVE_KNOB("PVE_ACTOR_GRID"); const int v = g ? atoi(g) : 0; return v > 0 ? v : 1024; }();
         const int grid = (n_envs + 3) / 4 < wgs ? (n_envs + 3) / 4 : wgs;
         if (exact_f32) {
             if (cap == 64) hipLaunchKernelGGL((k_actor_t<64, OBS_T>), dim3(grid), dim3(256), 0, s, W, obs, meta, actions, n_envs);

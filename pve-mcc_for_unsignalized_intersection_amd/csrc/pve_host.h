@@ -234,4 +234,5 @@ struct pve_handle_s {
     bool has_actor;                   // pve_set_actor installed an actor in the workspace
     int stop_phase;                   // pve_debug_stop_phase (diagnostics), -1 = off
     unsigned q_done_base;             // persistent roll-out: items completed per intersection since pve_reset (cumulative)
+    int last_launch_kind;             // PVE_LAUNCH_*: what the last stepping call launched (pve_debug_last_launch)
 };

@@ -162,6 +162,17 @@ struct RolloutArgs {
     unsigned long long *q_trace; // diagnostics (pve_debug_phase_cycles armed): [chunk][env][8] timestamps of every item, or null
 };
 
+// Item `chunk` of a persistent call -> its first tick within the call and its length (the schedule pve_step_many lays out:
+// n_full items of n_ticks ticks, then the taper).  Shared by the kernel's dequeue (q_take) and the test emulator, which runs
+// the items sequentially, so the schedule arithmetic of pve_capi.inc is under CPU parity as well.
+template <typename RA>
+PVE_HD void rollout_item(const RA &R, int chunk, int &k_base, int &n_ticks)
+{
+    k_base = (chunk < R.n_full ? chunk : R.n_full) * R.n_ticks;
+    for (int q = 0; q < chunk - R.n_full; q++) k_base += R.taper[q];                  // (uniform: scalar loop over <= 7 entries)
+    n_ticks = chunk < R.n_full ? R.n_ticks : (int)R.taper[chunk - R.n_full];
+}
+
 // Work queue of the persistent roll-out (device words, zero between launches: the last workgroup to leave clears them).
 // done[e] (behind this block) counts the items of intersection e completed since pve_reset, cumulatively (wrap-safe compares).
 constexpr int QUEUE_MAX_SHARDS = 16;

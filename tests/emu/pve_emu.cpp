@@ -48,7 +48,9 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
 }
 
 // k_rollout: the resident multi-tick form, phase by phase exactly as the kernel orders them
-template <int CAP> static void emu_rollout(const Const &c, const Params &P, const RolloutArgs &R)
+// k_base: first tick of this launch / queue item within the call's output blocks (0 for a chunked launch, whose Params are
+// shifted to its first block already; the item's first tick for the sequentially emulated work queue)
+template <int CAP> static void emu_rollout(const Const &c, const Params &P, const RolloutArgs &R, int k_base = 0)
 {
     typedef Tick<CAP> T;
     std::vector<Regs> regs(CAP);
@@ -95,7 +97,7 @@ template <int CAP> static void emu_rollout(const Const &c, const Params &P, cons
             for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_keep_prefix(t, sh);
             if (!idt) for (int t = 0; t < CAP; t++) T::ph_park_action(t, sh, regs[t]);
-            const Outputs O = T::tick_outputs(P, R, k);
+            const Outputs O = T::tick_outputs(P, R, k_base + k);
             for (int t = 0; t < CAP; t++)
                 T::template ph_final<true>(c, P, O, env, t, sh, regs[t], fcs[t], k + 1 == R.n_ticks || O.state_pre != nullptr);
             if (idt) for (int t = 0; t < CAP; t++) if (fcs[t].new_slot >= 0) sh.act_next[fcs[t].new_slot] = regs[t].act_nx;
@@ -155,7 +157,7 @@ template <int CAP> static void emu_tick_geo(const GeoConst &g, const Params &P)
 }
 
 // k_rollout_geo: the resident multi-tick form of the general-geometry tick, phase by phase as the kernel orders them
-template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &P, const RolloutArgs &R)
+template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &P, const RolloutArgs &R, int k_base = 0)
 {
     typedef TickGeo<CAP> T;
     typedef Tick<CAP, SharedGeo<CAP>> B;
@@ -206,7 +208,7 @@ template <int CAP> static void emu_rollout_geo(const GeoConst &g, const Params &
             for (int t = 0; t < CAP; t++) T::ph_lists_clear(t, sh);
             for (int t = 0; t < CAP; t++) B::ph_prefetch_arrival(P, env, t, sh, regs[t], g.lane_num);
             for (int t = 0; t < CAP; t++) B::ph_lock_slot(g.base, t, sh, regs[t]);
-            const Outputs O = B::template tick_outputs<true>(P, R, k);
+            const Outputs O = B::template tick_outputs<true>(P, R, k_base + k);
             if (O.state_pre) for (int t = 0; t < CAP; t++) T::ph_state_order(t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) B::ph_lock2_slot(t, sh, regs[t]);
             for (int t = 0; t < CAP; t++)
@@ -261,33 +263,51 @@ struct Backend {
         if (cap == 64) emu_tick<64>(c, P); else emu_tick<128>(c, P);
         return 0;
     }
-    static int launch_rollout(const Const &c, const Params &P_in, const RolloutArgs &R, int cap, void *, std::string &)
+    // The persistent form (R.queue): the kernel's workgroups pull (intersection, chunk) items from a queue; here the items run
+    // sequentially, chunk-major -- same item schedule (rollout_item), same first tick / pool row / output block per item, so the
+    // schedule arithmetic of pve_capi.inc is under CPU parity.
+    template <typename G, typename F>
+    static int run_launch(const G &g, const Params &P_in, const RolloutArgs &R, int cap, F emu)
     {
-        if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2) return 1;
-        if (R.queue) return 1;    // the persistent form is a launch shape of the HIP library; the emulator runs the chunked one
         Params P = P_in;
         RolloutArgs Rk = R;
-        if (R.source == 1) {
-            Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
-            P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
-        } else P.actions = nullptr;
-        if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
-        if (cap == 64) emu_rollout<64>(c, P, Rk); else emu_rollout<128>(c, P, Rk);
+        if (!R.queue) {
+            if (R.source == 1) {
+                Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
+                P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
+            } else P.actions = nullptr;
+            if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
+            emu(g, P, Rk, 0);
+            return 0;
+        }
+        for (int chunk = 0; chunk < R.n_full + R.n_taper; chunk++) {
+            int kb, nt;
+            rollout_item(R, chunk, kb, nt);
+            if (nt < 1 || kb + nt > R.call_ticks) return -1;
+            Rk.n_ticks = nt;
+            Rk.pool_tick0 = (R.source == 1 || R.source == 3) ? (R.pool_tick0 + kb) % R.n_pool : 0;
+            P.actions = R.source == 1 ? R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap : nullptr;
+            emu(g, P, Rk, kb);
+        }
         return 0;
     }
-    static int launch_rollout_geo(const GeoConst &g, const Params &P_in, const RolloutArgs &R, int cap, void *, std::string &)
+    static int launch_rollout(const Const &c, const Params &P_in, const RolloutArgs &R, int cap, void *, std::string &err)
+    {
+        if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2) return 1;
+        const int rc = run_launch(c, P_in, R, cap, [&](const Const &cc, const Params &P, const RolloutArgs &Rk, int kb) {
+            if (cap == 64) emu_rollout<64>(cc, P, Rk, kb); else emu_rollout<128>(cc, P, Rk, kb); });
+        if (rc < 0) err = "emulated work queue: inconsistent item schedule";
+        return rc;
+    }
+    static int launch_rollout_geo(const GeoConst &g, const Params &P_in, const RolloutArgs &R, int cap, void *, std::string &err)
     {
         const bool train = P_in.out.obs_pre || P_in.out.state_pre;
-        if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2 || R.queue || (train && R.source == 3)) return 1;
-        Params P = P_in;
-        RolloutArgs Rk = R;
-        if (R.source == 1) {
-            Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
-            P.actions = R.pool + (size_t)Rk.pool_tick0 * (size_t)P.n_envs * (size_t)cap;
-        } else P.actions = nullptr;
-        if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
-        if (cap == 64) emu_rollout_geo<64>(g, P, Rk); else emu_rollout_geo<128>(g, P, Rk);
-        return 0;
+        if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2 || (train && R.source == 3)) return 1;
+        if (R.queue && (train || R.source == 3)) return 1;                    // (as the HIP backend: pool / zero sources)
+        const int rc = run_launch(g, P_in, R, cap, [&](const GeoConst &gg, const Params &P, const RolloutArgs &Rk, int kb) {
+            if (cap == 64) emu_rollout_geo<64>(gg, P, Rk, kb); else emu_rollout_geo<128>(gg, P, Rk, kb); });
+        if (rc < 0) err = "emulated work queue: inconsistent item schedule";
+        return rc;
     }
     static int launch_compact(const Params &P, int cap, void *, std::string &)
     {

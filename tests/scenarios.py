@@ -536,9 +536,14 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
     for n in chunks:
         for _ in range(n):
             o1 = single()
-        o2 = many.step_many(n, source=source, chunk=(0 if n < 6 else (n // 3 + 1)), persistent=persistent)     # also in several launches
+        ch = 0 if n < 6 else (n // 3 + 1)
+        o2 = many.step_many(n, source=source, chunk=ch, persistent=persistent)     # also in several launches
         one.synchronize(); many.synchronize()
         assert many.ticks == one.ticks
+        # which path ran (a regressed eligibility test would silently fall back to chunked launches and still pass)
+        want = "persistent" if (persistent and ch > 0 and n > ch and not (backend == "emu" and source == "actor")) else \
+            ("tick" if (backend == "emu" and source == "actor") else "resident")
+        assert many.last_launch() == want, (many.last_launch(), want, source, n)
         batches_equal(one, many, "%s, chunk of %d" % (source, n))
         same_outputs(o1, o2, "%s, chunk of %d" % (source, n))
     # trajectory mode: every tick's outputs
@@ -624,7 +629,10 @@ def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chun
     for n in chunks:
         for _ in range(n):
             o1 = single()
-        o2 = many.step_many(n, source=source, chunk=(0 if n < 6 else (n // 3 + 1)), persistent=persistent)
+        ch = 0 if n < 6 else (n // 3 + 1)
+        o2 = many.step_many(n, source=source, chunk=ch, persistent=persistent)
+        want = "persistent" if (persistent and ch > 0 and n > ch and source != "table") else "resident"
+        assert many.last_launch() == want, (many.last_launch(), want, source, n)
         one.synchronize(); many.synchronize()
         batches_equal(one, many, "lane_num %d, chunk of %d" % (lane_num, n))
         same_outputs(o1, o2, "lane_num %d, chunk of %d" % (lane_num, n))

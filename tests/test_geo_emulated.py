@@ -94,3 +94,9 @@ def test_emulated_step_many_geo_emits_training_states(lane_num, cap, dtype, chun
 def test_emulated_step_many_geo_table_source(lane_num, cap):
     """PVE_SRC_TABLE for the 4- / 8-lane layouts (k_rollout_geo<.., IDT>) == single ticks with the table applied per tick."""
     scenarios.check_step_many_geo(BACKEND, lane_num, n_envs=3, capacity=cap, chunks=(1, 7, 40, 3), trajectory_chunk=8, source="table")
+
+
+@pytest.mark.parametrize("lane_num,cap", [(8, 128), (4, 64)])
+def test_geo_work_queue_item_schedule_emulated(lane_num, cap):
+    """The persistent form of the general-geometry roll-out through the emulator's sequential work queue."""
+    scenarios.check_step_many_geo(BACKEND, lane_num, n_envs=3, capacity=cap, chunks=(1, 7, 40, 20), trajectory_chunk=8, persistent=True)

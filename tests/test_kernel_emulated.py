@@ -141,3 +141,12 @@ def test_emulated_step_many_symmetric_lanes_equal_distances():
     """Runs of equal virtual distances (lanes that spawn in the same tick, zero actions) through the resident loop."""
     arr = scenarios.symmetric_arrivals(2, gap_s=3.4, rows=40, lane_groups=[[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]])
     scenarios.check_step_many(BACKEND, "zero", n_envs=2, chunks=(1, 30, 90), trajectory_chunk=10, arrivals=arr)
+
+
+@pytest.mark.parametrize("source,cap,rate", [("pool", 128, 1100.0), ("zero", 128, 1100.0), ("table", 128, 1100.0), ("pool", 64, 420.0)])
+def test_work_queue_item_schedule_emulated(source, cap, rate):
+    """pve_rollout.persistent through the emulator: the item schedule pve_step_many lays out (full items, taper, 3-tick tail;
+    k_base / pool row / table row / trajectory block per item) run sequentially, item by item, with the kernel's own
+    rollout_item() -- == single ticks bit for bit, and the persistent path IS the one taken (pve_debug_last_launch)."""
+    scenarios.check_step_many(BACKEND, source, n_envs=3, capacity=cap, rate=rate, chunks=(1, 7, 40, 20, 9, 33), trajectory_chunk=12,
+                              persistent=True, seed=29)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Same-process A/B of launch shapes for a short call (default 20 ticks, the driver's timed region): the persistent
 work-queue launch with several item schedules against the two stream-pipelined sub-batches, alternating, median of R
-repetitions.  Diagnostics only (PVE_TAPER_TAIL is the library's A/B knob for the item schedule)."""
+repetitions.  Diagnostics only.  PVE_TAPER_TAIL is an A/B knob of the KNOB build of the library (the product library
+reads no environment variable on its launch path): `make -C pve-mcc_for_unsignalized_intersection_amd/csrc knobs`, then
+PVE_LIBRARY_PATH=build/libpveenv_knobs.so python tools/ab_launch_shapes.py."""
 import os
 import sys
 import time

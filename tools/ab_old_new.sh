@@ -6,9 +6,10 @@
 #   bash tools/ab_old_new.sh "<args>|<args>|..." [reps] [lib ...]     libs default to build/libpveenv_old.so
 B="python bench.py --no-cpu-baseline --no-copy-peak --no-companion --no-verify"
 IFS='|' read -ra SHAPES <<< "${1:-}"
-REPS=${2:-3}; shift 2 2>/dev/null
+REPS=${2:-3}
+[ $# -ge 2 ] && shift 2 || shift $#          # (only the arguments that are present)
 LIBS=("$@"); [ ${#LIBS[@]} -eq 0 ] && LIBS=(build/libpveenv_old.so)
-us() { tail -1 | python -c "import json,sys; print('%.2f' % (json.loads(sys.stdin.read())['ms_per_step'] * 1e3))"; }
+us() { grep "^{" | tail -1 | python -c "import json,sys; print('%.2f' % (json.loads(sys.stdin.read())['ms_per_step'] * 1e3))"; }
 for a in "${SHAPES[@]}"; do
   for rep in $(seq 1 "$REPS"); do
     for l in "${LIBS[@]}"; do echo -n "$(basename $l .so | sed s/libpveenv_//) $(PVE_LIBRARY_PATH=$PWD/$l $B $a 2>/dev/null | us) "; done

@@ -15,7 +15,8 @@ B="python bench.py --no-cpu-baseline --no-copy-peak --no-companion"
 time_shape() {   # $1 = bench args, $2 = reps
   local args="$1" reps="${2:-3}" rep out rc
   for rep in $(seq 1 "$reps"); do
-    out=$($B $args 2>/tmp/gpu_sh_err.txt | tail -1); rc=$?
+    $B $args > /tmp/gpu_sh_out.txt 2>/tmp/gpu_sh_err.txt; rc=$?      # (bench.py's own exit code, not the tail's)
+    out=$(tail -1 /tmp/gpu_sh_out.txt)
     python - "$rc" "$out" <<'PY'
 import json, sys
 rc, line = sys.argv[1], sys.argv[2]
