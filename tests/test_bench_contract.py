@@ -48,6 +48,16 @@ def check_line(out, n, envs=12):
     assert rk["first_env"] == [envs * k for k in range(n)] and rk["envs_per_rank"] == envs      # disjoint env ranges = disjoint seeds
     assert all(ms > 0 for ms in rk["ms"]) and max(rk["ms"]) <= d["ms_per_step"] * 6 * (1 + 1e-9)
     assert r["nominal"]["alg_bytes_per_slot_step"] == 380.0 and "binding" in r
+    # multi-rank runs carry BASELINE config 4 beside the weak-scaled headline: 64-slot intersections, rank k owns the global
+    # envs shard_range(envs x n, k, n), its own barrier-bracketed timed region, MAX over ranks, one all-gather, verified
+    c4 = d.get("config4")
+    if n == 1:
+        assert c4 is None
+    else:
+        assert c4["n_gpus"] == n and c4["steps"] == 6 and c4["verified"] is True and c4["overflow"] == 0
+        assert c4["ranks"]["seen"] == n and c4["ranks"]["first_env"] == [envs * k for k in range(n)]
+        assert abs(c4["value"] - 64 * envs * n * 6 / (c4["ms_per_step"] * 6 / 1e3)) / c4["value"] < 1e-9
+        assert max(c4["ranks"]["ms"]) <= c4["ms_per_step"] * 6 * (1 + 1e-9) and "32452843" in c4["ranks"]["arrival_seeds"]
     return d
 
 
