@@ -146,6 +146,15 @@ __device__ __forceinline__ void rollout_actor(const unsigned char *packed, const
     }
 }
 
+// PVE_SRC_TABLE: table[row][min(id, table_ids - 1)] -- a UNIFORM 64-bit row base plus a 32-bit lane offset (the `saddr + voffset`
+// form of a global load; the plain index is a sign extension + 64-bit multiply-add per lane); the unsigned minimum also clamps a
+// negative id (an empty slot, whose value is never used)
+__device__ __forceinline__ double table_action(const double *table, int row, int table_ids, int id)
+{
+    const unsigned col = (unsigned)id < (unsigned)table_ids ? (unsigned)id : (unsigned)(table_ids - 1);
+    return *(const double *)((const char *)(table + (size_t)row * (size_t)table_ids) + col * 8u);
+}
+
 // ------------------------------------------------------------------ persistent roll-out: the work queue
 // One launch for a whole pve_step_many call: as many workgroups as the chip holds at once, each pulling (intersection,
 // chunk) items -- chunk c of intersection e = ticks [c T, (c + 1) T) of the call -- until the call is done.  Nothing waits in
@@ -293,7 +302,8 @@ template <int CAP, int WPE, bool PROF = false, bool ACT = false, bool TRAIN = fa
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout(const Const c_arg, const Params P_arg,
                                                                                                const RolloutArgs R_arg)
 {
-    static_assert(!PERS || (!PROF && !TRAIN), "the persistent form has no diagnostics / training-output variant");
+    static_assert(!PERS || !PROF, "the persistent form has no phase-cycle diagnostics variant");
+    static_assert(!(ACT && IDT), "one action source per variant");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     __shared__ Shared<CAP> sh;
@@ -378,8 +388,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         } else T::ph_load(c, P, env0_, t0_, sh, r);     // P.actions = the first tick's actions
         if constexpr (ACT) { if (!act_handed) r.act = sh.act_next[t0_]; }   // (uncontrolled slots: whatever is there, masked in S1)
         if constexpr (IDT) {                            // the first tick's action of the vehicle in this slot: table[row][id]
-            const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
-            r.act = r.alive ? R.pool[(size_t)pool_idx * (size_t)R.table_ids + idc] : 0.0;
+            r.act = r.alive ? table_action(R.pool, pool_idx, R.table_ids, r.id) : 0.0;
         }
     }
     double sp_act = 0;                                  // IDT: the action of the vehicle this lane spawns
@@ -432,13 +441,23 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         int nx = -1;
         if (k + 1 < n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
         if constexpr (IDT) {
-            const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
-            r.act_nx = (nx >= 0 && r.alive) ? R.pool[(size_t)nx * (size_t)R.table_ids + idc] : 0.0;
+            r.act_nx = (nx >= 0 && r.alive) ? table_action(R.pool, nx, R.table_ids, r.id) : 0.0;
         } else T::ph_prefetch_action(P, R, env, t, nx, r);
         T::ph_effects(c, t, sh, r);
         lds_barrier();
         PVE_PHASE_MARK(7)
         T::ph_prefetch_arrival(P, env, t, sh, r, NL);
+        bool sp_late = false;                         // IDT: the intersection is full, FIN decides who spawns (uniform, rare)
+        if constexpr (IDT) {
+            // the first action of the vehicle lane t spawns at the end of this tick: the spawn votes are complete since the
+            // barrier behind FX and, unless the intersection is full, every lane that wants to spawn does (ph_final), so its id
+            // is known HERE -- the gather flies under LOCK .. FIN instead of sitting between FIN and STAGE
+            const unsigned want = (unsigned)(sh.m_spawn[0] & 0xFFFull);
+            sp_late = __builtin_popcount(want) > CAP - sh.hd.n_alive;
+            sp_act = 0;
+            if (t < NL && nx >= 0 && !sp_late && ((want >> t) & 1u))
+                sp_act = table_action(R.pool, nx, R.table_ids, sh.hd.id_seq + __builtin_popcount(want & ((1u << t) - 1u)));
+        }
         T::ph_lock(c, t, sh, r);
         lds_barrier();
         T::ph_lock2(t, sh, r);
@@ -455,19 +474,17 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         PVE_PHASE_MARK(9)
         if constexpr (IDT) {
             if (fc.new_slot >= 0) sh.act_next[fc.new_slot] = r.act_nx;   // (act_next = xy32: dead since REWARD)
-            // the vehicle this lane spawns (id known since FIN): its first action, in flight under barrier A and STAGE
-            sp_act = 0;
-            if (fc.sp_slot >= 0 && nx >= 0) {
-                const int idc = fc.sp_id < R.table_ids ? fc.sp_id : R.table_ids - 1;
-                sp_act = R.pool[(size_t)nx * (size_t)R.table_ids + idc];
-            }
+            // (a full intersection: who spawns is known since FIN only; the gather is in flight under barrier A and STAGE)
+            if (sp_late) sp_act = (fc.sp_slot >= 0 && nx >= 0) ? table_action(R.pool, nx, R.table_ids, fc.sp_id) : 0.0;
         }
         if (fc.still) {                               // (uniform) nobody moves: the registers carry over
             T::ph_stage_header(t, sh, fc);
             T::ph_carry_over(t, sh, r, fc);
         } else {
             lds_barrier();                            // A: nobody reads the tick's work arrays any more
-            if (TRAIN && O.state_pre) T::ph_state(P, O, env, t, sh, r);   // (uniform; barrier A also orders the obs_pre rows of this tick)
+            // (uniform; barrier A also orders the obs_pre rows of this tick.  PERS: the stale rows of an item's first tick are what
+            //  ANOTHER workgroup's item stored -- block k - 1 of the trajectory --: coherent loads)
+            if (TRAIN && O.state_pre) T::template ph_state<PERS>(P, O, env, t, sh, r);
             T::ph_stage(c, t, sh, r, fc);
             if constexpr (IDT) { if (fc.sp_slot >= 0) sh.act_next[fc.sp_slot] = sp_act; }
             if constexpr (ACT) {
@@ -912,52 +929,47 @@ struct Backend {
         } else P.actions = nullptr;
         if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
         const bool train = P.out.obs_pre || P.out.state_pre;
-        if (R.queue) {                                                        // persistent form (pve_rollout.persistent)
-            if (train || (R.source == 2 && (act_off || R.exact_f32 || !R.actor_actions))) return 1;
+        const bool act = R.source == 2, idt = R.source == 3, pers = R.queue != nullptr;
+        long long grid = P.n_envs;
+        if (pers) {                                                           // persistent form (pve_rollout.persistent)
+            if (act && (act_off || R.exact_f32 || !R.actor_actions)) return 1;
 #ifdef PVE_QUEUE_TRACE
             Rk.q_trace = P.phase_cycles;                                      // (per-item timestamps: make trace)
 #else
             if (P.phase_cycles) return 1;       // pve_debug_phase_cycles armed: the chunked launches record the cycles (as the geo path does)
 #endif
             // as many workgroups as the chip holds at once (the queue needs no more; fewer when the call has fewer items)
-            long long grid = g_occ.resident(0, cap, [&](int *nb) {
+            grid = g_occ.resident(0, cap, [&](int *nb) {
                 return (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout<64, 4, false, false, false, false, true>, 64, 0)
                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout<128, 4, false, false, false, false, true>, 128, 0); }, err);
             if (grid < 0) return -1;
             const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
             if (const char *g = PVE_KNOB("PVE_PERSISTENT_GRID")) { const long long v = atoll(g); if (v > 0) grid = v; }   // A/B knob
             if (grid > items) grid = items;
-            if (R.source == 2) {                                               // the closed loop: the actor inside the persistent kernel
-                if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true, false, false, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
-                else hipLaunchKernelGGL((k_rollout<128, 4, false, true, false, false, true>), dim3((unsigned)grid), dim3(128), 0, s, c, P, Rk);
-            } else if (R.source == 3) {                                        // PVE_SRC_TABLE (same register budget: same residency)
-                if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, true, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
-                else hipLaunchKernelGGL((k_rollout<128, 4, false, false, false, true, true>), dim3((unsigned)grid), dim3(128), 0, s, c, P, Rk);
-            } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, false, true>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);
-            else hipLaunchKernelGGL((k_rollout<128, 4, false, false, false, false, true>), dim3((unsigned)grid), dim3(128), 0, s, c, P, Rk);
-            return check_launch(err);
-        }
-        // the phase-cycle diagnostics exist for the default kernel only: every other variant (table, actor, training outputs)
-        // answers "no resident kernel" and the caller falls back to per-tick launches, which record the cycles
-        if (train && P.phase_cycles) return 1;
-        if (R.source == 3) {                                                  // PVE_SRC_TABLE
-            if (train || P.phase_cycles) return 1;
-            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, false, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
-            else hipLaunchKernelGGL((k_rollout<128, 4, false, false, false, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
-        } else if (R.source == 2) {
-            if (train) {
-                if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
-                else hipLaunchKernelGGL((k_rollout<128, 4, false, true, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
-            } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
-            else hipLaunchKernelGGL((k_rollout<128, 4, false, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
-        } else if (train) {
-            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, false, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
-            else hipLaunchKernelGGL((k_rollout<128, 4, false, false, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
         } else if (P.phase_cycles) {
+            // the phase-cycle diagnostics exist for the default kernel only: every other variant (table, actor, training outputs)
+            // answers "no resident kernel" and the caller falls back to per-tick launches, which record the cycles
+            if (train || idt || act) return 1;
             if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, true>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
             else hipLaunchKernelGGL((k_rollout<128, 4, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
-        } else if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4>), dim3(P.n_envs), dim3(64), 0, s, c, P, Rk);
-        else hipLaunchKernelGGL((k_rollout<128, 4>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
+            return check_launch(err);
+        }
+        // variant = capacity x action source (pool / zero, actor, id-indexed table) x training outputs x launch form
+#define PVE_ROLLOUT(ACT_, TRAIN_, IDT_, PERS_)                                                                                           \
+        do {                                                                                                                             \
+            if (cap == 64) hipLaunchKernelGGL((k_rollout<64, 4, false, ACT_, TRAIN_, IDT_, PERS_>), dim3((unsigned)grid), dim3(64), 0, s, c, P, Rk);  \
+            else hipLaunchKernelGGL((k_rollout<128, 4, false, ACT_, TRAIN_, IDT_, PERS_>), dim3((unsigned)grid), dim3(128), 0, s, c, P, Rk);          \
+        } while (0)
+#define PVE_ROLLOUT_SRC(TRAIN_, PERS_)                                                                                                   \
+        do {                                                                                                                             \
+            if (act) PVE_ROLLOUT(true, TRAIN_, false, PERS_);                                                                            \
+            else if (idt) PVE_ROLLOUT(false, TRAIN_, true, PERS_);                                                                       \
+            else PVE_ROLLOUT(false, TRAIN_, false, PERS_);                                                                               \
+        } while (0)
+        if (train) { if (pers) PVE_ROLLOUT_SRC(true, true); else PVE_ROLLOUT_SRC(true, false); }
+        else { if (pers) PVE_ROLLOUT_SRC(false, true); else PVE_ROLLOUT_SRC(false, false); }
+#undef PVE_ROLLOUT_SRC
+#undef PVE_ROLLOUT
         return check_launch(err);
     }
     static int launch_rollout_geo(const GeoConst &g, const Params &P_in, const RolloutArgs &R, int cap, void *stream, std::string &err)

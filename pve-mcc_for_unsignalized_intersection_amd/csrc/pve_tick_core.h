@@ -1886,7 +1886,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // neighbour precedes us in (lane, j) order ("fresh", read back from obs_pre written in FIN), else
     // the row it stored last tick ("stale", obs_prev_post at the same slot); zeros when absent (ref :1335).
     // Runs after a workgroup barrier + fence so that obs_pre rows of the other threads are visible.
-    template <class ROW, class OutT>
+    // COH: the stale rows may have been stored by ANOTHER workgroup of this launch (persistent roll-out, first tick of an
+    // item: block k - 1 of the trajectory belongs to the previous item of the intersection): coherent loads
+    template <class ROW, bool COH, class OutT>
     static PVE_HD void state_rows(const OutT &O, size_t base, const Regs &r)
     {
         const int sl = r.ds;
@@ -1898,16 +1900,21 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const int x = r.kr[q];
             ROW *row = dst + (q + 1) * OBSW;
             if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = (ROW)0; continue; }
+            if (COH && !(x < sl)) {
+                const ROW *src = prev + (base + x) * OBSW;
+                for (int k = 0; k < OBSW; k++) row[k] = gld<true>(src + k);
+                continue;
+            }
             const ROW *src = (x < sl) ? (pre + (base + x) * OBSW) : (prev + (base + x) * OBSW);
             for (int k = 0; k < OBSW; k++) row[k] = src[k];
         }
     }
-    template <class OutT>
+    template <bool COH = false, class OutT>
     static PVE_HD void ph_state(const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh, Regs &r)
     {
         if (!O.state_pre || !r.dctl) return;              // (dense mapping: the rows of the vehicle in slot ds)
-        if (P.obs_f32) state_rows<float>(O, (size_t)env * CAP, r);
-        else state_rows<double>(O, (size_t)env * CAP, r);
+        if (P.obs_f32) state_rows<float, COH>(O, (size_t)env * CAP, r);
+        else state_rows<double, COH>(O, (size_t)env * CAP, r);
     }
     static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r) { ph_state(P, P.out, env, t, sh, r); }
 

@@ -653,13 +653,16 @@ def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chun
 
 
 def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=None, calls=(40, 25, 60, 35), seed=81, n_pool=7,
-                               obs_dtype=torch.float64, chunk=0, source="pool", min_ctl_per_tick=5, lane_num=12):
+                               obs_dtype=torch.float64, chunk=0, source="pool", min_ctl_per_tick=5, lane_num=12, persistent=False):
     """Training outputs on the fast path (lane_num 4 / 8: f3 x f4):
     pve_step_many trajectory roll-outs with state_pre -- the 7 x 28 states with fresh / stale neighbour rows (ref
     :1325-1337) and the 7-action vectors (column 2, ref :290) -- compared with the oracle at EVERY tick of every env (ids,
     neighbours, rewards, row 0, full state), across call boundaries (the first tick of a call reads the rows the previous
     call stored) and chunked launches.  float32 rows: the same within float32 round-off of the stored rows.  The 4- / 8-lane
-    layouts process (and list) the vehicles in (lane, intention, j) order (ref :233-275)."""
+    layouts process (and list) the vehicles in (lane, intention, j) order (ref :233-275).
+    persistent=True (round 5; lane_num 12): the trainer's roll-out through the work queue -- k_rollout<.., TRAIN, PERS>: the stale
+    rows of an item's first tick are what the previous item of the intersection (another workgroup) stored.
+    source="table": actions by (tick, vehicle id) (k_rollout<.., TRAIN, IDT>)."""
     from pve_mcc_amd import _capi
     from pve_mcc_amd.arrivals import synthetic_intentions
     rng = np.random.default_rng(seed)
@@ -674,6 +677,9 @@ def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=None, calls
     pool_np = rng.uniform(-3, 3, size=(n_pool, n_envs, capacity)).astype(np.float32).astype(np.float64)
     if source == "pool":
         b.set_action_pool(torch.as_tensor(pool_np))
+    table_np = rng.uniform(-3, 3, size=(19, 140)).astype(np.float32).astype(np.float64)      # (few columns: later ids share the last)
+    if source == "table":
+        b.set_action_table(torch.as_tensor(table_np))
     if lane_num == 12:
         oracles = [OracleEnv(arr[e]) for e in range(n_envs)]
     else:
@@ -683,14 +689,21 @@ def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=None, calls
     t, n_ctl_total = 0, 0
     ring = [b.alloc_trajectory(max(calls)) for _ in range(2)]
     for ci, n in enumerate(calls):
-        traj = b.step_many(n, source=source, trajectory=ring[ci & 1] if ci else True, chunk=chunk)
+        traj = b.step_many(n, source=source, trajectory=ring[ci & 1] if ci else True, chunk=chunk, persistent=persistent)
         b.synchronize()
+        if persistent:
+            assert b.last_launch() == ("persistent" if 0 < chunk < n else "resident"), (b.last_launch(), chunk, n)
         host = {x: _np(traj[x][:n]) for x in ("flags", "reward", "nbr", "lanej", "obs_pre", "state_pre", "env_out")}
         for k in range(n):
             for e, o in enumerate(oracles):
-                _vid, ctlm, _ = o.alive_view()
+                vid, ctlm, _ = o.alive_view()
                 na = o.n_alive
-                acts = np.where(ctlm != 0, pool_np[(t + k) % n_pool, e, :na], 0.0) if source == "pool" else np.zeros(na)
+                if source == "pool":
+                    acts = np.where(ctlm != 0, pool_np[(t + k) % n_pool, e, :na], 0.0)
+                elif source == "table":
+                    acts = np.where(ctlm != 0, table_np[(t + k) % table_np.shape[0], np.minimum(vid, table_np.shape[1] - 1)], 0.0)
+                else:
+                    acts = np.zeros(na)
                 rec = o.tick(acts, want_state=True)
                 f = host["flags"][k, e, :na].astype(np.int64)
                 lja = host["lanej"][k, e, :na].astype(np.int64)
@@ -713,6 +726,39 @@ def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=None, calls
     assert n_ctl_total >= min_ctl_per_tick * total            # (the scenario did exercise controlled vehicles)
     assert b.metrics()["overflow"] == 0
     return n_ctl_total
+
+
+def check_closed_loop_state_rows(backend, n_envs=6, capacity=128, rate=1000.0, calls=(30, 17, 40), chunk=7, seed=87,
+                                 obs_dtype=torch.float32, persistent=False):
+    """The trainer's closed-loop roll-out: pve_step_many(PVE_SRC_ACTOR, trajectory = 1) with the training outputs (obs_pre,
+    state_pre: k_rollout<.., ACT, TRAIN[, PERS]>) == step_with_actor ticks (actor launch + k_tick with its own STATE phase), bit
+    for bit: rows, 7 x 28 states, rewards, flags of every tick, and the persistent state after every call."""
+    from oracle.actor_np import flat_weights, load_weights
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=sum(calls) * 0.1 + 30, seed=seed)
+    outs = ("obs_post", "obs_pre", "state_pre", "reward", "flags", "nbr", "new_slot", "env_out")
+    one = make_batch(arr, n_envs, capacity, backend, outputs=outs, obs_dtype=obs_dtype)
+    many = make_batch(arr, n_envs, capacity, backend, outputs=outs, obs_dtype=obs_dtype)
+    w = flat_weights(load_weights())
+    n_ctl = 0
+    for b in (one, many):
+        b.reset()
+        b.set_actor(w)
+    for n in calls:
+        traj = many.step_many(n, actor=True, trajectory=True, chunk=chunk, persistent=persistent)
+        many.synchronize()
+        if persistent and backend != "emu":
+            assert many.last_launch() == ("persistent" if 0 < chunk < n else "resident"), many.last_launch()
+        for k in range(n):
+            o = one.step_with_actor()
+            f = _np(o["flags"])
+            assert np.array_equal(f, _np(traj["flags"][k])), "flags, tick %d" % k
+            ctl = (f & 2) != 0
+            n_ctl += int(ctl.sum())
+            for x in ("reward", "obs_pre", "state_pre", "nbr"):
+                assert np.array_equal(_np(o[x])[ctl], _np(traj[x][k])[ctl]), "%s, tick %d of a call of %d" % (x, k, n)
+        batches_equal(one, many, "closed-loop training roll-out, call of %d" % n)
+    assert n_ctl >= sum(calls)
+    return n_ctl
 
 
 def check_step_many_pipelined(backend, n_envs=5, n_sub=2, capacity=128, ticks=40, seed=73):

@@ -150,3 +150,16 @@ def test_work_queue_item_schedule_emulated(source, cap, rate):
     rollout_item() -- == single ticks bit for bit, and the persistent path IS the one taken (pve_debug_last_launch)."""
     scenarios.check_step_many(BACKEND, source, n_envs=3, capacity=cap, rate=rate, chunks=(1, 7, 40, 20, 9, 33), trajectory_chunk=12,
                               persistent=True, seed=29)
+
+
+@pytest.mark.parametrize("source,dtype", [("pool", torch.float64), ("table", torch.float32), ("zero", torch.float64)])
+def test_trainer_rollout_through_the_work_queue_emulated(source, dtype):
+    """Round 5: the training outputs (obs_pre, state_pre with fresh / stale neighbour rows, 7-action vectors) of persistent
+    trajectory roll-outs -- items of the emulated work queue in sequence, the stale rows of an item's first tick taken from
+    the previous item's last block -- against the oracle at every tick; PVE_SRC_TABLE with the training outputs."""
+    scenarios.check_step_many_state_rows(BACKEND, n_envs=2, calls=(30, 12, 25), chunk=7, obs_dtype=dtype, source=source, persistent=True,
+                                         min_ctl_per_tick=(1 if source == "zero" else 5))
+
+
+def test_closed_loop_training_rollout_emulated():
+    scenarios.check_closed_loop_state_rows(BACKEND, n_envs=2, calls=(12, 9), chunk=5)
