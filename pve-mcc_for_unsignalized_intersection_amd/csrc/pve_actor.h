@@ -370,14 +370,25 @@ __device__ __forceinline__ float actor_tanh3(float z)
     return 3.0f - 6.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
+// Sum of the 16 values of a lane by HALVES: (e[0..7] + e[8..15]) -> 8, -> 4, -> 2, -> 1.  Every level is a packed float32 add
+// on register pairs that are adjacent already (4 + 2 + 1 v_pk_add_f32 + 1 v_add_f32 = 8 instructions, no moves); the
+// adjacent-pair tree ((e0 + e1) + (e2 + e3)) + ... compiled to the same 8 packed adds plus ~17 v_mov_b32 that built the pairs.
+typedef float pve_v8f __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float actor_hsum16(pve_v16f e)
+{
+    const pve_v8f a = __builtin_shufflevector(e, e, 0, 1, 2, 3, 4, 5, 6, 7) + __builtin_shufflevector(e, e, 8, 9, 10, 11, 12, 13, 14, 15);
+    const pve_v4f b = __builtin_shufflevector(a, a, 0, 1, 2, 3) + __builtin_shufflevector(a, a, 4, 5, 6, 7);
+    const pve_v2f c = __builtin_shufflevector(b, b, 0, 1) + __builtin_shufflevector(b, b, 2, 3);
+    return c[0] + c[1];
+}
+
 // LayerNorm (input already centered by the centered dense kernel) + ReLU over the 64 hidden units of a vehicle, 32 of
 // them in this lane; gam / bet point at this lane's 32 parameters (lane order)
 __device__ __forceinline__ void actor_ln_relu32(pve_v16f (&v)[2], const float *gam, const float *bet)
 {
     pve_v16f e = v[0] * v[0];
     e = __builtin_elementwise_fma(v[1], v[1], e);
-    const float s = ((((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]))) +
-                     (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15]))));
+    const float s = actor_hsum16(e);
     const float rstd = __builtin_amdgcn_rsqf(actor_xsum2(s) * (1.0f / (float)ACT_H) + 1e-12f);
 #pragma unroll
     for (int m = 0; m < 2; m++) {
@@ -419,17 +430,13 @@ __device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *
     pve_v8h ah[2], al[2];                                     // operand ring
     ah[0] = actor_a_operand(A1, A2, 0, 0, o); al[0] = actor_a_operand(A1, A2, 0, 1, o);
     // ---- LayerNorm over the 28 inputs (14 + 14 of them in the two lanes; the padding entries are zeros)
-    float s0 = ((((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) +
-                (((x[8] + x[9]) + (x[10] + x[11])) + ((x[12] + x[13]) + (x[14] + x[15]))));
-    const float mean = actor_xsum2(s0) * (1.0f / (float)ACT_IN);
     pve_v16f d;
 #pragma unroll
     for (int c = 0; c < 16; c++) d[c] = x[c];
+    const float mean = actor_xsum2(actor_hsum16(d)) * (1.0f / (float)ACT_IN);
     d = d - mean;
     if (hf) { d[12] = 0.f; d[13] = 0.f; d[14] = 0.f; d[15] = 0.f; }   // features 28..31 do not exist
-    const pve_v16f e0 = d * d;
-    const float var = ((((e0[0] + e0[1]) + (e0[2] + e0[3])) + ((e0[4] + e0[5]) + (e0[6] + e0[7]))) +
-                       (((e0[8] + e0[9]) + (e0[10] + e0[11])) + ((e0[12] + e0[13]) + (e0[14] + e0[15]))));
+    const float var = actor_hsum16(d * d);
     const float rstd0 = __builtin_amdgcn_rsqf(actor_xsum2(var) * (1.0f / (float)ACT_IN) + 1e-12f);
     pve_v8h bh[4], bl[4];                                     // B operands of the current layer: K-blocks as half pairs
     {
@@ -470,9 +477,7 @@ __device__ __forceinline__ float actor_tile32(const pve_v8h *A1, const pve_v8h *
     // ---- dense 64 -> 1, 3 tanh
     pve_v16f pv = g[0] * *(const pve_v16f *)(prm + PV_W3 + (hf * 2 + 0) * 16);
     pv = __builtin_elementwise_fma(g[1], *(const pve_v16f *)(prm + PV_W3 + (hf * 2 + 1) * 16), pv);
-    const float part = ((((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
-                        (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15]))));
-    return actor_tanh3(actor_xsum2(part) + prm[PV_B3]);
+    return actor_tanh3(actor_xsum2(actor_hsum16(pv)) + prm[PV_B3]);
 }
 
 // The <= 16 raw features lane (j, hf) contracts, straight from the observation row of `slot` (float32 or float64 rows):
