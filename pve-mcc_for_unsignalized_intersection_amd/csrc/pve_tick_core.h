@@ -448,8 +448,12 @@ struct FinCarry {
     int ls;                          // t <= NL: lane_start[t] after re-pack + spawn
     int sp_slot, sp_id, sp_vnum;     // t < NL: slot / id / id_info[1] of the vehicle lane t spawns (sp_slot < 0: none)
     int sp_int;                      // general-geometry kernel: its intention (ref :382-394)
-    int n_post, n_sp, n_over, n_fin, n_ctl, n_lock, n_coll, n_pre;
-    double sr, sj;
+    // header: thread 0 adds the tick's counters and sums to the resident header IN FIN (nobody else reads those fields); only
+    // what other threads still read during FIN changes behind barrier A (ph_stage_header): n_alive and id_seq.  As members of
+    // this struct the nine counters / sums were live vector registers in EVERY lane across FIN's peak (uniform values, but
+    // LDS-derived, so the compiler keeps them per lane): the training and general-geometry variants spilled 6-110 registers.
+    int n_post, n_sp;
+    int n_ctl;                       // controlled vehicles of this tick (the actor pass of k_rollout<.., ACT>)
 };
 struct CRegs {                       // MODE_COMPACT moves every persistent field verbatim
     double p, v, a, jerk, jerk_sum, vir_dis, closer_p;
@@ -1620,21 +1624,32 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (!RES && t < NL) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
         const int n_ctl = mask_count<NW>(sh.m_ctl);
         // (the counters of the header / env_out are thread 0's business: the other wave does not count four masks for nothing)
-        fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp); fc.n_over = n_over; fc.n_fin = 0; fc.n_ctl = n_ctl;
-        fc.n_lock = 0; fc.n_coll = 0; fc.n_pre = N; fc.sr = 0; fc.sj = 0;
+        fc.n_ctl = n_ctl; fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp);
         if (t == 0) {
-            if (RES) { n_post = (int)sh.keep_pre()[sh.hd.lane_start[NL]] + __builtin_popcount(sp); fc.n_post = n_post; }
+            if (RES) n_post = (int)sh.keep_pre()[sh.hd.lane_start[NL]] + __builtin_popcount(sp);
             const int n_lock = mask_count<NW>(sh.m_lead);
             const int n_fin = mask_count<NW>(sh.m_fin);
             const int n_del = mask_count<NW>(sh.m_del);
-            fc.n_fin = n_fin; fc.n_lock = n_lock; fc.n_coll = mask_count<NW>(sh.m_coll);
+            const int n_coll = mask_count<NW>(sh.m_coll);
             double sr = 0, sj = 0;
 #if PVE_DEVICE_CODE
             for (int k = 0; k < NW; k++) { sr += sh.red_reward[k]; sj += sh.red_jerk[k]; }
 #else
             sr = sh.red_reward[0]; sj = sh.red_jerk[0];
 #endif
-            fc.sr = sr; fc.sj = sj;
+            if (RES) {
+                fc.n_post = n_post;
+                sh.hd.passed += n_fin;                                                // ref :356
+                sh.hd.passed_step_total += sh.acc_passed_steps;                       // ref :359
+                sh.hd.sum_reward = sh.hd.sum_reward + sr;
+                sh.hd.sum_jerk = sh.hd.sum_jerk + sj;
+                sh.hd.alive_steps += N;
+                sh.hd.ctl_steps += n_ctl;
+                sh.hd.ticks += 1;
+                sh.hd.collided += n_coll;
+                sh.hd.locks += n_lock;
+                sh.hd.overflow += n_over;
+            }
             if (!RES) {
                 gh.current_time = sh.hd.current_time;
                 gh.n_alive = n_post;
@@ -1647,7 +1662,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                 gh.alive_steps = sh.hd.alive_steps + N;
                 gh.ctl_steps = sh.hd.ctl_steps + n_ctl;
                 gh.ticks = sh.hd.ticks + 1;
-                gh.collided = sh.hd.collided + fc.n_coll;
+                gh.collided = sh.hd.collided + n_coll;
                 gh.locks = sh.hd.locks + n_lock;
                 gh.overflow = sh.hd.overflow + n_over;
             }
@@ -1811,22 +1826,12 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (t <= NL) sh.hd.lane_start[t] = fc.ls;
         ph_stage_header(t, sh, fc);
     }
-    // the accumulators of the header: only thread 0 reads or writes them, so a still tick needs no barrier around this
+    // n_alive and id_seq: what the other threads still read during FIN (a still tick changes neither, but the call is harmless)
     static PVE_HD void ph_stage_header(int t, Sh &sh, const FinCarry &fc)
     {
-        if (t == 0) {
+        if (t == 0) {                                     // (the accumulators went in FIN)
             sh.hd.n_alive = fc.n_post;
             sh.hd.id_seq += fc.n_sp;
-            sh.hd.passed += fc.n_fin;                                             // ref :356
-            sh.hd.passed_step_total += sh.acc_passed_steps;                       // ref :359
-            sh.hd.sum_reward = sh.hd.sum_reward + fc.sr;
-            sh.hd.sum_jerk = sh.hd.sum_jerk + fc.sj;
-            sh.hd.alive_steps += fc.n_pre;
-            sh.hd.ctl_steps += fc.n_ctl;
-            sh.hd.ticks += 1;
-            sh.hd.collided += fc.n_coll;
-            sh.hd.locks += fc.n_lock;
-            sh.hd.overflow += fc.n_over;
         }
     }
     // a still tick: the vehicle stays in the registers, only the flags word and the next action change hands

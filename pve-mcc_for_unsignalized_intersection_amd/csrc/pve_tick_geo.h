@@ -921,20 +921,29 @@ template <int CAP> struct TickGeo {
         if (!RES && t < ND) { gh.head_lane[t] = sh.hd.head_lane[t]; gh.head_j[t] = sh.hd.head_j[t]; }
         const int n_ctl = mask_count<NW>(sh.m_ctl);
         // (the header's counters are thread 0's business: cf. Tick::ph_final)
-        fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp); fc.n_over = n_over; fc.n_fin = 0; fc.n_ctl = n_ctl;
-        fc.n_lock = 0; fc.n_coll = 0; fc.n_pre = N; fc.sr = 0; fc.sj = 0;
+        fc.n_ctl = n_ctl; fc.n_post = n_post; fc.n_sp = __builtin_popcount(sp);
         if (t == 0) {
             const int n_lock = mask_count<NW>(sh.m_lead);
             const int n_fin = mask_count<NW>(sh.m_fin);
             const int n_del = mask_count<NW>(sh.m_del);
-            fc.n_fin = n_fin; fc.n_lock = n_lock; fc.n_coll = mask_count<NW>(sh.m_coll);
             double sr = 0, sj = 0;
 #if PVE_DEVICE_CODE
             for (int k = 0; k < NW; k++) { sr += sh.red_reward[k]; sj += sh.red_jerk[k]; }
 #else
             sr = sh.red_reward[0]; sj = sh.red_jerk[0];
 #endif
-            fc.sr = sr; fc.sj = sj;
+            if (RES) {                                 // (the header's accumulators: cf. Tick::ph_final)
+                sh.hd.passed += n_fin;
+                sh.hd.passed_step_total += sh.acc_passed_steps;
+                sh.hd.sum_reward = sh.hd.sum_reward + sr;
+                sh.hd.sum_jerk = sh.hd.sum_jerk + sj;
+                sh.hd.alive_steps += N;
+                sh.hd.ctl_steps += n_ctl;
+                sh.hd.ticks += 1;
+                sh.hd.collided += mask_count<NW>(sh.m_coll);
+                sh.hd.locks += n_lock;
+                sh.hd.overflow += n_over;
+            }
           if (!RES) {
             gh.current_time = sh.hd.current_time;
             gh.n_alive = n_post;
@@ -1002,17 +1011,22 @@ template <int CAP> struct TickGeo {
                 row[6 + 4 * k] = (ZROW || has) ? na[k] : 0.0; row[7 + 4 * k] = (ZROW || has) ? (double)nrt[k] : 0.0;
             }
             if (O.obs_pre) {
+                // obs_pre AND obs_post in ONE pass over the row: every value goes to both rows and dies (two passes keep all 28
+                // values live across both: 44-110 spilled registers in the training variants).  A vehicle that leaves has no
+                // obs_post row: its second store rewrites the obs_pre element (same value, same address: harmless)
+                const bool wpost = O.obs_post && new_slot >= 0;
                 if (P.obs_f32) {                        // (obs_pre / state_pre follow the row type, as in the 12-lane kernels)
                     float *o = env_at<CAP * OBSW>((float *)O.obs_pre, env, t * OBSW);
+                    float *q = wpost ? env_at<CAP * OBSW>((float *)O.obs_post, env, new_slot * OBSW) : o;
 #pragma unroll
-                    for (int k = 0; k < OBSW; k++) o[k] = (float)row[k];
+                    for (int k = 0; k < OBSW; k++) { const float x = (float)row[k]; o[k] = x; q[k] = x; }
                 } else {
                     double *o = env_at<CAP * OBSW>(O.obs_pre, env, t * OBSW);
+                    double *q = wpost ? env_at<CAP * OBSW>(O.obs_post, env, new_slot * OBSW) : o;
 #pragma unroll
-                    for (int k = 0; k < OBSW; k++) o[k] = row[k];
+                    for (int k = 0; k < OBSW; k++) { o[k] = row[k]; q[k] = row[k]; }
                 }
-            }
-            if (O.obs_post && new_slot >= 0) {
+            } else if (O.obs_post && new_slot >= 0) {
                 if (P.obs_f32) {
                     float *o = env_at<CAP * OBSW>((float *)O.obs_post, env, new_slot * OBSW);
 #pragma unroll
