@@ -504,10 +504,12 @@ def run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=None, v
 
 
 def persistent_items(K, T):
-    """Items per intersection of a persistent call of K ticks with items of at most T ticks (pve_capi.inc: the ticks are
-    dealt into the fewest equal items, the call ends with one item of 3 ticks)."""
-    tail = 3 if K >= 8 and K - 3 >= 1 else 0
-    return -(-(K - tail) // T) + (1 if tail else 0)
+    """Items per intersection of a persistent call of K ticks with items of at most T ticks (pve_capi.inc: the call ends with a
+    geometric taper of 3, 6, 12 .. ticks below T, the ticks in front of it are dealt into the fewest equal items)."""
+    n_tail, left, sz = 0, K, 3
+    while K >= 8 and sz < T and n_tail < 4 and left - sz >= sz:
+        n_tail, left, sz = n_tail + 1, left - sz, sz * 2
+    return -(-left // T) + n_tail
 
 
 def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=4096):
@@ -524,10 +526,10 @@ def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=
         gives the queue nothing to balance)."""
     if lane_num == 12 and not actor and n_envs >= 4096:     # (the queue balances a batch of >= 2x the workgroups the chip holds)
         if cap == 128:
-            return 1, 10, True           # (a 20-tick call becomes items of 9, 8 and 3 ticks)
+            return 1, (12 if K < 100 else 10), True      # (a 20-tick call becomes items of 11, 6 and 3 ticks)
         return 1, 0, False
     if lane_num == 12 and actor and cap == 128 and n_envs >= 4096:
-        return 1, (25 if K >= 100 else 10), True     # closed loop: 34.6 against 35.9 us per tick (long call), 41.7 against 43.6 (20 ticks)
+        return 1, (25 if K >= 100 else 12), True     # closed loop: 34.6 against 35.9 us per tick (long call), 41.7 against 43.6 (20 ticks)
     if lane_num != 12 and cap == 128 and not actor and not table and n_envs >= 4096 and K >= 100:
         return 1, 10, True          # 8 lanes: 37.0 against 38.2 us per tick, 4 lanes x 128: 36.5 against 41.7; 20 ticks: no gain (2 streams)
     return 2, ((25 if K >= 100 else 5) if cap == 128 else 0), False

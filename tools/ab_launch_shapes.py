@@ -30,16 +30,12 @@ for e in (one, two):
     e.set_action_pool(pool)
 torch.cuda.synchronize()
 variants = [("2 streams, launches of 5", two, dict(chunk=5), None),
-            ("2 streams, launches of 10", two, dict(chunk=10), None),
-            ("persistent 5,5,5,5", one, dict(chunk=5, persistent=True), ""),
-            ("persistent 7,7,6", one, dict(chunk=7, persistent=True), ""),
-            ("persistent 10,10", one, dict(chunk=10, persistent=True), ""),
-            ("persistent 6,6,5 + 3", one, dict(chunk=6, persistent=True), "3"),
-            ("persistent 8,7 + 3,2", one, dict(chunk=8, persistent=True), "3,2"),
-            ("persistent 6,6,6 + 2", one, dict(chunk=6, persistent=True), "2"),
             ("persistent 9,8 + 3", one, dict(chunk=9, persistent=True), "3"),
-            ("persistent 6,6,4 + 4", one, dict(chunk=6, persistent=True), "4"),
             ("one launch of 4096 x 20", one, dict(chunk=0), None)]
+# more item schedules: AB_SHAPES="12:5,3;10:6,4;..." = chunk_ticks : PVE_TAPER_TAIL (knob build of the library)
+for spec in filter(None, os.environ.get("AB_SHAPES", "12:5,3;11:6,3;14:3,3;17:3;7:;6:3").split(";")):
+    ch, tail = spec.split(":")
+    variants.insert(-1, ("persistent chunk %s + tail [%s]" % (ch, tail), one, dict(chunk=int(ch), persistent=True), tail))
 calls = {}
 
 
