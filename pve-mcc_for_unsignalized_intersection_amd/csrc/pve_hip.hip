@@ -470,7 +470,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             adst = -1;
             T::template ph_final<true>(c, P, O, env, t, sh, r, fc, true, &adst);
             adsts[t] = (uint8_t)(adst < 0 ? 255 : adst);  // (dense thread t; threads >= n_ctl: 255)
-        } else T::template ph_final<true, !TRAIN && !IDT>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
+        } else T::template ph_final<true, !TRAIN>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
         PVE_PHASE_MARK(9)
         if constexpr (IDT) {
             if (fc.new_slot >= 0) sh.act_next[fc.new_slot] = r.act_nx;   // (act_next = xy32: dead since REWARD)
