@@ -984,7 +984,7 @@ def main(argv=None, env_factory=None):
         if args.actor:
             kname += " with the actor inside (ACT)" if mode == "rollout" else " + k_actor_h"
         # (another kernel variant than the profiled one: the committed counter passes are those of the default = id-sin command)
-        other = args.actor or lane_num != 12 or args.obs_f32 or traj_on or not id_sin
+        other = args.actor or lane_num != 12 or args.obs_f32 or traj_on or (mode == "rollout" and not id_sin)
         pkey = (("persist" if K >= 100 else "persist_short") if pers else None)
         tr, traffic_src = (None, None) if (emu or not steady) else pmc_traffic(int(envs_per_launch), cap, outputs, mode, tpl, other, pkey)
         traffic = tr["hbm_bytes_per_launch"] if tr else None

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON the MI355X box (through gpurun) to collect every measurement that profiles/ summarises.
-# Usage: gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r4'   then   python tools/make_profile_summaries.py gpurun_out/r4 r04
+# Usage: gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r5'   then   python tools/make_profile_summaries.py gpurun_out/r5 r05
+# (the default bench command = BASELINE.md 3's id-indexed tape: k_rollout<128, 4, false, false, false, true, true>)
 set -u
 R=${1:-r4}
 export TMPDIR=/tmp
@@ -26,8 +27,8 @@ run bench_actor_f64.json $NB --actor --obs-f64
 run bench_actor_step.json $NB --actor --mode step
 run bench_actor_driver_like.json $NB --actor --steps 20 --warmup 5
 run bench_trajectory.json $NB --trajectory 1
-run bench_id_sin.json $NB --tape id-sin
-run bench_id_sin_driver_like.json $NB --tape id-sin --steps 20 --warmup 5
+run bench_pool.json $NB --tape pool
+run bench_pool_driver_like.json $NB --tape pool --steps 20 --warmup 5
 run bench_lanes8.json $B --lane-num 8 --steps 300
 run bench_lanes8_step.json $NB --lane-num 8 --steps 300 --pipeline 3 --mode step
 run bench_lanes4.json $B --lane-num 4 --capacity 64 --rate 1200 --steps 300
@@ -71,8 +72,10 @@ python tools/phase_profile.py --ticks 100 --many > $O/phase_profile_rollout.txt 
 python tools/phase_profile.py --ticks 100 --many --capacity 64 > $O/phase_profile_rollout_cap64.txt 2>&1
 python tools/phase_profile.py --ticks 100 --lane-num 8 > $O/phase_profile_lanes8.txt 2>&1
 python tools/phase_profile.py --ticks 100 --lane-num 4 --capacity 64 --rate 1200 > $O/phase_profile_lanes4.txt 2>&1
-python tools/ab_launch_shapes.py 2>&1 | grep -v amdgpu.ids > $O/ab_launch_shapes.txt
-AB_CAP=64 python tools/ab_launch_shapes.py 2>&1 | grep -v amdgpu.ids > $O/ab_launch_shapes_cap64.txt
+# (the item-schedule variants need the knob build: PVE_TAPER_TAIL; the product library ignores the variable)
+make -s -C pve-mcc_for_unsignalized_intersection_amd/csrc knobs > /dev/null 2>&1 && {
+  PVE_LIBRARY_PATH=$(pwd)/build/libpveenv_knobs.so AB_SHAPES="12:6,3;12:5,3;13:5,2;9:3;6:3;17:3;14:3,3;10:;5:;12:5,2,1" python tools/ab_launch_shapes.py 2>&1 | grep -v amdgpu.ids > $O/ab_launch_shapes.txt
+  PVE_LIBRARY_PATH=$(pwd)/build/libpveenv_knobs.so AB_CAP=64 AB_SHAPES="12:6,3;17:3;19:;15:5;10:6,4" python tools/ab_launch_shapes.py 2>&1 | grep -v amdgpu.ids > $O/ab_launch_shapes_cap64.txt; }
 # ---- per-item timeline of one persistent call (diagnostics build of the library: -DPVE_QUEUE_TRACE)
 make -s -C pve-mcc_for_unsignalized_intersection_amd/csrc trace > /dev/null 2>&1 && \
   PVE_LIBRARY_PATH=$(pwd)/build/libpveenv_trace.so python tools/persistent_trace.py 2>&1 | grep -v amdgpu.ids > $O/persistent_trace.txt

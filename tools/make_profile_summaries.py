@@ -83,9 +83,10 @@ try:
     clk = shader_clock(os.path.join(src, "phase_profile_rollout.txt"))
     # (tag, kernel name prefix, profile key, ticks of the counted launch, envs per launch, which launch)
     for tag, kkey, mode, tpl, envs, field in (
-            ("persist", "void k_rollout<128, 4, false, false, false, false, true>", "persist", 100, 4096, "last"),
-            ("persist_short", "void k_rollout<128, 4, false, false, false, false, true>", "persist_short", 20, 4096, "last"),
-            ("rollout", "void k_rollout<128, 4, false, false, false, false, false>", "rollout", 25, 2048, "mean/launch"),
+            # (the default command gathers BASELINE.md 3's tape by vehicle id: the IDT variants)
+            ("persist", "void k_rollout<128, 4, false, false, false, true, true>", "persist", 100, 4096, "last"),
+            ("persist_short", "void k_rollout<128, 4, false, false, false, true, true>", "persist_short", 20, 4096, "last"),
+            ("rollout", "void k_rollout<128, 4, false, false, false, true, false>", "rollout", 25, 2048, "mean/launch"),
             ("step", "void k_tick<128>", "step", 1, 2048, "mean/launch"),
             ("actor", "void k_rollout<128, 4, false, true, false, false, true>", "actor_persist", 100, 4096, "last")):
         f = os.path.join(src, "pmc_sq_%s.txt" % tag)

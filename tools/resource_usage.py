@@ -30,9 +30,9 @@ def collect():
 
 if __name__ == "__main__":
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
-    print("%-44s %5s %5s %6s %6s %8s %7s %5s" % ("kernel", "VGPR", "AGPR", "vspill", "sspill", "scratch", "LDS", "occ"))
+    print("%-62s %5s %5s %6s %6s %8s %7s %5s" % ("kernel", "VGPR", "AGPR", "vspill", "sspill", "scratch", "LDS", "occ"))
     for r in collect():
         if flt in r["name"]:
-            print("%-44s %5d %5d %6d %6d %8d %7d %5d" % (r["name"][:44], r.get("VGPRs", -1), r.get("AGPRs", -1),
+            print("%-62s %5d %5d %6d %6d %8d %7d %5d" % (r["name"][:62], r.get("VGPRs", -1), r.get("AGPRs", -1),
                   r.get("VGPRs Spill", -1), r.get("SGPRs Spill", -1), r.get("ScratchSize [bytes/lane]", -1),
                   r.get("LDS Size [bytes/block]", -1), r.get("Occupancy [waves/SIMD]", -1)))

@@ -51,7 +51,8 @@ for k in range(a.runs):
 print("%d runs: %d green, %d ended at a deferred spawn, 0 differences" % (a.runs, ok, stopped))
 # pve_step_many (k_rollout: still ticks, staged ticks, chunked launches, trajectory outputs) == single ticks, bit for bit
 for k in range(a.many):
-    kind = str(rng.choice(["k_rollout", "k_rollout", "actor", "geo", "geo", "state", "persistent", "persistent", "geo_state", "geo_table"]))
+    kind = str(rng.choice(["k_rollout", "k_rollout", "actor", "geo", "geo", "state", "persistent", "persistent", "geo_state", "geo_table",
+                           "state_pers", "state_pers", "closed_state"]))
     seed = int(rng.integers(1, 1 << 30))
     t0 = time.time()
     if kind in ("k_rollout", "actor"):
@@ -76,6 +77,29 @@ for k in range(a.many):
         scenarios.check_step_many(a.backend, src, n_envs=n_envs, capacity=cap, rate=rate, prefill=int(rng.choice([0, 150])),
                                   chunks=chunks, trajectory_chunk=int(rng.integers(2, 30)), seed=seed, persistent=True)
         what = "cap %3d rate %6.0f %s chunks %s x %3d envs (persistent)" % (cap, rate, src, chunks, n_envs)
+    elif kind == "state_pers":                                  # round 5: the trainer's roll-out through the work queue, pool / zero / table sources
+        import torch
+        dt = torch.float32 if rng.random() < 0.5 else torch.float64
+        cap = int(rng.choice([64, 128, 128]))
+        lo, hi = RATES[(12, cap)]
+        rate = float(rng.uniform(lo * 1.2, hi * 0.95))
+        calls = tuple(int(x) for x in rng.integers(5, 60, size=int(rng.integers(2, 5))))
+        src = str(rng.choice(["pool", "zero", "table"]))
+        n_envs = int(rng.choice([3, 20, 70]))
+        scenarios.check_step_many_state_rows(a.backend, n_envs=n_envs, capacity=cap, calls=calls, rate=rate, seed=seed, obs_dtype=dt,
+                                             chunk=int(rng.choice([3, 7, 16])), source=src, min_ctl_per_tick=0, persistent=True)
+        what = "cap %3d state rows %s calls %s rate %6.0f %s x %2d envs (persistent)" % (cap, str(dt).split(".")[-1], calls, rate, src, n_envs)
+    elif kind == "closed_state":                                # round 5: closed loop + training outputs (k_rollout<ACT, TRAIN[, PERS]>)
+        import torch
+        cap = int(rng.choice([64, 128]))
+        lo, hi = RATES[(12, cap)]
+        rate = float(rng.uniform(lo * 1.2, hi * 0.8))
+        calls = tuple(int(x) for x in rng.integers(5, 50, size=int(rng.integers(2, 4))))
+        pers = bool(rng.random() < 0.6)
+        scenarios.check_closed_loop_state_rows(a.backend, n_envs=int(rng.choice([4, 30])), capacity=cap, rate=rate, calls=calls,
+                                               chunk=int(rng.choice([3, 7, 16])), seed=seed, persistent=pers,
+                                               obs_dtype=torch.float32 if rng.random() < 0.5 else torch.float64)
+        what = "cap %3d closed-loop state rows calls %s rate %6.0f persistent %s" % (cap, calls, rate, pers)
     elif kind in ("geo_state", "geo_table"):                    # f3 x f4 (round 4): training outputs / id-indexed table for 4 / 8 lanes
         import torch
         ln = int(rng.choice([4, 8]))
