@@ -908,6 +908,14 @@ def main(argv=None, env_factory=None):
         companion = {"what": "the same workload with every tick's outputs retained (pve_step_many trajectory = 1, calls of %d "
                              "ticks into a ring of two buffers per sub-batch)" % tl,
                      "ms_per_step": tc / K * 1e3, "value": float(cap) * n_envs * K / tc, "unit": "env-steps/s", "steps": K}
+        # ... and certified like the headline: the sampled envs replayed from reset by the oracle through ALL the ticks so far,
+        # the last tick's outputs taken from the trajectory block that holds them
+        if not args.no_verify and all(n in outputs for n in ("flags", "reward", "env_out")) and n_sub == 1:
+            n_calls = -(-K // tl)
+            last_buf, last_k = ring2[(n_calls - 1) & 1], (K - (n_calls - 1) * tl) - 1
+            cv = verify_against_oracle(locate, lambda e: {n: last_buf[n][last_k, locate(e)[1]].cpu().numpy() for n in ("flags", "reward", "env_out")},
+                                       arr, pool_np, tick[0], lane_num, choice, table_np=table_np)
+            companion.update(verified=cv["verified"], verification=cv)
         del ring2
     # ---- the slot-indexed sin pool (the headline of rounds 1-4) beside BASELINE.md 3's id-indexed tape, or the other way round
     # with --tape pool: K more ticks of the same envs under the other tape, timed outside the headline (and verified) region
@@ -949,7 +957,7 @@ def main(argv=None, env_factory=None):
     if world > 1 and lane_num == 12 and not args.no_companion and K > 0 and (mode == "rollout" or emu):
         del env
         config4 = run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=env_factory, verify=not args.no_verify)
-    ok_flag = 0.0 if (verify["verified"] is False or any(c and c["verified"] is False for c in (closed_loop, cap64, cap64_on_spec, config4))) else 1.0
+    ok_flag = 0.0 if (verify["verified"] is False or any(c and c.get("verified") is False for c in (closed_loop, cap64, cap64_on_spec, config4, companion))) else 1.0
     if world > 1:
         tv = torch.tensor([ok_flag], dtype=torch.float64, device=dev)
         dist.all_reduce(tv, op=dist.ReduceOp.MIN)
@@ -1090,7 +1098,7 @@ def main(argv=None, env_factory=None):
         dist.destroy_process_group()
     if ok_flag < 1.0:
         bad = [v.get("mismatch") for v in [verify] + [c.get("verification") or c.get("verification_rank0") or {}
-                                                      for c in (closed_loop, cap64, cap64_on_spec, config4) if c] if v.get("verified") is False]
+                                                      for c in (closed_loop, cap64, cap64_on_spec, config4, companion) if c] if v.get("verified") is False]
         sys.exit("bench.py: the timed environments do NOT match the checker (%s)" % "; ".join(str(b) for b in bad))
 
 

@@ -306,7 +306,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     static_assert(!(ACT && IDT), "one action source per variant");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
-    __shared__ Shared<CAP> sh;
+    // (WPE = 5, the 96-VGPR experiment: the block without the lane << 16 | j words is 16 368 B -> 10 workgroups per CU)
+    typedef Shared<CAP, (CAP == 128 && WPE == 4)> ShT;
+    __shared__ ShT sh;
     __shared__ __attribute__((aligned(64))) float aprm[ACT ? PV_TOTAL : 1];
     __shared__ uint8_t adsts[ACT ? CAP : 1];         // post-compaction slot of every dense thread's vehicle (255: gone)
     __shared__ int q_word[4];                       // PERS: item (env, chunk) of the workgroup + the dequeue state of lane 0
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     KernargPtr kav_ = ka0_;
     Regs r;
     FinCarry fc;
-    typedef Tick<CAP> T;
+    typedef Tick<CAP, ShT> T;
     unsigned long long pc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev_ = PROF ? wall_clock64() : 0ull;
     const unsigned long long sclk0_ = PROF ? clock64() : 0ull, wclk0_ = tprev_;   // shader clock vs the 100 MHz constant clock
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             adst = -1;
             T::template ph_final<true>(c, P, O, env, t, sh, r, fc, true, &adst);
             adsts[t] = (uint8_t)(adst < 0 ? 255 : adst);  // (dense thread t; threads >= n_ctl: 255)
-        } else T::template ph_final<true, !TRAIN>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
+        } else T::template ph_final<true, !TRAIN && WPE == 4>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
         PVE_PHASE_MARK(9)
         if constexpr (IDT) {
             if (fc.new_slot >= 0) sh.act_next[fc.new_slot] = r.act_nx;   // (act_next = xy32: dead since REWARD)
@@ -954,6 +956,20 @@ struct Backend {
             else hipLaunchKernelGGL((k_rollout<128, 4, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
             return check_launch(err);
         }
+#ifdef PVE_AB_KNOBS
+        // A/B knob: the 96-VGPR build of the headline kernel (table source, persistent form, 128 slots): 10 workgroups per CU with the
+        // 16 KB LDS block, at the price of ~30 scratch accesses per tick
+        if (getenv("PVE_ROLLOUT_WPE5") && pers && idt && !train && cap == 128) {
+            int nb = 0; hipDeviceProp_t prop; int dev = 0;
+            (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout<128, 5, false, false, false, true, true>, 128, 0);
+            long long g5 = (long long)nb * prop.multiProcessorCount;
+            const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
+            if (g5 > items) g5 = items;
+            hipLaunchKernelGGL((k_rollout<128, 5, false, false, false, true, true>), dim3((unsigned)g5), dim3(128), 0, s, c, P, Rk);
+            return check_launch(err);
+        }
+#endif
         // variant = capacity x action source (pool / zero, actor, id-indexed table) x training outputs x launch form
 #define PVE_ROLLOUT(ACT_, TRAIN_, IDT_, PERS_)                                                                                           \
         do {                                                                                                                             \
