@@ -440,24 +440,35 @@ def run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=None, v
     arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=(prefill + W + K) * 0.1 + 20.0, seed=20250213 + 32452843 + lo, lane_num=12)
     outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
     n_sub, chunk, pers = launch_shape(cap, K, 12, False, table=True, n_envs=n_envs)
-    if emu:
-        env, n_sub = env_factory(n_envs, cap, arr, outputs), 1
-    elif n_sub == 1:
-        env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs)
-    else:
-        env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=n_sub, device=dev, outputs=outputs)
-    env.reset()
-    table_np = id_sin_table(prefill + W + K + 8)
-    env.set_action_table(torch.as_tensor(table_np))
-    calls = {n: env.prepare_step_many(n, source="table", chunk=chunk, persistent=pers) for n in {prefill, W, K} if n > 0}
 
     def sync():
         if not emu:
             torch.cuda.synchronize(dev)
-    for n in (prefill, W):
-        if n > 0:
-            calls[n]()
-    sync()
+    # set-up, prefill and warm-up are local; a rank that cannot set the leg up must not leave the others waiting in a
+    # collective (nor cost the run its headline): every rank learns whether ALL ranks are ready before the timed region
+    env, table_np, calls, problem = None, None, None, None
+    try:
+        if emu:
+            env, n_sub = env_factory(n_envs, cap, arr, outputs), 1
+        elif n_sub == 1:
+            env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs)
+        else:
+            env = pve_mcc_amd.PipelinedIntersections(n_envs, cap, arr, n_sub=n_sub, device=dev, outputs=outputs)
+        env.reset()
+        table_np = id_sin_table(prefill + W + K + 8)
+        env.set_action_table(torch.as_tensor(table_np))
+        calls = {n: env.prepare_step_many(n, source="table", chunk=chunk, persistent=pers) for n in {prefill, W, K} if n > 0}
+        for n in (prefill, W):
+            if n > 0:
+                calls[n]()
+        sync()
+    except Exception as ex:                               # noqa: BLE001 (reported in the line, the headline stands)
+        problem = "%s: %s" % (type(ex).__name__, ex)
+    ready = torch.tensor([0.0 if problem else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+    if float(ready.item()) < 1.0:
+        return {"what": "BASELINE config 4 (64-slot intersections sharded over %d ranks)" % world, "skipped": True,
+                "reason": problem or "another rank could not set the leg up", "verified": None}
     dist.barrier()
     sync()
     m0 = env.metrics()
@@ -481,8 +492,11 @@ def run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=None, v
         return env.subs[k], le
     if verify:
         sync()
-        ver = verify_against_oracle(locate, lambda e: {n: locate(e)[0].out[n][locate(e)[1]].cpu().numpy() for n in ("flags", "reward", "env_out")},
-                                    arr, None, prefill + W + K, 12, None, table_np=table_np, n_sample=min(4, n_envs))
+        try:
+            ver = verify_against_oracle(locate, lambda e: {n: locate(e)[0].out[n][locate(e)[1]].cpu().numpy() for n in ("flags", "reward", "env_out")},
+                                        arr, None, prefill + W + K, 12, None, table_np=table_np, n_sample=min(4, n_envs))
+        except Exception as ex:                           # noqa: BLE001 (every rank must reach the collective below)
+            ver = dict(verified=False, mismatch="%s: %s" % (type(ex).__name__, ex))
     else:
         ver = dict(verified=None, reason="skipped (--no-verify)")
     ok = torch.tensor([0.0 if ver["verified"] is False else 1.0], dtype=torch.float64, device=dev)
