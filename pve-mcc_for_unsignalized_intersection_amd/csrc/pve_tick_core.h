@@ -1192,19 +1192,30 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         r.reward = 0; r.hit = 0; r.hdr = -1; r.djerk = 0;
 #pragma unroll
         for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
-        if (t < NL && sh.hd.lane_start[t < NL ? t + 1 : 0] > sh.hd.lane_start[t < NL ? t : 0]) {
-            // thread d < 12: lane d is non-empty -> its list was rebuilt (ref :234); head persisted for next tick's step (ref :1517)
+        // thread d < 12: lane d is non-empty -> its list was rebuilt (ref :234); head persisted for next tick's step (ref :1517).
+        // The valid bits of the rebuilt lists are combined by two ballots and ONE read-modify-write of the header word: an LDS
+        // atomic or / and per lane on that one word is expanded by the compiler's atomic optimizer into a scalar loop over the
+        // active lanes (s_ff1 / v_readlane / ... : ~7 instructions x 12 lanes on the first wave's path, every tick)
+        const bool rebuilt = t < NL && sh.hd.lane_start[t < NL ? t + 1 : 0] > sh.hd.lane_start[t < NL ? t : 0];
+        bool hvalid = false;
+        if (rebuilt) {
             const int base = sh.loff[t];
             if (sh.nfin[t] > 0) {
                 const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[sidx_at(sh.s_idx, base)];
-                lds_or(&sh.hd.head_valid, 1 << t);
+                hvalid = true;
                 int hl = sh.lane_of[hr];
                 sh.hd.head_lane[t] = hl;
                 sh.hd.head_j[t] = hr - sh.hd.lane_start[hl];
-            } else {
-                lds_and(&sh.hd.head_valid, ~(1 << t));
             }
         }
+#if PVE_DEVICE_CODE
+        {
+            const unsigned mr = (unsigned)__ballot(rebuilt), mv = (unsigned)__ballot(hvalid);   // (lanes 0..11 of the first wave; 0 elsewhere)
+            if (t == 0) sh.hd.head_valid = (sh.hd.head_valid & ~(int)mr) | (int)mv;
+        }
+#else
+        if (rebuilt) { if (hvalid) sh.hd.head_valid |= 1 << t; else sh.hd.head_valid &= ~(1 << t); }
+#endif
         if (!r.dctl) return;
         const int sl = r.ds, lane = r.dlane;
         const double ps = r.dp;

@@ -528,9 +528,11 @@ template <int CAP> struct TickGeo {
         // (a) one thread per list d: head of list d, persisted for next tick's step (ref :1517); lists are rebuilt only
         //     when their physical lane holds a vehicle (ref :234), otherwise the old head stays (stale by design)
         const bool lists = sh.pool_ok != 0;
+        bool hrebuilt = false, hvalid = false;             // (combined by ballots below: cf. Tick::ph_scan)
         if (t >= CAP - ND && t - (CAP - ND) < g.dir_num) {     // the last 16 threads: the (mostly empty) tail of the last wave
             const int d = t - (CAP - ND), li = sh.tab.dir_lane[d], m = sh.tab.dir_index[d];
             if (sh.hd.lane_start[li + 1] > sh.hd.lane_start[li]) {
+                hrebuilt = true;
                 double best = INFINITY; int bs = -1;
                 if (lists) {
                     if (sh.fill[d] > 0) { const int e0 = sidx_at(sh.s_idx, sh.lbase[d]); bs = sh.u_slot[e0]; best = sh.u_vd[e0]; }   // sorted: the first entry
@@ -550,15 +552,21 @@ template <int CAP> struct TickGeo {
                         }
                 }
                 if (bs >= 0) {
-                    lds_or(&sh.hd.head_valid, 1 << d);
+                    hvalid = true;
                     const int hl = sh.lane_of[bs];
                     sh.hd.head_lane[d] = hl;
                     sh.hd.head_j[d] = bs - sh.hd.lane_start[hl];
-                } else {
-                    lds_and(&sh.hd.head_valid, ~(1 << d));
                 }
             }
         }
+#if PVE_DEVICE_CODE
+        {   // lanes 48..63 of the LAST wave hold the lists 0..15: one read-modify-write of the header word by its first such lane
+            const unsigned mr = (unsigned)(__ballot(hrebuilt) >> 48), mv = (unsigned)(__ballot(hvalid) >> 48);
+            if (t == CAP - ND) sh.hd.head_valid = (sh.hd.head_valid & ~(int)mr) | (int)mv;
+        }
+#else
+        if (hrebuilt) { const int d = t - (CAP - ND); if (hvalid) sh.hd.head_valid |= 1 << d; else sh.hd.head_valid &= ~(1 << d); }
+#endif
         if (!(r.alive && r.ctl)) return;
         // (b) every controlled vehicle goes through the members of its route's list
         const int d = r.route, li = r.lane, m = r.intent;
