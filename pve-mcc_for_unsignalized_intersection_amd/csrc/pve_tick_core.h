@@ -1786,24 +1786,31 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         //  of scalar-load round trips at the top of FIN; a null pointer stays null because s = 0 or the field is unused)
         Outputs o;
         const long long s = R.trajectory ? (long long)k * P.n_envs * CAP : 0;
-        const long long se = R.trajectory ? (long long)k * P.n_envs * 8 : 0;
-        const long long f32 = P.obs_f32 ? 1 : 0;
-        const long long rowb = OBSW * (f32 ? 4 : 8);
-        o.obs_post = (double *)((char *)P.out.obs_post + (P.out.obs_post ? s * rowb : 0));
-        // training outputs: this tick's rows with pre-compaction indexing and the 7 x 28 states; the stale
-        // neighbour rows are what the PREVIOUS tick stored: the caller's rows for the launch's first tick, then block k - 1
-        if (TRAIN) {
-            o.obs_pre = (double *)((char *)P.out.obs_pre + (P.out.obs_pre ? s * rowb : 0));
-            o.state_pre = (double *)((char *)P.out.state_pre + (P.out.state_pre ? s * rowb * (NNB + 1) : 0));
-            o.obs_prev_post = (k == 0 || !P.out.obs_post) ? (const double *)R.prev_rows
-                                                          : (const double *)((const char *)o.obs_post - (long long)P.n_envs * CAP * rowb);
-        } else { o.obs_pre = nullptr; o.state_pre = nullptr; o.obs_prev_post = nullptr; }
-        o.reward = P.out.reward + (P.out.reward ? s : 0);
-        o.flags = P.out.flags + (P.out.flags ? s : 0);
-        o.lanej = P.out.lanej + (P.out.lanej ? s : 0);
-        o.nbr = P.out.nbr + (P.out.nbr ? s * NNB : 0);
-        o.new_slot = P.out.new_slot + (P.out.new_slot ? s : 0);
-        o.env_out = P.out.env_out + (P.out.env_out ? se : 0);
+        // the caller's pointers as they are ...
+        o.obs_post = P.out.obs_post; o.reward = P.out.reward; o.flags = P.out.flags; o.lanej = P.out.lanej; o.nbr = P.out.nbr;
+        o.new_slot = P.out.new_slot; o.env_out = P.out.env_out;
+        if (TRAIN) { o.obs_pre = P.out.obs_pre; o.state_pre = P.out.state_pre; o.obs_prev_post = (const double *)R.prev_rows; }
+        else { o.obs_pre = nullptr; o.state_pre = nullptr; o.obs_prev_post = nullptr; }
+        if (s != 0) {
+            // ... shifted to block k of a trajectory roll-out (uniform branch: a roll-out that overwrites its outputs -- the bench
+            // headline -- skips these ~50 scalar instructions on every tick)
+            const long long se = (long long)k * P.n_envs * 8;
+            const long long rowb = OBSW * (P.obs_f32 ? 4 : 8);
+            if (o.obs_post) o.obs_post = (double *)((char *)o.obs_post + s * rowb);
+            // training outputs: this tick's rows with pre-compaction indexing and the 7 x 28 states; the stale
+            // neighbour rows are what the PREVIOUS tick stored: the caller's rows for the call's first tick, then block k - 1
+            if (TRAIN) {
+                if (o.obs_pre) o.obs_pre = (double *)((char *)o.obs_pre + s * rowb);
+                if (o.state_pre) o.state_pre = (double *)((char *)o.state_pre + s * rowb * (NNB + 1));
+                if (o.obs_post) o.obs_prev_post = (const double *)((const char *)o.obs_post - (long long)P.n_envs * CAP * rowb);
+            }
+            if (o.reward) o.reward += s;
+            if (o.flags) o.flags += s;
+            if (o.lanej) o.lanej += s;
+            if (o.nbr) o.nbr += s * NNB;
+            if (o.new_slot) o.new_slot += s;
+            if (o.env_out) o.env_out += se;
+        }
         return o;
     }
     // next tick's action of slot t: the load is issued under FX .. LOCK2 and parked in LDS at the start of FIN
