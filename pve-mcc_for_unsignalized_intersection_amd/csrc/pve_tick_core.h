@@ -583,9 +583,14 @@ PVE_HD void get_xy_f32(const PVE_AS4 Const &c, double pd, int lane, float &X, fl
     float x = before ? (p - Lb + 6.f * cw) : (inside ? ax : ((m == 0) ? -cw : 5.f * cw));
     float y = before ? p0y : (inside ? ay : ((m == 0) ? (-6.f * cw + p) : (6.f * cw - p)));
     if (m == 1) { x = p - 6.f * cw; y = 3.f * cw; }
-    const float rc = (float)sel4(c.rot_cos, lane / 3), rs = (float)sel4(c.rot_sin, lane / 3);
-    X = x * rc - y * rs;
-    Y = y * rc + x * rs;
+    // the approach's rotation as an EXACT quarter turn (negations and a swap): the reference rotates by 3.141593 / 2 per approach
+    // (ref :1251), 1.7e-7 rad per step away from pi / 2, i.e. < 1e-4 m at 170 m -- inside this pre-filter's 5 cm margin; the
+    // two table selects + conversions + four products of the general form were ~35 vector instructions per vehicle
+    const int q = lane / 3;
+    const bool odd = (q & 1) != 0;
+    const float xr = odd ? -y : x, yr = odd ? x : y;          // q = 1: (-y, x)
+    X = (q & 2) ? -xr : xr;                                   // q = 2: (-x, -y), q = 3: (y, -x)
+    Y = (q & 2) ? -yr : yr;
 }
 
 // ------------------------------------------------------------------ reward terms: ref :311-320
@@ -616,10 +621,23 @@ PVE_HD double exp_m2_0(double x)
     p = __builtin_fma(p, r, 1.0);
     return ldexp(p, (int)k);
 }
+// x / y for the VALUE-only quotients of the reward terms (never an input of a decision; asserted at 1e-9, bar 1e-5):
+// v_rcp_f64 + two Newton steps (~1 ulp) in 6 instructions instead of the 13 of the IEEE division sequence
+PVE_HD double value_div(double x, double y)
+{
+#if PVE_DEVICE_CODE
+    double r = __builtin_amdgcn_rcp(y);
+    r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+    return x * r;
+#else
+    return x / y;
+#endif
+}
 PVE_HD double reward_coth_term(double t_distance)
 {
     const double u = exp_m2_0(-0.5 * t_distance);       // e^(2x); -t/4 * 2 is exact
-    return (u + 1.0) / (u - 1.0);
+    return value_div(u + 1.0, u - 1.0);
 }
 // log(z) for z in [1e-5, 1.00001] (ref :317-318: z = (d/10)^5 + 1e-5, d < 10): z = 2^e * m, m in [sqrt(1/2), sqrt(2)),
 // log(m) = 2s(1 + s^2/3 + s^4/5 + ...), s = (m - 1)/(m + 1), |s| <= 0.172: 10 terms give 1e-16.
@@ -631,7 +649,7 @@ PVE_HD double reward_log_term(double z)
     m = lo ? m + m : m;
     e = lo ? e - 1 : e;
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    const double s = value_div(f, 2.0 + f);
     const double w = s * s;
     double q = 1.0 / 19.0;
     q = __builtin_fma(q, w, 1.0 / 17.0);
