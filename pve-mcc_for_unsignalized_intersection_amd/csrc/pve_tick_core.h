@@ -414,7 +414,8 @@ template <int CAP, bool LJ = (CAP == 128)> struct Shared {
         double act_next[CAP];        // k_rollout: the NEXT tick's action of every slot, prefetched under the tail of this tick
     };
     double tabA[2][4], tabB[2][4], tabC[2][4];   // get_virtual_distance table (copy of Const, lane-indexed reads; BUILD only)
-    alignas(4) uint8_t l2lp[NL][4];  // lane2lane[d][k] (15 = none) | our position inside lane2lane[that lane] << 4 (rows are read as one dword)
+    alignas(4) uint8_t l2lp[NL][4];  // lane2lane[d][k] (15 = none) | our position inside lane2lane[that lane] << 4 | (that lane % 3) << 6
+                                     // (rows are read as one dword; the high nibble IS the index m * 4 + position into tabA / B / C)
     int lead_n;                      // scratch units claimed by the dead-lock cycles
 };
 
@@ -754,7 +755,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
         if (t < NL * 4) {
             const int L = c.l2l[t >> 2][t & 3];
-            sh.l2lp[t >> 2][t & 3] = (uint8_t)((L < 0 ? 15 : L) | ((c.l2l_inv[t >> 2][t & 3] & 3) << 4));
+            sh.l2lp[t >> 2][t & 3] = (uint8_t)((L < 0 ? 15 : L) | ((c.l2l_inv[t >> 2][t & 3] & 3) << 4) | ((L < 0 ? 0 : (L % 3) & 1) << 6));
         }
     }
 
@@ -895,14 +896,15 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         // three batches of independent LDS reads (lane tables, distance tables + list offsets), then the writes: written
         // as one loop per k the compiler emits four serial chains of three round trips each
         const int pk = *(const int *)sh.l2lp[lane];           // 4 x (lane | position << 4)
-        int d[4], kk[4];
+        int d[4], kk[4], mk[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { d[k] = (pk >> (8 * k)) & 15; kk[k] = (pk >> (8 * k + 4)) & 3; }   // (none = 15 never on these lanes)
+        for (int k = 0; k < 4; k++) {                        // (none = 15 never on these lanes; a conflicting lane is a left turn or a
+            d[k] = (pk >> (8 * k)) & 15; kk[k] = (pk >> (8 * k + 4)) & 3; mk[k] = (pk >> (8 * k + 4)) & 7;   //  straight: m = lane % 3 in {0, 1})
+        }
         double tA[4], tB[4], tC[4]; int lo[4], so[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int m = d[k] % 3;
-            tA[k] = sh.tabA[m][kk[k]]; tB[k] = sh.tabB[m][kk[k]]; tC[k] = sh.tabC[m][kk[k]];
+            tA[k] = (&sh.tabA[0][0])[mk[k]]; tB[k] = (&sh.tabB[0][0])[mk[k]]; tC[k] = (&sh.tabC[0][0])[mk[k]];   // tab?[m][kk]
             lo[k] = sh.loff[d[k]]; so[k] = sh.segoff[d[k]][kk[k] + 1];
         }
 #pragma unroll
