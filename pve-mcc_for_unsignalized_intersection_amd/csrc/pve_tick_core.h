@@ -638,7 +638,8 @@ PVE_HD double value_div(double x, double y)
 PVE_HD double reward_coth_term(double t_distance)
 {
     const double u = exp_m2_0(-0.5 * t_distance);       // e^(2x); -t/4 * 2 is exact
-    return value_div(u + 1.0, u - 1.0);
+    const double den = u - 1.0;                         // (< 0; exactly 0 only for t < 2.2e-16, where 1 / tanh(-t/4) = -4 / t is
+    return den == 0.0 ? -INFINITY : value_div(u + 1.0, den);   //  far beyond the clamp: -inf, never the NaN of 2 * rcp(0) refined)
 }
 // log(z) for z in [1e-5, 1.00001] (ref :317-318: z = (d/10)^5 + 1e-5, d < 10): z = 2^e * m, m in [sqrt(1/2), sqrt(2)),
 // log(m) = 2s(1 + s^2/3 + s^4/5 + ...), s = (m - 1)/(m + 1), |s| <= 0.172: 10 terms give 1e-16.
