@@ -886,14 +886,16 @@ def check_full_size_vs_oracle(backend, n_envs, capacity, rate, ticks=420, n_samp
 
 
 def check_driver_shape_vs_oracle(backend, n_envs=4096, n_sub=2, capacity=128, rate=1100.0, chunk=5, n_sample=16,
-                                 calls=(50, 50, 50, 50, 50, 50, 5, 20), n_pool=16, seed=20250213, trajectory=False, persistent=False):
+                                 calls=(50, 50, 50, 50, 50, 50, 5, 20), n_pool=16, seed=20250213, trajectory=False, persistent=False,
+                                 table=False):
     """Exactly the launch shape the driver's `bench.py --steps 20 --warmup 5` runs:
     PipelinedIntersections, `n_sub` sub-batches on their own streams, pve_step_many calls of 50 (prefill) / 5 (warm-up) /
     20 (timed) ticks split into launches of `chunk` ticks, action pool of 16 slot-indexed entries.  `n_sample` envs spread
     over the batch are shadowed by their own oracles: after EVERY call the last tick's outputs (controlled set, rewards,
     counters, neighbour ids, observation rows) and at the end the state field by field; overflow == 0 over the whole
     batch.  trajectory=True: the calls write into a ring of two trajectory buffers (bench.py --trajectory 1) and EVERY
-    tick's outputs are compared."""
+    tick's outputs are compared.  table=True (round 5: the bench headline): BASELINE.md 3's tape a = float32(sin(0.37 id + 0.05
+    tick)) by vehicle id through PVE_SRC_TABLE instead of the slot-indexed pool."""
     from pve_mcc_amd.batched import PipelinedIntersections
     from tests.hip_adapter import emulator_lib
     rng = np.random.default_rng(seed)
@@ -904,18 +906,31 @@ def check_driver_shape_vs_oracle(backend, n_envs=4096, n_sub=2, capacity=128, ra
     pipe = PipelinedIntersections(n_envs, capacity, arr, n_sub=n_sub, outputs=outs, **kw)
     pipe.reset()
     pool_np = rng.uniform(-3, 3, size=(n_pool, n_envs, capacity)).astype(np.float32).astype(np.float64)
-    pipe.set_action_pool(torch.as_tensor(pool_np))
+    src = None
+    if table:
+        cols = int(12 * (total * 0.1 + 4)) + 64
+        tab_np = np.sin(0.37 * np.arange(cols, dtype=np.float64)[None, :] + 0.05 * np.arange(total + 8, dtype=np.float64)[:, None])
+        tab_np = tab_np.astype(np.float32).astype(np.float64)
+        pipe.set_action_table(torch.as_tensor(tab_np))
+        src = "table"
+    else:
+        pipe.set_action_pool(torch.as_tensor(pool_np))
     sample = sorted(set(np.linspace(0, n_envs - 1, n_sample).astype(int).tolist()))
     oracles = {e: OracleEnv(arr[e]) for e in sample}
     ring = [pipe.alloc_trajectory(max(calls)) for _ in range(2)] if trajectory else None
     t, peak = 0, 0
 
+    def oracle_actions(e, o, tk):
+        vid, ctlm, _ = o.alive_view()
+        if table:
+            return np.where(ctlm != 0, tab_np[tk % tab_np.shape[0], np.minimum(vid, tab_np.shape[1] - 1)], 0.0)
+        return np.where(ctlm != 0, pool_np[tk % n_pool, e, :len(vid)], 0.0)
+
     def compare_tick(e, o, tk, flags, rew, eo, nbr, new_slot, obs_post):
         nonlocal peak
         n = o.n_alive
         peak = max(peak, n)
-        _vid, ctlm, _ = o.alive_view()
-        rec = o.tick(np.where(ctlm != 0, pool_np[tk % n_pool, e, :n], 0.0))
+        rec = o.tick(oracle_actions(e, o, tk))
         ctl = (flags[:n] & 2) != 0
         assert int(eo[0]) == n and int(ctl.sum()) == len(rec["ids"]), "controlled set: tick %d env %d" % (tk, e)
         assert int(eo[2]) == rec["collisions"] and int(eo[3]) == rec["lock"], "counters: tick %d env %d" % (tk, e)
@@ -929,9 +944,9 @@ def check_driver_shape_vs_oracle(backend, n_envs=4096, n_sub=2, capacity=128, ra
 
     for ci, n in enumerate(calls):
         if trajectory:
-            trajs = pipe.step_many(n, trajectory=ring[ci & 1], chunk=chunk, update_views=False)
+            trajs = pipe.step_many(n, source=src, trajectory=ring[ci & 1], chunk=chunk, update_views=False, persistent=persistent)
         else:
-            pipe.step_many(n, chunk=chunk, persistent=persistent)
+            pipe.step_many(n, source=src, chunk=chunk, persistent=persistent)
         pipe.synchronize()
         for e in sample:
             k, le = pipe.sub_of(e)
@@ -943,8 +958,11 @@ def check_driver_shape_vs_oracle(backend, n_envs=4096, n_sub=2, capacity=128, ra
                     compare_tick(e, o, t + q, *(host[x][q] for x in ("flags", "reward", "env_out", "nbr", "new_slot", "obs_post")))
             else:
                 sub = pipe.subs[k]
-                if n > 1:
+                if n > 1 and not table:
                     o.run_pool(n - 1, pool_np[:, e, :], t)
+                elif n > 1:
+                    for q in range(n - 1):
+                        o.tick(oracle_actions(e, o, t + q))
                 compare_tick(e, o, t + n - 1, *(_np(sub.out[x][le]) for x in ("flags", "reward", "env_out", "nbr", "new_slot")),
                              _np(sub.obs[le]))
         t += n

@@ -562,3 +562,14 @@ def test_gpu_closed_loop_training_rollout(persistent, chunk):
     phase) per tick, bit for bit."""
     scenarios.check_closed_loop_state_rows(BACKEND, n_envs=48, chunk=chunk, persistent=persistent)
     scenarios.check_closed_loop_state_rows(BACKEND, n_envs=20, capacity=64, rate=420.0, chunk=chunk, persistent=persistent, obs_dtype=torch.float64, seed=3)
+
+
+@pytest.mark.parametrize("trajectory", [False, True])
+def test_gpu_headline_kernel_id_tape_driver_shape_vs_oracle(trajectory):
+    """The bench headline as the driver runs it (round 5): ONE batch of 4096 x 128, BASELINE.md 3's tape by vehicle id gathered on
+    the device (k_rollout<.., IDT, PERS>), calls of 50 / 5 / 20 ticks as persistent launches with items of <= 12 ticks -- 16
+    intersections shadowed by their oracles after every call (trajectory: at EVERY tick, the retained-outputs leg), final state
+    field by field, overflow 0 over the whole batch."""
+    m, peak = scenarios.check_driver_shape_vs_oracle(BACKEND, n_sub=1, chunk=12, persistent=True, table=True, trajectory=trajectory,
+                                                     calls=(50, 50, 50, 50, 50, 50, 5, 20) if not trajectory else (50, 50, 50, 50, 50, 50, 25, 20))
+    assert m["alive_steps"] / m["ticks"] > 50 and peak <= 128

@@ -163,3 +163,12 @@ def test_trainer_rollout_through_the_work_queue_emulated(source, dtype):
 
 def test_closed_loop_training_rollout_emulated():
     scenarios.check_closed_loop_state_rows(BACKEND, n_envs=2, calls=(12, 9), chunk=5)
+
+
+def test_id_tape_driver_shape_small_emulated():
+    """The table-source form of the driver-shape scenario through the emulator (small batch): the scenario's oracle side of the
+    id-indexed tape, the emulated work queue's item schedule."""
+    scenarios.check_driver_shape_vs_oracle(BACKEND, n_envs=6, n_sub=1, chunk=12, n_sample=6, calls=(30, 20, 5, 20), persistent=True, table=True,
+                                           rate=900.0)
+    scenarios.check_driver_shape_vs_oracle(BACKEND, n_envs=4, n_sub=1, chunk=7, n_sample=4, calls=(25, 20), persistent=True, table=True,
+                                           trajectory=True, rate=900.0)
