@@ -475,9 +475,9 @@ def run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=None, v
     t0 = time.perf_counter()
     calls[K]()
     sync()
+    dt = time.perf_counter() - t0                         # (this rank's K ticks; the closing barrier follows, MAX over ranks below)
     dist.barrier()
     sync()
-    dt = time.perf_counter() - t0
     tw = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     dt_max = float(tw.item())
@@ -845,6 +845,10 @@ def main(argv=None, env_factory=None):
         for (_, e1), st in zip(evs, ev_streams):
             e1.record(st)
     sync()
+    # this rank's K ticks, from the first enqueue to their completion.  The closing bracket (barrier + synchronize) follows; the
+    # job's time is the MAX over the ranks' own times -- the env-parallel path has no collective, so the latency of the
+    # bracketing barrier itself (an RCCL kernel) is not part of any rank's K ticks
+    wall_local = time.perf_counter() - t0
     if os.environ.get("PVE_BENCH_TIMELINE") and not emu:     # host side of the timed region, us (diagnostics, stderr)
         t_end = time.perf_counter()
         sys.stderr.write("timeline us: record %.1f  enqueue %.1f  wait %.1f  total %.1f | per-stream event spans %s\n" % (
@@ -853,14 +857,13 @@ def main(argv=None, env_factory=None):
     if world > 1:
         dist.barrier()
     sync()
-    wall = time.perf_counter() - t0
+    wall = wall_local
     # average duration of one tick of one sub-batch on its stream (K back-to-back ticks per stream)
     gpu_ms = (sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)) if not emu else wall * 1e3
     if world > 1:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tw = torch.tensor([wall_local], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
-    wall_local = wall
     m1 = env.metrics()
     delta = {k: m1[k] - m0[k] for k in m1}
     # the single RCCL all-gather (metrics only; the rank's own wall-clock and first global env index ride along)
