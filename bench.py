@@ -275,7 +275,7 @@ ACTION_TOL = 5e-4       # |a_device - a_numpy| on actions in [-3, 3]: two float3
 STATE_FIELDS = ("p", "v", "a", "jerk", "jerk_sum", "vir_dis", "closer_p", "id", "seq", "vnum", "step", "count", "meta", "hdr")
 
 
-def verify_closed_loop(torch, dev, locate, arr, total_ticks, cap, obs_dtype, weights, n_sample=2 * VERIFY_ENVS):
+def verify_closed_loop(torch, dev, locate, arr, total_ticks, cap, obs_dtype, weights, n_sample=2 * VERIFY_ENVS, lane_num=12, choice=None):
     """Closed loop (BASELINE config 5), outside the timed region: `n_sample` of the envs this rank just timed are replayed
     from reset on the GPU as ONE small batch in the two-launch form (step_with_actor: actor kernel + tick kernel per tick,
     whose tick is the kernel the oracle certifies) for the same number of ticks.  The timed path (the actor inside the
@@ -296,8 +296,9 @@ def verify_closed_loop(torch, dev, locate, arr, total_ticks, cap, obs_dtype, wei
     if total_ticks < 1:
         res.update(verified=None, reason="no tick executed")
         return res
+    geo = dict(lane_num=lane_num, intentions=None if choice is None else choice[sample]) if lane_num != 12 else {}
     small = pve_mcc_amd.BatchedIntersections(len(sample), cap, arr[sample], device=dev, obs_dtype=obs_dtype,
-                                             outputs=("obs_post", "reward", "flags", "env_out"))
+                                             outputs=("obs_post", "reward", "flags", "env_out"), **geo)
     small.reset()
     small.set_actor(weights)
     for _ in range(int(total_ticks)):
@@ -544,8 +545,10 @@ def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=
         return 1, 0, False
     if lane_num == 12 and actor and cap == 128 and n_envs >= 4096:
         return 1, (25 if K >= 100 else 12), True     # closed loop: 34.6 against 35.9 us per tick (long call), 41.7 against 43.6 (20 ticks)
-    if lane_num != 12 and cap == 128 and not actor and not table and n_envs >= 4096 and K >= 100:
-        return 1, 10, True          # 8 lanes: 37.0 against 38.2 us per tick, 4 lanes x 128: 36.5 against 41.7; 20 ticks: no gain (2 streams)
+    if lane_num != 12 and cap == 128 and not table and n_envs >= 4096 and K >= 100:
+        # 8 lanes: 37.0 against 38.2 us per tick, 4 lanes x 128: 36.5 against 41.7; 20 ticks: no gain (2 streams).  Closed loop (round 5,
+        # the actor inside k_rollout_geo): 4 lanes x 128 38.4 against 41.8, 8 lanes 41.3 against 41.5; 20 ticks: 49.0 (2 streams) against 54-57
+        return 1, 10, True
     return 2, ((25 if K >= 100 else 5) if cap == 128 else 0), False
 
 
@@ -705,7 +708,7 @@ def main(argv=None, env_factory=None):
     d_sub, d_chunk, d_pers = launch_shape(cap, K, lane_num, args.actor, table=id_sin, n_envs=n_envs)
     if not rollout_like:
         d_sub, d_chunk, d_pers = 2, 0, False
-    can_pers = rollout_like and not emu and (lane_num == 12 or not args.actor)
+    can_pers = rollout_like and not emu
     pers = can_pers and args.chunk != 0 and \
         (bool(args.persistent) if args.persistent is not None else (d_pers and args.pipeline in (None, 1)))
     if args.pipeline is None:
@@ -882,9 +885,9 @@ def main(argv=None, env_factory=None):
             return env, e
         k, le = env.sub_of(e)
         return subs[k], le
-    if args.actor and not args.no_verify and not emu and lane_num == 12:
+    if args.actor and not args.no_verify and not emu:
         sync()
-        verify = verify_closed_loop(torch, dev, locate, arr, tick[0], cap, obs_dtype, actor_weights())
+        verify = verify_closed_loop(torch, dev, locate, arr, tick[0], cap, obs_dtype, actor_weights(), lane_num=lane_num, choice=choice)
     elif args.actor:
         verify = dict(verified=None, reason="closed loop: skipped (--no-verify) or no GPU replay available")
     elif not args.no_verify:

@@ -218,11 +218,11 @@ int pve_step_all_actor(pve_handle h, const float *weights, const void *obs_in, d
  *                  loop of main.py:398-441 with the actor of model_agent_maddpg.py:23-49; the first tick reads
  *                  `actor_obs` (zeros after pve_reset, ref :380), later ticks the rows written through out->obs_post,
  *                  which is therefore required (and may be the same buffer as actor_obs when trajectory = 0)
- * and the results are bit-identical to n_ticks separate calls (tested).  For lane_num = 12 the ticks run inside one
- * kernel launch with the intersection state resident on the chip between ticks (k_rollout: no state traffic to HBM, only
- * the per-tick outputs) -- PVE_SRC_ACTOR included: the actor runs inside that kernel on the rows its dense threads have
- * just built (with PVE_CFG_ACTOR_F32: an actor launch + a tick launch per tick); other layouts enqueue n_ticks launches
- * from C.
+ * and the results are bit-identical to n_ticks separate calls (tested).  The ticks run inside one kernel launch with the
+ * intersection state resident on the chip between ticks (k_rollout for lane_num 12, k_rollout_geo for lane_num 4 / 8: no
+ * state traffic to HBM, only the per-tick outputs) -- PVE_SRC_ACTOR included: the actor runs inside that kernel on the rows
+ * the tick has just stored (with PVE_CFG_ACTOR_F32, or together with the training outputs for lane_num 4 / 8: an actor launch
+ * + a tick launch per tick, enqueued from C).
  * trajectory = 0: every tick overwrites the `out` buffers (the last tick's outputs remain; metrics accumulate in the
  * handle as usual); trajectory = 1: every non-NULL `out` buffer holds n_ticks consecutive per-tick blocks
  * ([n_ticks][n_envs][cap]...), the roll-out a trainer consumes.  The training outputs (lane_num 12): obs_pre may be
@@ -252,7 +252,7 @@ typedef struct pve_rollout {
                                      (the reference's episode loop main.py:397-441 has no such boundary either).  Same results as
                                      persistent = 0.  Eligible: lane_num 12 with every source (ZERO / POOL / TABLE / ACTOR unless
                                      PVE_CFG_ACTOR_F32), with or without trajectory = 1, with or without the training outputs
-                                     obs_pre / state_pre; lane_num 4 / 8 with ZERO / POOL and without the training outputs.
+                                     obs_pre / state_pre; lane_num 4 / 8 with ZERO / POOL / ACTOR and without the training outputs.
                                      Anything else is run as chunked launches (pve_debug_last_launch tells which).
                                      PVE_SRC_ACTOR: `actor_actions` is the hand-off buffer between the items of an intersection
                                      (every item's last tick stores the next actions there, the next item reads them): it must

@@ -624,19 +624,29 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu((CAP == 64 
 // TRAIN: the training outputs (obs_pre, state_pre) per tick of a trajectory roll-out; IDT: PVE_SRC_TABLE (actions by (tick,
 // vehicle id), gathered by the vehicle's own thread and parked at its NEW slot in `p[]`, which is free between FIN and the next
 // S1) -- as in k_rollout, variants of their own so that the default kernel keeps its register allocation.
-// PERS: the persistent work-queue form (k_rollout<.., PERS>: same queue, same hand-off), pool / zero sources.
-template <int CAP, bool FIX4 = false, int WPE = 4, bool TRAIN = false, bool IDT = false, bool PERS = false>
+// PERS: the persistent work-queue form (k_rollout<.., PERS>: same queue, same hand-off), pool / zero / actor sources.
+// ACT: pve_step_many(PVE_SRC_ACTOR) -- the closed loop of main.py:398-441 for lane_num 4 / 8 resident on the chip, as in
+// k_rollout<.., ACT>: behind STAGE every wave runs the actor (pve_actor.h: actor_tile32) on its tiles of 32 controlled
+// vehicles, whose float32 / float64 rows FIN has just stored to obs_post; the phases here work per slot, so the list of the
+// controlled vehicles' NEW slots (`adsts`, by rank among the controlled vehicles) is filed behind FIN; the actions wait in
+// `p[]` (free between FIN and the next S1) where RELOAD looks for them, the spawned vehicles get the action of the all-zero
+// row.  Every tick is staged (no `still` shortcut): the actor runs every tick.
+template <int CAP, bool FIX4 = false, int WPE = 4, bool TRAIN = false, bool IDT = false, bool PERS = false, bool ACT = false>
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout_geo(const GeoConst g_arg, const Params P_arg,
                                                                                                 const RolloutArgs R_arg)
 {
-    static_assert(!PERS || (!TRAIN && !IDT), "the persistent form of the geometry kernel: pool / zero sources");
+    static_assert(!PERS || (!TRAIN && !IDT), "the persistent form of the geometry kernel: pool / zero / actor sources");
+    static_assert(!ACT || (!TRAIN && !IDT), "the closed loop of the geometry kernel: one action source, no training outputs");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(GeoConst) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     __shared__ SharedGeo<CAP> sh;
+    __shared__ __attribute__((aligned(64))) float aprm[ACT ? PV_TOTAL : 1];
+    __shared__ uint8_t adsts[ACT ? CAP : 1];         // NEW slot of the k-th controlled vehicle (255: gone / no such vehicle)
     __shared__ int q_word[4];
     int t0_ = threadIdx.x;
     int env0_ = PERS ? 0 : blockIdx.x;
     int k_base_ = 0, chunk_ = 0;
+    bool aprm_staged = false;                        // PERS + ACT: the float parameters are in LDS (once per workgroup)
     KernargPtr kav_ = ka0_;
     Regs r;
     FinCarry fc;
@@ -651,16 +661,48 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R);
         pool_idx = R.pool_tick0;
         n_ticks = R.n_ticks;
+        const double *act0 = nullptr;
         if constexpr (PERS) {
             int e, ch, kb, nt;
             if (!q_take(R, P.n_envs, t0_, q_word, e, ch, kb, nt)) break;
             env0_ = e; chunk_ = ch; k_base_ = kb; n_ticks = nt;
-            const double *act0 = nullptr;
             if (R.source == 1) {
                 pool_idx = (R.pool_tick0 + k_base_) % R.n_pool;
                 act0 = R.pool + (size_t)pool_idx * (size_t)P.n_envs * CAP;
             }
-            T::template ph_load<true>(g, P, env0_, t0_, sh, r, act0, true);
+        }
+        // ACT (cf. k_rollout): the first item of an intersection in a call computes its first actions from the caller's rows,
+        // every later item takes them from `actor_actions`, where the previous item's last tick left them
+        bool act_handed = false;
+        if constexpr (PERS && ACT) {
+            act_handed = chunk_ > 0;
+            if (act_handed) act0 = R.actor_actions;
+        }
+        if constexpr (ACT) if (!act_handed) {
+            if (!PERS || !aprm_staged) {
+                const float *gp = (const float *)(R.actor_packed + AP_PRM);
+                for (int n = t0_; n < PV_TOTAL; n += CAP) aprm[n] = gp[n];
+            }
+            const int mt = P.i32[I_META][(size_t)env0_ * CAP + t0_];
+            const bool cc = (mt & (M_ALIVE | M_CONTROL)) == (M_ALIVE | M_CONTROL);
+            vote<CAP / 64>(sh.m_ctl, t0_, cc);
+            adsts[t0_] = 255;
+            lds_barrier();
+            if (cc) adsts[mask_rank<CAP / 64>(sh.m_ctl, t0_)] = (uint8_t)t0_;
+            const int nc = mask_count<CAP / 64>(sh.m_ctl);
+            lds_barrier();                               // parameters staged, list complete
+            rollout_actor<CAP>(R.actor_packed, aprm, sh.p, adsts, nc, R.actor_obs, P.obs_f32 != 0, (size_t)env0_ * CAP, t0_);
+            lds_barrier();                               // (the actions wait in p[], which LOAD does not touch)
+        }
+        if constexpr (PERS && ACT) {
+            if (!aprm_staged && act_handed) {            // (a workgroup whose first item is a later chunk: parameters for its ticks)
+                const float *gp = (const float *)(R.actor_packed + AP_PRM);
+                for (int n = t0_; n < PV_TOTAL; n += CAP) aprm[n] = gp[n];
+            }
+            aprm_staged = true;
+        }
+        if constexpr (PERS) {
+            T::template ph_load<true, ACT>(g, P, env0_, t0_, sh, r, act0, true);
             lds_barrier();
             T::template ph_load_late<true>(P, env0_, t0_, sh, r);
         } else {
@@ -668,6 +710,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         lds_barrier();
         T::ph_load_late(P, env0_, t0_, sh, r);
         }
+        if constexpr (ACT) { if (!act_handed) r.act = sh.p[t0_]; }   // (uncontrolled slots: whatever is there, masked in S1)
         if constexpr (IDT) {                            // the first tick's action of the vehicle in this slot: table[row][id]
             const int idc = r.id < 0 ? 0 : (r.id < R.table_ids ? r.id : R.table_ids - 1);
             r.act = r.alive ? R.pool[(size_t)pool_idx * (size_t)R.table_ids + idc] : 0.0;
@@ -730,7 +773,12 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         lds_barrier();
         B::ph_lock2_slot(t, sh, r);
         lds_barrier();
-        T::template ph_final<true>(g, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
+        T::template ph_final<true>(g, P, O, env, t, sh, r, fc, ACT || k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
+        if constexpr (ACT) {
+            // the k-th controlled vehicle's NEW slot (m_ctl: the votes of S1); entries beyond the controlled count: no vehicle
+            if (t >= fc.n_ctl) adsts[t] = 255;
+            if (r.alive && r.ctl) adsts[mask_rank<CAP / 64>(sh.m_ctl, t)] = (uint8_t)(fc.new_slot < 0 ? 255 : fc.new_slot);
+        }
         if constexpr (IDT) {
             if (!fc.still && fc.new_slot >= 0) sh.p[fc.new_slot] = r.act_nx;      // (p[] is free between FIN and the next S1)
             sp_act = 0;                               // the vehicle this lane spawns (id known since FIN): its first action
@@ -746,10 +794,23 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             if (TRAIN && O.state_pre) T::ph_state(P, O, env, t, sh, r);   // (uniform; barrier A also orders the obs_pre rows of this tick)
             T::ph_stage(g, t, sh, r, fc);
             if constexpr (IDT) { if (fc.sp_slot >= 0) sh.p[fc.sp_slot] = sp_act; }
+            if constexpr (ACT) {
+                // next tick's actions: the vehicle lane t spawns gets the action of an all-zero row (ref :380, :420), the
+                // controlled vehicles that stay get actor(row)
+                if (fc.sp_slot >= 0) sh.p[fc.sp_slot] = (double)aprm[PV_A0];
+                // (PERS: also on an item's last tick, unless it is the call's last: the next item starts from these actions)
+                const bool hand_on = PERS && k + 1 == n_ticks && chunk_ + 1 < R.n_full + R.n_taper;
+                if (k + 1 < n_ticks || hand_on)
+                    rollout_actor<CAP>(R.actor_packed, aprm, sh.p, adsts, fc.n_ctl, O.obs_post, P.obs_f32 != 0, (size_t)env * CAP, t);
+                if (hand_on) {
+                    lds_barrier();                    // (every tile's actions are in p[])
+                    R.actor_actions[(size_t)env * CAP + t] = sh.p[t];
+                }
+            }
             lds_barrier();                            // B: the staging area is complete
             if (k + 1 < n_ticks) {
                 T::ph_reload(t, sh, r);
-                if constexpr (IDT) r.act = sh.p[t];
+                if constexpr (IDT || ACT) r.act = sh.p[t];
             }
         }
     }
@@ -825,7 +886,7 @@ static std::string hip_err(const char *what, hipError_t e)
 struct OccCache {
     static constexpr int MAX_DEV = 64;
     std::mutex mu;
-    int wgs[MAX_DEV][2][2] = {};
+    int wgs[MAX_DEV][3][2] = {};       // family: 0 = k_rollout, 1 = k_rollout_geo, 2 = k_rollout_geo with the actor
     int n_cu[MAX_DEV] = {};
     // -> workgroups the device holds at once for (family, cap), or -1 (err set); `query` = the occupancy call of the variant
     template <typename Q>
@@ -991,9 +1052,12 @@ struct Backend {
     static int launch_rollout_geo(const GeoConst &g, const Params &P_in, const RolloutArgs &R, int cap, void *stream, std::string &err)
     {
         static const bool off = PVE_KNOB("PVE_NO_ROLLOUT_KERNEL") != nullptr;   // A/B knob: one launch per tick instead
+        static const bool act_off = PVE_KNOB("PVE_NO_ROLLOUT_ACTOR") != nullptr;   // A/B knob: actor + tick launches instead
         const bool train = P_in.out.obs_pre || P_in.out.state_pre;
-        if (off || R.source == 2 /* the actor reads 12-lane rows */ || P_in.phase_cycles || (train && R.source == 3)) return 1;
-        if (R.queue && (train || R.source == 3)) return 1;                    // (the queue form: pool / zero sources)
+        const bool act = R.source == 2 /* PVE_SRC_ACTOR */;
+        if (off || P_in.phase_cycles || (train && (R.source == 3 || act))) return 1;
+        if (act && (act_off || R.exact_f32 || (R.queue && !R.actor_actions))) return 1;
+        if (R.queue && (train || R.source == 3)) return 1;                    // (the queue form: pool / zero / actor sources)
         hipStream_t s = (hipStream_t)stream;
         Params P = P_in;
         RolloutArgs Rk = R;
@@ -1003,42 +1067,44 @@ struct Backend {
         } else P.actions = nullptr;
         if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
         dim3 grid(P.n_envs);
+        const bool fix4 = g.lane_num == 4;           // (the 4-lane layout's far-conflict path is a kernel of its own)
         if (R.queue) {
-            // the persistent form: as many workgroups as the chip holds at once (the variants share their register budget and LDS
-            // block: one occupancy query per capacity)
-            long long gq = g_occ.resident(1, cap, [&](int *nb) {
+            // the persistent form: as many workgroups as the chip holds at once (the variants of one capacity share their register
+            // budget; the actor's parameters add 2 KB of LDS: a query of its own)
+            long long gq = g_occ.resident(act ? 2 : 1, cap, [&](int *nb) {
+                if (act) return (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<64, true, 4, false, false, true, true>, 64, 0)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<128, true, 4, false, false, true, true>, 128, 0);
                 return (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<64, true, 4, false, false, true>, 64, 0)
                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<128, true, 4, false, false, true>, 128, 0); }, err);
             if (gq < 0) return -1;
             const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
             if (gq > items) gq = items;
             grid = dim3((unsigned)gq);
-            if (g.lane_num == 4) {
-                if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, true, 4, false, false, true>), grid, dim3(64), 0, s, g, P, Rk);
-                else hipLaunchKernelGGL((k_rollout_geo<128, true, 4, false, false, true>), grid, dim3(128), 0, s, g, P, Rk);
-            } else if (cap == 64) hipLaunchKernelGGL((k_rollout_geo<64, false, 4, false, false, true>), grid, dim3(64), 0, s, g, P, Rk);
-            else hipLaunchKernelGGL((k_rollout_geo<128, false, 4, false, false, true>), grid, dim3(128), 0, s, g, P, Rk);
-            return check_launch(err);
         }
-        // (variant = layout x capacity x {default, training outputs, id-indexed table})
+        // (variant = layout x capacity x {default, training outputs, id-indexed table, actor} x launch form)
+#define PVE_LAUNCH_GEO_V(CAP_, FIX_, TRAIN_, IDT_, PERS_, ACT_) \
+        hipLaunchKernelGGL((k_rollout_geo<CAP_, FIX_, 4, TRAIN_, IDT_, PERS_, ACT_>), grid, dim3(CAP_), 0, s, g, P, Rk)
 #define PVE_LAUNCH_GEO(CAP_, FIX_)                                                                                              \
         do {                                                                                                                    \
-            if (train) hipLaunchKernelGGL((k_rollout_geo<CAP_, FIX_, 4, true, false>), grid, dim3(CAP_), 0, s, g, P, Rk);       \
-            else if (R.source == 3) hipLaunchKernelGGL((k_rollout_geo<CAP_, FIX_, 4, false, true>), grid, dim3(CAP_), 0, s, g, P, Rk); \
-            else hipLaunchKernelGGL((k_rollout_geo<CAP_, FIX_>), grid, dim3(CAP_), 0, s, g, P, Rk);                             \
+            if (R.queue) { if (act) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, true, true); else PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, true, false); } \
+            else if (act) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, false, true);                                               \
+            else if (train) PVE_LAUNCH_GEO_V(CAP_, FIX_, true, false, false, false);                                             \
+            else if (R.source == 3) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, true, false, false);                                     \
+            else PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, false, false);                                                       \
         } while (0)
-        if (g.lane_num == 4) {
+        if (fix4) {
             if (cap == 64) PVE_LAUNCH_GEO(64, true); else PVE_LAUNCH_GEO(128, true);
         } else if (cap == 64) PVE_LAUNCH_GEO(64, false);
         else {
 #ifdef PVE_AB_KNOBS
             static const bool w5 = getenv("PVE_ROLLOUT_GEO_WPE5") != nullptr;     // A/B knob: 96-VGPR build, 10 workgroups per CU (414 spills)
-            if (w5 && !train && R.source != 3) hipLaunchKernelGGL((k_rollout_geo<128, false, 5>), grid, dim3(128), 0, s, g, P, Rk);
+            if (w5 && !train && !act && !R.queue && R.source != 3) hipLaunchKernelGGL((k_rollout_geo<128, false, 5>), grid, dim3(128), 0, s, g, P, Rk);
             else
 #endif
             PVE_LAUNCH_GEO(128, false);
         }
 #undef PVE_LAUNCH_GEO
+#undef PVE_LAUNCH_GEO_V
         return check_launch(err);
     }
     static int launch_tick_geo(const GeoConst &g, const Params &P, int cap, void *stream, std::string &err)

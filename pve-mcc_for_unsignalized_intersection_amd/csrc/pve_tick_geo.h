@@ -166,8 +166,9 @@ template <int CAP> struct TickGeo {
 
     // ============================================================== L: load
     // COH (persistent roll-out): the state may have been stored by another workgroup of this launch -> coherent loads
-    // (Tick::ph_load); act0: the first tick's actions of the item ([n_envs][CAP] or null) instead of P.actions
-    template <bool COH = false>
+    // (Tick::ph_load); act0: the first tick's actions of the item ([n_envs][CAP] or null) instead of P.actions; COHA: the
+    // actions too (the persistent closed loop hands them from one item to the next)
+    template <bool COH = false, bool COHA = false>
     static PVE_HD void ph_load(const PVE_AS4 GeoConst &g, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r,
                                const double *act0 = nullptr, bool use_act0 = false)
     {
@@ -193,7 +194,7 @@ template <int CAP> struct TickGeo {
         r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
         const double *acts = use_act0 ? act0 : P.actions;
         if (t < 64 || t < N) {                    // first wave unconditionally (no dependence on n_alive), later waves live slots only
-            if (acts) r.act = *env_at<CAP>(acts, env, t);
+            if (acts) r.act = gld<COHA>(env_at<CAP>(acts, env, t));
             r.p = gld<COH>(env_at<CAP>(P.f64[F_P], env, t)); r.v = gld<COH>(env_at<CAP>(P.f64[F_V], env, t)); r.a = gld<COH>(env_at<CAP>(P.f64[F_A], env, t));
             r.meta = gld<COH>(env_at<CAP>(P.i32[I_META], env, t)); r.step = gld<COH>(env_at<CAP>(P.i32[I_STEP], env, t));
             r.seq = gld<COH>(env_at<CAP>(P.i32[I_SEQ], env, t)); r.vnum = gld<COH>(env_at<CAP>(P.i32[I_VNUM], env, t)); r.count = gld<COH>(env_at<CAP>(P.i32[I_COUNT], env, t));

@@ -652,6 +652,92 @@ def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chun
     return m1
 
 
+def check_step_many_geo_actor(backend, lane_num, n_envs=6, capacity=128, seed=77, chunks=(1, 9, 30, 4, 45), rate=None,
+                              trajectory_chunk=11, obs_dtype=torch.float64, persistent=False, oracle_ticks=0):
+    """The closed loop for the 4- / 8-lane layouts (main.py:398-441 drives every lane_num; the shipped checkpoint's args.txt
+    records lane_num = 4): pve_step_many(PVE_SRC_ACTOR) -- the actor inside k_rollout_geo<.., ACT[, PERS]> -- == step_with_actor
+    ticks (actor launch + k_tick_geo), bit for bit: persistent state, headers, observation rows, last-tick outputs and, in
+    trajectory mode, every tick's outputs.  oracle_ticks > 0: first, for that many ticks, the two-launch form itself against
+    the sequential general-geometry oracle, which is handed the actions the device actor produced (rewards + state)."""
+    from oracle.actor_np import flat_weights, load_weights
+    from pve_mcc_amd.arrivals import synthetic_intentions
+    rate = rate or {8: 1300.0, 4: (1500.0 if capacity == 128 else 1000.0)}[lane_num]
+    total = sum(chunks) + trajectory_chunk + oracle_ticks
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed, lane_num=lane_num)
+    ch = synthetic_intentions(n_envs, arr.shape[1], seed=seed, lane_num=lane_num) if lane_num == 8 else None
+    outs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out", "lanej")
+    kw = dict(lane_num=lane_num, intentions=ch, outputs=outs, obs_dtype=obs_dtype)
+    one = make_batch(arr, n_envs, capacity, backend, **kw)
+    many = make_batch(arr, n_envs, capacity, backend, **kw)
+    w = flat_weights(load_weights())
+    for b in (one, many):
+        b.reset()
+        b.set_actor(w)
+    if oracle_ticks:
+        from oracle.oracle_geo import OracleGeoEnv
+        oracles = [OracleGeoEnv(arr[e], lane_num, choice=None if ch is None else ch[e]) for e in range(n_envs)]
+        for t in range(oracle_ticks):
+            acts = _np(one.act()).copy()
+            out = one.step_with_actor()
+            many.step_with_actor()
+            rew, flags, lanej = _np(out["reward"]), _np(out["flags"]).astype(np.int64), _np(out["lanej"]).astype(np.int64)
+            for e, o in enumerate(oracles):
+                n = o.n_alive
+                _vid, ctlm, _ = o.alive_view()
+                assert np.all(acts[e, :n][ctlm == 0] == 0) and np.all(acts[e, n:] == 0), "uncontrolled slots get 0 (main.py:401)"
+                rec = o.tick(acts[e, :n])
+                f = flags[e, :n]
+                order = np.lexsort((lanej[e, :n] & 0xFFFF, (f >> 6) & 3, lanej[e, :n] >> 16))
+                ctl = order[((f & 2) != 0)[order]]
+                assert len(ctl) == len(rec["ids"]), "controlled set: tick %d env %d" % (t, e)
+                assert close(rec["reward"], rew[e, ctl], 1e-9), "reward: tick %d env %d" % (t, e)
+        for e, o in enumerate(oracles):
+            info, vi, vf = state_snapshot(one, e)
+            ovi, ovf, _, _ = o.vehicles()
+            assert np.array_equal(vi[:, :13], ovi[:, :13]), "state ints after the oracle ticks, env %d" % e
+            assert close(ovf[:, :5], vf[:, :5], 1e-9), "state floats after the oracle ticks, env %d" % e
+
+    def same_outputs(o1, o2, what):
+        f = _np(o1["flags"])
+        assert np.array_equal(f, _np(o2["flags"])), what + ": flags"
+        alive, ctl = (f & 1) != 0, (f & 2) != 0
+        for k in ("reward", "new_slot", "lanej"):
+            assert np.array_equal(_np(o1[k])[alive], _np(o2[k])[alive]), what + ": " + k
+        assert np.array_equal(_np(o1["nbr"])[ctl], _np(o2["nbr"])[ctl]), what + ": nbr"
+        assert np.array_equal(_np(o1["env_out"]), _np(o2["env_out"])), what + ": env_out"
+
+    def same_rows(what):
+        post_ctl = (_np(one.state_field("meta")) & 0x81) == 0x81
+        assert np.array_equal(_np(one.obs)[post_ctl], _np(many.obs)[post_ctl]), what + ": observation rows"
+
+    n_ctl = 0
+    for n in chunks:
+        for _ in range(n):
+            o1 = one.step_with_actor()
+        ch_t = 0 if n < 6 else (n // 3 + 1)
+        o2 = many.step_many(n, actor=True, chunk=ch_t, persistent=persistent)
+        want = "tick" if backend == "emu" else ("persistent" if (persistent and ch_t > 0 and n > ch_t) else "resident")
+        assert many.last_launch() == want, (many.last_launch(), want, n)
+        one.synchronize(); many.synchronize()
+        what = "lane_num %d closed loop, call of %d" % (lane_num, n)
+        batches_equal(one, many, what)
+        same_outputs(o1, o2, what)
+        same_rows(what)
+        n_ctl += int(_np(o1["env_out"])[:, 1].sum())
+    traj = many.step_many(trajectory_chunk, actor=True, trajectory=True, chunk=trajectory_chunk // 2 + 1, persistent=persistent)
+    for k in range(trajectory_chunk):
+        o1 = one.step_with_actor()
+        same_outputs(o1, {n: traj[n][k] for n in traj}, "trajectory tick %d" % k)
+        post_ctl = (_np(one.state_field("meta")) & 0x81) == 0x81
+        assert np.array_equal(_np(one.obs)[post_ctl], _np(traj["obs_post"][k])[post_ctl]), "trajectory obs, tick %d" % k
+    batches_equal(one, many, "after the trajectory chunk")
+    m1, m2 = one.metrics(), many.metrics()
+    for k in m1:
+        assert m1[k] == m2[k], (k, m1[k], m2[k])
+    assert n_ctl >= 3 * len(chunks) * n_envs and m1["overflow"] == 0, (n_ctl, m1)
+    return m1
+
+
 def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=None, calls=(40, 25, 60, 35), seed=81, n_pool=7,
                                obs_dtype=torch.float64, chunk=0, source="pool", min_ctl_per_tick=5, lane_num=12, persistent=False):
     """Training outputs on the fast path (lane_num 4 / 8: f3 x f4):

@@ -100,3 +100,13 @@ def test_emulated_step_many_geo_table_source(lane_num, cap):
 def test_geo_work_queue_item_schedule_emulated(lane_num, cap):
     """The persistent form of the general-geometry roll-out through the emulator's sequential work queue."""
     scenarios.check_step_many_geo(BACKEND, lane_num, n_envs=3, capacity=cap, chunks=(1, 7, 40, 20), trajectory_chunk=8, persistent=True)
+
+
+@pytest.mark.parametrize("lane_num,cap,dtype", [(4, 128, torch.float64), (8, 64, torch.float32)])
+def test_emulated_closed_loop_geo_vs_oracle_and_step_many(lane_num, cap, dtype):
+    """The closed loop for lane_num 4 / 8 (main.py:398-441; the shipped checkpoint's args.txt records lane_num = 4): actor
+    launch + general-geometry tick against the sequential oracle fed with the same actions, then pve_step_many(PVE_SRC_ACTOR)
+    == step_with_actor ticks (the emulator enqueues per-tick launches; the resident form is the GPU suite's)."""
+    scenarios.check_step_many_geo_actor(BACKEND, lane_num, n_envs=3, capacity=cap, chunks=(1, 9, 25), trajectory_chunk=7,
+                                        obs_dtype=dtype, oracle_ticks=120)
+
