@@ -653,7 +653,7 @@ def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chun
 
 
 def check_step_many_geo_actor(backend, lane_num, n_envs=6, capacity=128, seed=77, chunks=(1, 9, 30, 4, 45), rate=None,
-                              trajectory_chunk=11, obs_dtype=torch.float64, persistent=False, oracle_ticks=0):
+                              trajectory_chunk=11, obs_dtype=torch.float64, persistent=False, oracle_ticks=0, strict=True):
     """The closed loop for the 4- / 8-lane layouts (main.py:398-441 drives every lane_num; the shipped checkpoint's args.txt
     records lane_num = 4): pve_step_many(PVE_SRC_ACTOR) -- the actor inside k_rollout_geo<.., ACT[, PERS]> -- == step_with_actor
     ticks (actor launch + k_tick_geo), bit for bit: persistent state, headers, observation rows, last-tick outputs and, in
@@ -734,7 +734,8 @@ def check_step_many_geo_actor(backend, lane_num, n_envs=6, capacity=128, seed=77
     m1, m2 = one.metrics(), many.metrics()
     for k in m1:
         assert m1[k] == m2[k], (k, m1[k], m2[k])
-    assert n_ctl >= 3 * len(chunks) * n_envs and m1["overflow"] == 0, (n_ctl, m1)
+    if strict:                                            # (a randomised soak may draw an empty or an overfull scene: both forms agree there too)
+        assert n_ctl >= 3 * len(chunks) * n_envs and m1["overflow"] == 0, (n_ctl, m1)
     return m1
 
 

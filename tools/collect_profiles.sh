@@ -26,6 +26,12 @@ run bench_actor_chunked.json $NB --actor --persistent 0
 run bench_actor_f64.json $NB --actor --obs-f64
 run bench_actor_step.json $NB --actor --mode step
 run bench_actor_driver_like.json $NB --actor --steps 20 --warmup 5
+run bench_actor_lanes4.json $NB --actor --lane-num 4
+run bench_actor_lanes4_step.json $NB --actor --lane-num 4 --mode step
+run bench_actor_lanes4_chunked.json $NB --actor --lane-num 4 --persistent 0
+run bench_actor_lanes8.json $NB --actor --lane-num 8
+run bench_actor_lanes8_step.json $NB --actor --lane-num 8 --mode step
+run bench_actor_lanes4_cap64.json $NB --actor --lane-num 4 --capacity 64 --rate 1000
 run bench_trajectory.json $NB --trajectory 1
 run bench_pool.json $NB --tape pool
 run bench_pool_driver_like.json $NB --tape pool --steps 20 --warmup 5
@@ -46,6 +52,7 @@ st stats_step --mode step
 st stats_cap64 --capacity 64
 st stats_actor --actor --steps 300
 st stats_actor_step --actor --mode step --steps 300
+st stats_actor_lanes4 --actor --lane-num 4 --steps 300
 st stats_lanes8 --lane-num 8 --steps 300
 st stats_lanes4 --lane-num 4 --capacity 64 --rate 1200 --steps 300
 # ---- HBM counters in their own passes (kernel-trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass).  The timed launch of a

@@ -27,6 +27,7 @@ summary(os.path.join(src, "stats_driver_like", "r_results.db"), prefix + "_kerne
 summary(os.path.join(src, "stats_cap64", "r_results.db"), prefix + "_kernel_stats_cap64.txt", 30)
 summary(os.path.join(src, "stats_actor", "r_results.db"), prefix + "_kernel_stats_actor.txt", 30)
 summary(os.path.join(src, "stats_actor_step", "r_results.db"), prefix + "_kernel_stats_actor_step.txt", 300)
+summary(os.path.join(src, "stats_actor_lanes4", "r_results.db"), prefix + "_kernel_stats_actor_lanes4.txt", 12)
 summary(os.path.join(src, "stats_lanes8", "r_results.db"), prefix + "_kernel_stats_lanes8.txt", 12)
 summary(os.path.join(src, "stats_lanes4", "r_results.db"), prefix + "_kernel_stats_lanes4.txt", 4)
 summary(os.path.join(src, "stats_chunked", "r_results.db"), prefix + "_kernel_stats_chunked.txt", 30)

@@ -52,7 +52,7 @@ print("%d runs: %d green, %d ended at a deferred spawn, 0 differences" % (a.runs
 # pve_step_many (k_rollout: still ticks, staged ticks, chunked launches, trajectory outputs) == single ticks, bit for bit
 for k in range(a.many):
     kind = str(rng.choice(["k_rollout", "k_rollout", "actor", "geo", "geo", "state", "persistent", "persistent", "geo_state", "geo_table",
-                           "state_pers", "state_pers", "closed_state"]))
+                           "state_pers", "state_pers", "closed_state", "closed_geo", "closed_geo"]))
     seed = int(rng.integers(1, 1 << 30))
     t0 = time.time()
     if kind in ("k_rollout", "actor"):
@@ -100,6 +100,18 @@ for k in range(a.many):
                                                chunk=int(rng.choice([3, 7, 16])), seed=seed, persistent=pers,
                                                obs_dtype=torch.float32 if rng.random() < 0.5 else torch.float64)
         what = "cap %3d closed-loop state rows calls %s rate %6.0f persistent %s" % (cap, calls, rate, pers)
+    elif kind == "closed_geo":                                  # round 5: closed loop for 4 / 8 lanes inside k_rollout_geo<.., ACT[, PERS]>
+        import torch
+        ln = int(rng.choice([4, 8]))
+        cap = int(rng.choice([64, 128]))
+        lo, hi = RATES[(ln, cap)]
+        rate = float(rng.uniform(lo, hi * 0.7))
+        pers = bool(rng.random() < 0.6)
+        chunks = tuple(int(x) for x in rng.integers(1, 60, size=int(rng.integers(2, 5))))
+        scenarios.check_step_many_geo_actor(a.backend, ln, n_envs=int(rng.choice([3, 9, 40, 300])) if pers else int(rng.choice([3, 8, 12])),
+                                            capacity=cap, chunks=chunks, rate=rate, trajectory_chunk=int(rng.integers(2, 20)), seed=seed,
+                                            obs_dtype=torch.float32 if rng.random() < 0.5 else torch.float64, persistent=pers, strict=False)
+        what = "%d lanes cap %3d rate %6.0f closed loop chunks %s persistent %s" % (ln, cap, rate, chunks, pers)
     elif kind in ("geo_state", "geo_table"):                    # f3 x f4 (round 4): training outputs / id-indexed table for 4 / 8 lanes
         import torch
         ln = int(rng.choice([4, 8]))
