@@ -31,7 +31,7 @@ summary(os.path.join(src, "stats_actor_lanes4", "r_results.db"), prefix + "_kern
 summary(os.path.join(src, "stats_lanes8", "r_results.db"), prefix + "_kernel_stats_lanes8.txt", 12)
 summary(os.path.join(src, "stats_lanes4", "r_results.db"), prefix + "_kernel_stats_lanes4.txt", 4)
 summary(os.path.join(src, "stats_chunked", "r_results.db"), prefix + "_kernel_stats_chunked.txt", 30)
-for extra in ("phase_counters.txt", "persistent_trace.txt", "ab_launch_shapes.txt", "ab_launch_shapes_cap64.txt", "soak_random.txt", "soak_random_many.txt"):
+for extra in ("phase_counters.txt", "pmc_ta_persist.txt", "persistent_trace.txt", "ab_launch_shapes.txt", "ab_launch_shapes_cap64.txt", "soak_random.txt", "soak_random_many.txt"):
     if os.path.isfile(os.path.join(src, extra)):
         shutil.copyfile(os.path.join(src, extra), os.path.join(prof, prefix + "_" + extra))
 for m in ("persist", "persist_short", "rollout", "step"):
