@@ -50,7 +50,7 @@ enum {
 #define PVE_CFG_OBS_F32      0x2   /* flags: pve_outputs.obs_post and the actor's obs input hold float32 [n_envs][cap][28]
                                       (the type the actor consumes, model_agent_maddpg.py:15; SURVEY.md 8d "FP32 observation
                                       output": 268 instead of 380 algorithmic bytes per slot-step).  Fused ticks only:
-                                      obs_pre / state_pre follow (lane_num 12; refused for lane_num 4 / 8); pve_compact(obs) is refused. */
+                                      obs_pre / state_pre follow the row type (every lane_num); pve_compact(obs) is refused. */
 #define PVE_CFG_GEO_SCAN     0x4   /* flags (diagnostics): the general-geometry kernel finds list members by scanning every controlled
                                       vehicle (its fallback when an intersection's lists overflow the LDS entry pool) instead of reading
                                       the per-route lists; results are identical (tested) */
