@@ -635,7 +635,7 @@ template <int CAP, bool FIX4 = false, int WPE = 4, bool TRAIN = false, bool IDT 
 __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_rollout_geo(const GeoConst g_arg, const Params P_arg,
                                                                                                 const RolloutArgs R_arg)
 {
-    static_assert(!PERS || (!TRAIN && !IDT), "the persistent form of the geometry kernel: pool / zero / actor sources");
+    static_assert(!(TRAIN && IDT), "lane_num 4 / 8: the table source without the training outputs");
     static_assert(!ACT || (!TRAIN && !IDT), "the closed loop of the geometry kernel: one action source, no training outputs");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(GeoConst) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
@@ -666,10 +666,8 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             int e, ch, kb, nt;
             if (!q_take(R, P.n_envs, t0_, q_word, e, ch, kb, nt)) break;
             env0_ = e; chunk_ = ch; k_base_ = kb; n_ticks = nt;
-            if (R.source == 1) {
-                pool_idx = (R.pool_tick0 + k_base_) % R.n_pool;
-                act0 = R.pool + (size_t)pool_idx * (size_t)P.n_envs * CAP;
-            }
+            if (R.source == 1 || R.source == 3) pool_idx = (R.pool_tick0 + k_base_) % R.n_pool;
+            if (R.source == 1) act0 = R.pool + (size_t)pool_idx * (size_t)P.n_envs * CAP;
         }
         // ACT (cf. k_rollout): the first item of an intersection in a call computes its first actions from the caller's rows,
         // every later item takes them from `actor_actions`, where the previous item's last tick left them
@@ -791,7 +789,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             T::ph_carry_over(t, sh, r, fc);
         } else {
             lds_barrier();                            // A: nobody reads the tick's work arrays any more
-            if (TRAIN && O.state_pre) T::ph_state(P, O, env, t, sh, r);   // (uniform; barrier A also orders the obs_pre rows of this tick)
+            // (uniform; barrier A also orders the obs_pre rows of this tick.  PERS: the stale rows of an item's first tick are what
+            //  ANOTHER workgroup's item stored: coherent loads)
+            if (TRAIN && O.state_pre) T::template ph_state<PERS>(P, O, env, t, sh, r);
             T::ph_stage(g, t, sh, r, fc);
             if constexpr (IDT) { if (fc.sp_slot >= 0) sh.p[fc.sp_slot] = sp_act; }
             if constexpr (ACT) {
@@ -1057,7 +1057,10 @@ struct Backend {
         const bool act = R.source == 2 /* PVE_SRC_ACTOR */;
         if (off || P_in.phase_cycles || (train && (R.source == 3 || act))) return 1;
         if (act && (act_off || R.exact_f32 || (R.queue && !R.actor_actions))) return 1;
-        if (R.queue && (train || R.source == 3)) return 1;                    // (the queue form: pool / zero / actor sources)
+        const bool fix4 = g.lane_num == 4;           // (the 4-lane layout's far-conflict path is a kernel of its own)
+        // (the queue form with the training outputs: 8 lanes only -- the 4-lane variant would carry 32-46 spilled registers through
+        //  the tick; its trainer roll-out stays on chunked launches)
+        if (R.queue && train && fix4) return 1;
         hipStream_t s = (hipStream_t)stream;
         Params P = P_in;
         RolloutArgs Rk = R;
@@ -1067,7 +1070,6 @@ struct Backend {
         } else P.actions = nullptr;
         if (R.source == 3) Rk.pool_tick0 = R.pool_tick0 % R.n_pool;
         dim3 grid(P.n_envs);
-        const bool fix4 = g.lane_num == 4;           // (the 4-lane layout's far-conflict path is a kernel of its own)
         if (R.queue) {
             // the persistent form: as many workgroups as the chip holds at once (the variants of one capacity share their register
             // budget; the actor's parameters add 2 KB of LDS: a query of its own)
@@ -1084,9 +1086,16 @@ struct Backend {
         // (variant = layout x capacity x {default, training outputs, id-indexed table, actor} x launch form)
 #define PVE_LAUNCH_GEO_V(CAP_, FIX_, TRAIN_, IDT_, PERS_, ACT_) \
         hipLaunchKernelGGL((k_rollout_geo<CAP_, FIX_, 4, TRAIN_, IDT_, PERS_, ACT_>), grid, dim3(CAP_), 0, s, g, P, Rk)
+#define PVE_LAUNCH_GEO_TRAINQ_true(CAP_) (void)0      /* (refused above: never instantiated) */
+#define PVE_LAUNCH_GEO_TRAINQ_false(CAP_) PVE_LAUNCH_GEO_V(CAP_, false, true, false, true, false)
 #define PVE_LAUNCH_GEO(CAP_, FIX_)                                                                                              \
         do {                                                                                                                    \
-            if (R.queue) { if (act) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, true, true); else PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, true, false); } \
+            if (R.queue) {                                                                                                       \
+                if (act) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, true, true);                                                 \
+                else if (train) { PVE_LAUNCH_GEO_TRAINQ_##FIX_(CAP_); }                                                          \
+                else if (R.source == 3) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, true, true, false);                                   \
+                else PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, true, false);                                                    \
+            }                                                                                                                    \
             else if (act) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, false, true);                                               \
             else if (train) PVE_LAUNCH_GEO_V(CAP_, FIX_, true, false, false, false);                                             \
             else if (R.source == 3) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, true, false, false);                                     \
@@ -1104,6 +1113,8 @@ struct Backend {
             PVE_LAUNCH_GEO(128, false);
         }
 #undef PVE_LAUNCH_GEO
+#undef PVE_LAUNCH_GEO_TRAINQ_true
+#undef PVE_LAUNCH_GEO_TRAINQ_false
 #undef PVE_LAUNCH_GEO_V
         return check_launch(err);
     }

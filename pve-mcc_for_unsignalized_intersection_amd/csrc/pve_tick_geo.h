@@ -1138,7 +1138,9 @@ template <int CAP> struct TickGeo {
         }
         r.mmask = fresh;
     }
-    template <class ROW, class OutT>
+    // COH (persistent roll-out, cf. Tick::state_rows): the stale rows of an item's first tick were stored by ANOTHER workgroup of
+    // this launch (block k - 1 of the trajectory belongs to the previous item of the intersection): coherent loads
+    template <class ROW, bool COH, class OutT>
     static PVE_HD void state_rows(const OutT &O, size_t base, int t, const Regs &r)
     {
         ROW *dst = (ROW *)O.state_pre + (base + t) * (size_t)((NNB + 1) * OBSW);
@@ -1149,16 +1151,22 @@ template <int CAP> struct TickGeo {
             const int x = r.kr[q];
             ROW *row = dst + (q + 1) * OBSW;
             if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = (ROW)0; continue; }
-            const ROW *src = ((r.mmask >> q) & 1) ? (pre + (base + x) * OBSW) : (prev + (base + x) * OBSW);
+            const bool fresh = (r.mmask >> q) & 1;
+            if (COH && !fresh) {
+                const ROW *src = prev + (base + x) * OBSW;
+                for (int k = 0; k < OBSW; k++) row[k] = gld<true>(src + k);
+                continue;
+            }
+            const ROW *src = fresh ? (pre + (base + x) * OBSW) : (prev + (base + x) * OBSW);
             for (int k = 0; k < OBSW; k++) row[k] = src[k];
         }
     }
-    template <class OutT>
+    template <bool COH = false, class OutT>
     static PVE_HD void ph_state(const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh, Regs &r)
     {
         if (!O.state_pre || !(r.alive && r.ctl)) return;
-        if (P.obs_f32) state_rows<float>(O, (size_t)env * CAP, t, r);
-        else state_rows<double>(O, (size_t)env * CAP, t, r);
+        if (P.obs_f32) state_rows<float, COH>(O, (size_t)env * CAP, t, r);
+        else state_rows<double, COH>(O, (size_t)env * CAP, t, r);
     }
     static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r) { ph_state(P, P.out, env, t, sh, r); }
 };

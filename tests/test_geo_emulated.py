@@ -110,3 +110,19 @@ def test_emulated_closed_loop_geo_vs_oracle_and_step_many(lane_num, cap, dtype):
     scenarios.check_step_many_geo_actor(BACKEND, lane_num, n_envs=3, capacity=cap, chunks=(1, 9, 25), trajectory_chunk=7,
                                         obs_dtype=dtype, oracle_ticks=120)
 
+
+@pytest.mark.parametrize("lane_num,cap", [(8, 64), (4, 128)])
+def test_geo_work_queue_table_source_emulated(lane_num, cap):
+    """PVE_SRC_TABLE through the work queue for the 4- / 8-lane layouts (k_rollout_geo<.., IDT, PERS>; round 5)."""
+    scenarios.check_step_many_geo(BACKEND, lane_num, n_envs=3, capacity=cap, chunks=(1, 7, 40, 20), trajectory_chunk=8, source="table",
+                                  persistent=True)
+
+
+def test_geo_work_queue_training_outputs_emulated():
+    """The trainer's roll-out of the 8-lane layout through the work queue (k_rollout_geo<.., TRAIN, PERS>; the 4-lane layout
+    keeps chunked launches): obs_pre / state_pre / 7-action vectors of every tick against the oracle."""
+    scenarios.check_step_many_state_rows(BACKEND, n_envs=3, capacity=64, calls=(25, 12, 30), chunk=7, lane_num=8, persistent=True,
+                                         obs_dtype=torch.float32, min_ctl_per_tick=1)
+    scenarios.check_step_many_state_rows(BACKEND, n_envs=2, capacity=128, calls=(20, 9), chunk=6, lane_num=4, persistent=True,
+                                         min_ctl_per_tick=1)
+

@@ -432,6 +432,21 @@ def test_gpu_closed_loop_geo_resident_equals_two_launches(lane_num, cap, n_envs,
     print("lane_num %d x %d closed loop (persistent=%s): %s" % (lane_num, cap, persistent, {k: m[k] for k in ("spawned", "passed", "collided", "ctl_steps")}))
 
 
+@pytest.mark.parametrize("lane_num,cap,n_envs,quant", [(8, 128, 300, None), (4, 64, 600, 1.0), (4, 128, 40, None), (8, 64, 9, 1.0)])
+def test_gpu_persistent_geo_table_source(lane_num, cap, n_envs, quant):
+    """PVE_SRC_TABLE through the work queue for lane_num 4 / 8 (k_rollout_geo<.., IDT, PERS>) == ticks with the table applied per tick."""
+    scenarios.check_step_many_geo(BACKEND, lane_num, n_envs=n_envs, capacity=cap, quantize=quant, persistent=True, chunks=(1, 7, 40, 25),
+                                  trajectory_chunk=16, source="table")
+
+
+@pytest.mark.parametrize("lane_num,cap,dtype,n_envs", [(8, 128, torch.float64, 40), (8, 64, torch.float32, 120), (4, 128, torch.float32, 12)])
+def test_gpu_persistent_geo_training_outputs(lane_num, cap, dtype, n_envs):
+    """The trainer's roll-out of the 8-lane layout through the work queue (k_rollout_geo<.., TRAIN, PERS>: the stale rows of an
+    item's first tick are another workgroup's stores) vs the oracle at every tick; lane_num 4 keeps chunked launches (asserted)."""
+    scenarios.check_step_many_state_rows(BACKEND, n_envs=n_envs, capacity=cap, calls=(30, 17, 40), chunk=7, lane_num=lane_num,
+                                         persistent=True, obs_dtype=dtype, min_ctl_per_tick=1)
+
+
 def test_gpu_two_persistent_launches_share_the_chip():
     """Two handles, each with its own persistent launch on its own stream (2 x 2048 envs, 2 x 2048 workgroups: twice what the
     chip holds at once, so workgroups of both launches wait for slots while others spin on their hand-offs), and a batch of

@@ -121,14 +121,19 @@ for k in range(a.many):
         if kind == "geo_state":
             dt = torch.float32 if rng.random() < 0.5 else torch.float64
             calls = tuple(int(x) for x in rng.integers(5, 60, size=int(rng.integers(2, 5))))
-            scenarios.check_step_many_state_rows(a.backend, n_envs=int(rng.choice([2, 5])), capacity=cap, calls=calls, rate=rate, seed=seed,
-                                                 obs_dtype=dt, chunk=int(rng.choice([0, 7, 16])), lane_num=ln, min_ctl_per_tick=0)
-            what = "%d lanes cap %3d state rows %s calls %s rate %6.0f" % (ln, cap, str(dt).split(".")[-1], calls, rate)
+            pers = bool(rng.random() < 0.5)                     # (round 5: 8 lanes through the work queue; 4 lanes stay chunked)
+            scenarios.check_step_many_state_rows(a.backend, n_envs=int(rng.choice([2, 5, 30])) if pers else int(rng.choice([2, 5])),
+                                                 capacity=cap, calls=calls, rate=rate, seed=seed, obs_dtype=dt,
+                                                 chunk=int(rng.choice([3, 7, 16])) if pers else int(rng.choice([0, 7, 16])), lane_num=ln,
+                                                 min_ctl_per_tick=0, persistent=pers)
+            what = "%d lanes cap %3d state rows %s calls %s rate %6.0f persistent %s" % (ln, cap, str(dt).split(".")[-1], calls, rate, pers)
         else:
             chunks = tuple(int(x) for x in rng.integers(1, 70, size=int(rng.integers(2, 5))))
-            scenarios.check_step_many_geo(a.backend, ln, n_envs=int(rng.choice([3, 8, 12])), capacity=cap, chunks=chunks, rate=rate,
-                                          trajectory_chunk=int(rng.integers(2, 20)), seed=seed, source="table")
-            what = "%d lanes cap %3d rate %6.0f table chunks %s" % (ln, cap, rate, chunks)
+            pers = bool(rng.random() < 0.5)                     # (round 5: the table source through the work queue)
+            scenarios.check_step_many_geo(a.backend, ln, n_envs=int(rng.choice([3, 12, 60, 300])) if pers else int(rng.choice([3, 8, 12])),
+                                          capacity=cap, chunks=chunks, rate=rate, trajectory_chunk=int(rng.integers(2, 20)), seed=seed,
+                                          source="table", persistent=pers)
+            what = "%d lanes cap %3d rate %6.0f table chunks %s persistent %s" % (ln, cap, rate, chunks, pers)
     elif kind == "geo":                                         # k_rollout_geo == k_tick_geo ticks
         ln = int(rng.choice([4, 8]))
         cap = int(rng.choice([64, 128]))
