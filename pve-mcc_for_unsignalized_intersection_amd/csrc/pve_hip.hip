@@ -624,7 +624,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu((CAP == 64 
 // TRAIN: the training outputs (obs_pre, state_pre) per tick of a trajectory roll-out; IDT: PVE_SRC_TABLE (actions by (tick,
 // vehicle id), gathered by the vehicle's own thread and parked at its NEW slot in `p[]`, which is free between FIN and the next
 // S1) -- as in k_rollout, variants of their own so that the default kernel keeps its register allocation.
-// PERS: the persistent work-queue form (k_rollout<.., PERS>: same queue, same hand-off), pool / zero / actor sources.
+// PERS: the persistent work-queue form (k_rollout<.., PERS>: same queue, same hand-off), every source; with the training outputs
+// for 8 lanes only (the 4-lane variant <.., true, 4, TRAIN, .., PERS> would spill 32-46 registers: never instantiated, refused by
+// launch_rollout_geo).
 // ACT: pve_step_many(PVE_SRC_ACTOR) -- the closed loop of main.py:398-441 for lane_num 4 / 8 resident on the chip, as in
 // k_rollout<.., ACT>: behind STAGE every wave runs the actor (pve_actor.h: actor_tile32) on its tiles of 32 controlled
 // vehicles, whose float32 / float64 rows FIN has just stored to obs_post; the phases here work per slot, so the list of the
