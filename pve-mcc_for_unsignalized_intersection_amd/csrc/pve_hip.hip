@@ -29,6 +29,11 @@ using namespace pve;
 #else
 #define PVE_KNOB(name_) ((const char *)nullptr)
 #endif
+// the HOME build of the persistent table-source kernel (k_rollout<128, 5, ..>, 10 workgroups per CU) is what launch_rollout
+// takes when it is eligible; -DPVE_HOME_DEFAULT=0 builds a library that keeps the 8-workgroup kernel (A/B)
+#ifndef PVE_HOME_DEFAULT
+#define PVE_HOME_DEFAULT 1
+#endif
 
 typedef __attribute__((address_space(4))) const char *KernargPtr;
 // diagnostics (pve_debug_phase_cycles): every wave keeps the clock ticks it spent in each phase (incl. the
@@ -307,7 +312,8 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     // (WPE = 5, the 96-VGPR experiment: the block without the lane << 16 | j words is 16 368 B -> 10 workgroups per CU)
-    typedef Shared<CAP, (CAP == 128 && WPE == 4)> ShT;
+    // (WPE = 5 also: HOME -- the carried per-slot fields live in LDS instead of registers, pve_tick_core.h)
+    typedef Shared<CAP, (CAP == 128 && WPE == 4), (WPE == 5)> ShT;
     __shared__ ShT sh;
     __shared__ __attribute__((aligned(64))) float aprm[ACT ? PV_TOTAL : 1];
     __shared__ uint8_t adsts[ACT ? CAP : 1];         // post-compaction slot of every dense thread's vehicle (255: gone)
@@ -392,6 +398,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         if constexpr (IDT) {                            // the first tick's action of the vehicle in this slot: table[row][id]
             r.act = r.alive ? table_action(R.pool, pool_idx, R.table_ids, r.id) : 0.0;
         }
+        T::ph_home_store(t0_, sh, r);                   // (HOME: the carried fields to their LDS homes; ordered by the loop's first barrier)
     }
     double sp_act = 0;                                  // IDT: the action of the vehicle this lane spawns
     for (int k = 0; k < n_ticks; k++) {
@@ -424,11 +431,28 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         T::ph_lists_a(c, t, sh);
         lds_barrier();
         PVE_PHASE_MARK(2)
-        T::ph_step3(c, t, sh, r);
+        const bool last_tick = k + 1 == n_ticks;      // (uniform)
+        T::ph_step3(c, t, sh, r, last_tick);
         T::ph_step3_publish(t, sh, r);
         T::ph_lists_b(t, sh);
         lds_barrier();
         PVE_PHASE_MARK(3)
+        if constexpr (ShT::HOME) {
+            // the 3 CAP entry pool: BUILD .. WALK in passes over groups of lists that fit it (one pass unless the intersection
+            // holds ~100 controlled vehicles; pve_tick_core.h, group_end)
+            T::ph_build_prep(c, t, sh, r);
+            T::ph_scan_init(r);
+            for (int d0 = 0, pass = 0; d0 < NL; pass++) {
+                const int d1 = __builtin_amdgcn_readfirstlane(T::group_end(sh, d0));
+                T::ph_build_fill(c, t, sh, r, d0, d1);
+                lds_barrier();
+                T::ph_rank(t, sh, pass, d0, d1);
+                lds_barrier();
+                T::ph_scan_lists(c, t, sh, r, d0, d1);
+                d0 = d1;
+                if (d0 < NL) lds_barrier();           // (the next pass files its entries over the lists this one has just read)
+            }
+        } else {
         T::ph_build(c, t, sh, r);
         lds_barrier();
         PVE_PHASE_MARK(4)
@@ -436,6 +460,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         lds_barrier();
         PVE_PHASE_MARK(5)
         T::ph_scan(c, t, sh, r);
+        }
         PVE_PHASE_MARK(11)
         T::ph_reward(c, t, sh, r);
         lds_barrier();
@@ -443,7 +468,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         int nx = -1;
         if (k + 1 < n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
         if constexpr (IDT) {
-            r.act_nx = (nx >= 0 && r.alive) ? table_action(R.pool, nx, R.table_ids, r.id) : 0.0;
+            int my_id = r.id;
+            if constexpr (ShT::HOME) my_id = sh.h_id[t];
+            r.act_nx = (nx >= 0 && r.alive) ? table_action(R.pool, nx, R.table_ids, my_id) : 0.0;
         } else T::ph_prefetch_action(P, R, env, t, nx, r);
         T::ph_effects(c, t, sh, r);
         lds_barrier();
@@ -460,13 +487,13 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             if (t < NL && nx >= 0 && !sp_late && ((want >> t) & 1u))
                 sp_act = table_action(R.pool, nx, R.table_ids, sh.hd.id_seq + __builtin_popcount(want & ((1u << t) - 1u)));
         }
-        T::ph_lock(c, t, sh, r);
+        T::ph_lock(c, t, sh, r, last_tick);
         lds_barrier();
-        T::ph_lock2(t, sh, r);
+        T::ph_lock2(t, sh, r, last_tick);
         T::ph_keep_prefix(t, sh);
         lds_barrier();                                // (also what orders the previous tick's output stores before this tick's)
         PVE_PHASE_MARK(8)
-        if constexpr (!ACT && !IDT) T::ph_park_action(t, sh, r);
+        if constexpr (!ACT && !IDT) { if (!(ShT::HOME && last_tick)) T::ph_park_action(t, sh, r); }   // (HOME, last tick: the cells hold the jerks)
         const Outputs O = T::template tick_outputs<TRAIN>(P, R, k_base_ + k);
         if constexpr (ACT) {
             adst = -1;
@@ -479,6 +506,8 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             // (a full intersection: who spawns is known since FIN only; the gather is in flight under barrier A and STAGE)
             if (sp_late) sp_act = (fc.sp_slot >= 0 && nx >= 0) ? table_action(R.pool, nx, R.table_ids, fc.sp_id) : 0.0;
         }
+        HomeRegs hr;
+        T::ph_home_take(t, sh, r, fc, hr);                 // (HOME; the last reads of the old arrangement)
         if (fc.still) {                               // (uniform) nobody moves: the registers carry over
             T::ph_stage_header(t, sh, fc);
             T::ph_carry_over(t, sh, r, fc);
@@ -488,6 +517,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             //  ANOTHER workgroup's item stored -- block k - 1 of the trajectory --: coherent loads)
             if (TRAIN && O.state_pre) T::template ph_state<PERS>(P, O, env, t, sh, r);
             T::ph_stage(c, t, sh, r, fc);
+            T::ph_home_put(t, sh, fc, hr);
             if constexpr (IDT) { if (fc.sp_slot >= 0) sh.act_next[fc.sp_slot] = sp_act; }
             if constexpr (ACT) {
                 // next tick's actions: the vehicle lane t spawns gets the action of an all-zero row (ref :380, :420), the
@@ -527,6 +557,11 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     if constexpr (PERS) q_leave(*(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R), t0_);
 }
 
+// tools/probe_kernel.sh: compile ONE variant of k_rollout (seconds instead of minutes for the whole library) to read its register
+// allocation / ISA while working on it: -DPVE_PROBE_ONE="128, 5, false, false, false, true, true"
+#ifdef PVE_PROBE_ONE
+template __global__ void k_rollout<PVE_PROBE_ONE>(const Const, const Params, const RolloutArgs);
+#else
 // General-geometry tick (lane_num 4 / 8): same workgroup-per-intersection structure, phases of
 // pve_tick_geo.h (per-route sorted lists: PAIRS -> RANK -> WALK; the membership scan only as the overflow fallback).
 // Registers: 5 waves per SIMD (<= 96 VGPR) for CAP = 128 = 10 workgroups per CU.  CAP = 64 is one wave per workgroup and its
@@ -888,7 +923,7 @@ static std::string hip_err(const char *what, hipError_t e)
 struct OccCache {
     static constexpr int MAX_DEV = 64;
     std::mutex mu;
-    int wgs[MAX_DEV][3][2] = {};       // family: 0 = k_rollout, 1 = k_rollout_geo, 2 = k_rollout_geo with the actor
+    int wgs[MAX_DEV][4][2] = {};       // family: 0 = k_rollout, 1 = k_rollout_geo, 2 = k_rollout_geo with the actor, 3 = k_rollout<128, 5, ..> (HOME)
     int n_cu[MAX_DEV] = {};
     // -> workgroups the device holds at once for (family, cap), or -1 (err set); `query` = the occupancy call of the variant
     template <typename Q>
@@ -1019,20 +1054,26 @@ struct Backend {
             else hipLaunchKernelGGL((k_rollout<128, 4, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
             return check_launch(err);
         }
+        // k_rollout<128, 5, ..>: the HOME build of the persistent kernel (128 slots; table, pool and zero sources) -- 93 / 89 registers
+        // + the 16 368 B block with the carried per-slot fields in LDS homes = 10 workgroups per CU instead of 8, no scratch
+        // (pve_tick_core.h: Homes).  Its packed seq_in_lane | id_info[1] word holds arrival cursors < 2^23.  Only the queue form:
+        // a plain launch of 4096 workgroups would run as 2560 + 1536.
+        const bool home_ok = pers && !act && !train && cap == 128 && P.rows < (1 << 23);
+        bool home5 = PVE_HOME_DEFAULT != 0 && home_ok;
 #ifdef PVE_AB_KNOBS
-        // A/B knob: the 96-VGPR build of the headline kernel (table source, persistent form, 128 slots): 10 workgroups per CU with the
-        // 16 KB LDS block, at the price of ~30 scratch accesses per tick
-        if (getenv("PVE_ROLLOUT_WPE5") && pers && idt && !train && cap == 128) {
-            int nb = 0; hipDeviceProp_t prop; int dev = 0;
-            (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rollout<128, 5, false, false, false, true, true>, 128, 0);
-            long long g5 = (long long)nb * prop.multiProcessorCount;
+        if (const char *k5 = getenv("PVE_ROLLOUT_WPE5")) home5 = atoi(k5) != 0 && home_ok;   // A/B knob
+#endif
+        if (home5) {
+            long long g5 = g_occ.resident(3, cap, [&](int *nb) {
+                return hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout<128, 5, false, false, false, true, true>, 128, 0); }, err);
+            if (g5 < 0) return -1;
             const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
+            if (const char *g = PVE_KNOB("PVE_PERSISTENT_GRID")) { const long long v = atoll(g); if (v > 0) g5 = v; }   // A/B knob
             if (g5 > items) g5 = items;
-            hipLaunchKernelGGL((k_rollout<128, 5, false, false, false, true, true>), dim3((unsigned)g5), dim3(128), 0, s, c, P, Rk);
+            if (idt) hipLaunchKernelGGL((k_rollout<128, 5, false, false, false, true, true>), dim3((unsigned)g5), dim3(128), 0, s, c, P, Rk);
+            else hipLaunchKernelGGL((k_rollout<128, 5, false, false, false, false, true>), dim3((unsigned)g5), dim3(128), 0, s, c, P, Rk);
             return check_launch(err);
         }
-#endif
         // variant = capacity x action source (pool / zero, actor, id-indexed table) x training outputs x launch form
 #define PVE_ROLLOUT(ACT_, TRAIN_, IDT_, PERS_)                                                                                           \
         do {                                                                                                                             \
@@ -1202,3 +1243,4 @@ struct Backend {
 };
 
 #include "pve_capi.inc"
+#endif   // PVE_PROBE_ONE

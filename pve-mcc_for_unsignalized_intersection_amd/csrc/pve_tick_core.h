@@ -22,6 +22,7 @@
 #include "pve_types.h"
 #include <math.h>
 #include <string.h>
+#include <type_traits>
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PVE_AS4 __attribute__((address_space(4)))
@@ -310,10 +311,29 @@ PVE_HD int mad24(int a, int b, int c)
 }
 
 // ------------------------------------------------------------------ shared (LDS) block of one env
-template <int CAP, bool LJ = (CAP == 128)> struct Shared {
+// HOME (k_rollout<128, 5, ..>: the 96-register / 10-workgroups-per-CU build of the resident kernel): the per-slot state lives
+// in LDS, registers hold it only inside the phase that works on it.  The fields that are merely CARRIED through most of the
+// tick -- jerk_sum, closer_p, id, seq_in_lane | id_info[1], count -- have arrays of their own: FX updates count / jerk_sum in
+// place, the dense thread files closer_p where it belongs, the table source reads the id where it needs it.  vir_dis stays in
+// virdis[], p / v / a in p[] / v[] / a[] (S1 reads them there, and the next action in act_next[], instead of RELOAD handing
+// them over in registers).  When vehicles move, a thread takes its values at the very end of FIN (the registers of the
+// observation row are free again) and puts them at the new slot behind barrier A.  The entry pool shrinks to 3 CAP entries to
+// pay for the homes (the block stays at 16 368 B): BUILD .. WALK run in passes over groups of lists when a tick needs more.
+template <int CAP> struct Homes {
+    double h_jerk_sum[CAP], h_closer[CAP];
+    int h_id[CAP], h_sv[CAP], h_count[CAP];          // h_sv = seq_in_lane << 8 | id_info[1] (id_info[1] < CAP <= 128, rows < 2^23)
+};
+template <int CAP> struct HomesOff {};              // (empty base: the other blocks keep their size to the byte)
+struct HomeRegs { double jerk_sum, closer, vir_dis; int id, sv, count; };
+// POOL_: entries of the list pool (HOME: >= 2 CAP + 36 so that the staging overlays fit; the CPU test emulator instantiates a
+// smaller pool than the kernel's 3 CAP to drive ordinary traffic through the multi-pass form)
+template <int CAP, bool LJ = (CAP == 128), bool HOME_ = false, int POOL_ = (HOME_ ? 3 : 5) * CAP>
+struct Shared : std::conditional<HOME_, Homes<CAP>, HomesOff<CAP>>::type {
     static constexpr int NW = CAP / 64;
+    static constexpr bool HOME = HOME_;
+    static_assert(!HOME_ || (POOL_ * 4 >= 2 * CAP * 4 + CAP + 1 && POOL_ >= CAP && POOL_ % 8 == 0), "HOME: the staging overlays need 2 CAP ints + CAP + 1 bytes of s_idx");
     static constexpr bool PIN_READS = true;   // walk_window: keep the batched window reads from being sunk into guarded blocks
-    static constexpr int POOL = 5 * CAP;
+    static constexpr int POOL = POOL_;
     // virtual-lane lists (ref :238-273): list d = own controlled vehicles + those of the <=4 conflict
     // lanes; u_* = entries in segment order, s_* = sorted by (vd, slot). 5*CAP bounds the total.
     // CAP = 128: the entries sorted by (vd, slot) are an index array into u_vd / u_slot (no second copy of the
@@ -346,6 +366,7 @@ template <int CAP, bool LJ = (CAP == 128)> struct Shared {
     enum { SF_JERK = 0, SF_JERK_SUM, SF_VIR_DIS, SF_CLOSER_P, SF_P, SF_V, SF_A };
     template <int K> PVE_HD double *stf()
     {
+        if (HOME) return K == SF_JERK ? u_vd + CAP : (K == SF_P ? p : (K == SF_V ? v : a));   // (p in place too; the rest has homes)
         return K < 4 ? u_vd + (K + 1) * CAP : (K == SF_P ? u_vd : (K == SF_V ? v : a));
     }
     // k_rollout, LOCK2 -> FIN: kept vehicles below every slot (index CAP: all of them), so that FIN's new lane starts and the
@@ -361,6 +382,7 @@ template <int CAP, bool LJ = (CAP == 128)> struct Shared {
     template <int K> PVE_HD int *sti()   // K = I_ID .. I_HDR
     {
         if (DIRECT) return (int *)s_vd + K * CAP;
+        if (HOME) return K == I_STEP ? (int *)s_idx : (K == I_META ? (int *)s_idx + CAP : cnt);   // (step, meta; the header word)
         return K < 2 ? (int *)s_idx + K * CAP : (K < 4 ? (int *)p + (K - 2) * CAP : (K == 4 ? cnt : (K == 5 ? (int *)u_slot : (int *)(u_list + CAP))));
     }
     int acc_passed_steps, acc_collisions;
@@ -760,6 +782,16 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         }
     }
 
+    // HOME: the carried fields LOAD has fetched go to their LDS homes (once per launch / queue item, in front of the tick loop)
+    static PVE_HD void ph_home_store(int t, Sh &sh, Regs &r)
+    {
+        if constexpr (Sh::HOME) {
+            sh.h_jerk_sum[t] = r.jerk_sum; sh.h_closer[t] = r.closer_p;
+            sh.h_id[t] = r.id; sh.h_sv[t] = (r.seq << 8) | (r.vnum & 0xFF); sh.h_count[t] = r.count;
+            sh.p[t] = r.p; sh.v[t] = r.v; sh.a[t] = r.a; sh.virdis[t] = r.vir_dis; sh.act_next[t] = r.act;
+        }
+    }
+
     // ============================================================== S1: step, both outcomes
     static PVE_HD void outcome(const PVE_AS4 Const &c, double p, double v, double a, bool ctl, double &pn, double &vn)
     {   // ref :1528-1535
@@ -775,6 +807,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_step1(const PVE_AS4 Const &c, const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r)
     {
         r.ctl = 0; r.lane = 0; r.j = 0; r.a0 = r.a1 = 0;
+        if constexpr (Sh::HOME) {                         // the state lives in LDS (prologue / S3's publish / STAGE left it there)
+            r.p = sh.p[t]; r.v = sh.v[t]; r.a = sh.a[t]; r.act = sh.act_next[t];
+        }
         if (r.alive) {
             const int lane = (r.meta >> M_LANE_SHIFT) & M_LANE_MASK;    // (== slot_lane(sh.hd, t): slots are sorted by lane)
             r.lane = lane; r.j = t - sh.hd.lane_start[lane];
@@ -818,7 +853,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     }
 
     // ============================================================== S3: resolve the in-lane chain
-    static PVE_HD void ph_step3(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
+    // HOME: this tick's jerk leaves the registers right here -- a controlled vehicle's goes to its virdis[] cell (for the dense
+    // thread, as BUILD does otherwise) and into jerk_sum (ref :321; FX otherwise -- nobody reads jerk_sum in between); an
+    // uncontrolled vehicle's is only needed as persistent state, i.e. on the LAST tick of a launch / queue item: it waits in
+    // the slot's act_next[] cell (no next action to park then; BUILD's xy32 overlay only writes controlled slots).
+    static PVE_HD void ph_step3(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r, bool last = false)
     {
         if (r.alive) {
             int k = t;
@@ -831,6 +870,10 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             r.p = br ? sh.p1[t] : sh.p[t];
             r.v = br ? sh.v1[t] : sh.v[t];
             r.step += 1;                                                          // ref :1533
+            if constexpr (Sh::HOME) {
+                if (r.ctl) { sh.virdis[t] = r.jerk; sh.h_jerk_sum[t] = sh.h_jerk_sum[t] + fabs(r.jerk * c.inv_dt); }
+                else if (last) sh.act_next[t] = r.jerk;
+            }
         }
     }
     static PVE_HD void ph_step3_publish(int t, Sh &sh, Regs &r)
@@ -873,12 +916,33 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 
     // ============================================================== BUILD: every controlled vehicle files
     // itself into its own lane's list and into the lists of the lanes it conflicts with (ref :240-270)
+    // HOME (entry pool of 3 CAP entries): the lists of a tick are worked in GROUPS of consecutive lists [d0, d1) that fit the
+    // pool -- BUILD files, RANK sorts and WALK reads one group per pass, entry indices relative to the group's first list.  One
+    // group is the rule (loff[NL] = own + conflict entries of every controlled vehicle <= 5 per vehicle; 3 CAP holds ~100
+    // controlled vehicles); a single list never exceeds CAP entries, so every group makes progress.  Uniform.
+    static PVE_HD int group_end(const Sh &sh, int d0)
+    {
+        if constexpr (!Sh::HOME) return NL;
+        else {
+            const int b = sh.loff[d0];
+            if (sh.loff[NL] - b <= Sh::POOL) return NL;   // (the rule: one read)
+            int d1 = d0 + 1;
+            while (d1 < NL && sh.loff[d1 + 1] - b <= Sh::POOL) d1++;
+            return d1;
+        }
+    }
     static PVE_HD void ph_build(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
+    {
+        ph_build_prep(c, t, sh, r);
+        ph_build_fill(c, t, sh, r, 0, NL);
+    }
+    static PVE_HD void ph_build_prep(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         sh.rew_ovr[t] = 0; sh.hdr[t] = -1;                // their storage was bb / pref until the barrier before BUILD
         // carried in LDS, not in a register (WALK overwrites it for the controlled vehicles, FIN reads it back).  A controlled
         // vehicle's old vir_dis is dead (ref :1348-1354 rewrite it): its cell hands this tick's jerk to the dense thread.
-        sh.virdis[t] = (r.alive && r.ctl) ? r.jerk : r.vir_dis;
+        // (HOME: S3 has done it; an uncontrolled vehicle's vir_dis stays where it is)
+        if constexpr (!Sh::HOME) sh.virdis[t] = (r.alive && r.ctl) ? r.jerk : r.vir_dis;
         // ---- dense mapping from here: thread t works for the t-th controlled vehicle
         r.dctl = t < mask_count<NW>(sh.m_ctl);
         r.ds = 0; r.dlane = 0; r.dp = 0;
@@ -888,9 +952,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         const double p = sh.p[sl];
         r.ds = sl; r.dlane = lane; r.dp = p;
         get_xy_f32(c, p, lane, sh.xy32[sl][0], sh.xy32[sl][1]);
+    }
+    // the entries of the lists [d0, d1) (HOME: one group of lists per pass; else all twelve)
+    static PVE_HD void ph_build_fill(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r, int d0, int d1)
+    {
+        if (!r.dctl) return;
+        const int sl = r.ds, lane = r.dlane;
+        const double p = r.dp;
+        const int gb = Sh::HOME ? (int)sh.loff[d0] : 0;       // entry index of the group's first list
         const int q = t - sh.cstart[lane];                    // its rank among the controlled vehicles of its lane
-        {
-            const int e = sh.loff[lane] + q;                  // own lane: vd = p (ref :242-249)
+        if (!Sh::HOME || (lane >= d0 && lane < d1)) {
+            const int e = sh.loff[lane] + q - gb;             // own lane: vd = p (ref :242-249)
             sh.u_vd[e] = p; sh.u_slot[e] = (uint8_t)sl; sh.u_list[e] = (uint8_t)lane;
         }
         if (lane % 3 == 2) return;                            // right turns conflict with nobody (ref :156)
@@ -914,7 +986,8 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         for (int k = 0; k < 4; k++) {
             const double delta = p - tA[k] + tB[k];                            // ref :733-803 (the relation is symmetric: kk =
             const double vd = (delta > 0) ? (tC[k] + delta) : INFINITY;        // our position inside lane2lane[d]); not chosen -> never sorted
-            const int e = lo[k] + so[k] + q;
+            const int e = lo[k] + so[k] + q - gb;
+            if constexpr (Sh::HOME) { if (d[k] < d0 || d[k] >= d1) continue; }   // (another pass's list)
             sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)sl; sh.u_list[e] = (uint8_t)d[k];
             lds_add(&sh.nfin[d[k]], (delta > 0) ? 1 : 0);                       // (unconditional: no guarded block per entry)
         }
@@ -931,16 +1004,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // the whole run of equal distances in slot order (every later arrival rewrites the same values; the LDS executes
     // the operations of a wave in order, so the last fix-up is the last write).  A stale word that happens to carry the
     // stamp (left-over LDS contents) only sends an entry through the fix-up, which then files just itself.
-    static PVE_HD void ph_rank(int t, Sh &sh, int salt = 0)
+    static PVE_HD void ph_rank(int t, Sh &sh, int salt = 0, int d0 = 0, int d1 = NL)
     {
-        const int M = sh.loff[NL];
+        const int gb = Sh::HOME ? (int)sh.loff[d0] : 0;   // (HOME: the lists [d0, d1) of this pass, entries relative to the first)
+        const int M = (Sh::HOME ? (int)sh.loff[d1] : (int)sh.loff[NL]) - gb;
         const unsigned tag = Sh::DIRECT ? 0u : (((unsigned)sh.hd.ticks + (unsigned)salt * 0x9E37u) << 16);
         for (int e = t; e < M; e += CAP) {
             const int d = sh.u_list[e];
             const double vd = sh.u_vd[e];
             if (!(vd < INFINITY)) continue;               // not chosen (ref :259-270): not part of the list; the finite entries
                                                           // occupy the sorted positions [0, nfin[d])
-            const int lo = sh.loff[d], hi = sh.loff[d + 1];
+            const int lo = sh.loff[d] - gb, hi = sh.loff[d + 1] - gb;
             int pos = 0, eq = 0;
             int f = lo;
             for (; f + 8 <= hi; f += 8) {                 // 8 independent LDS reads per round
@@ -1208,19 +1282,30 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     }
 
     // ============================================================== WALK: predecessor, 6 nearest, reward, hit
-    static PVE_HD void ph_scan(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_scan_init(Regs &r)
     {
         r.reward = 0; r.hit = 0; r.hdr = -1; r.djerk = 0;
 #pragma unroll
         for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
+    }
+    static PVE_HD void ph_scan(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
+    {
+        ph_scan_init(r);
+        ph_scan_lists(c, t, sh, r, 0, NL);
+    }
+    // (HOME: the lists [d0, d1) of this pass; ph_scan_init once in front of the first pass)
+    static PVE_HD void ph_scan_lists(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r, int d0, int d1)
+    {
+        const int gb = Sh::HOME ? (int)sh.loff[d0] : 0;
         // thread d < 12: lane d is non-empty -> its list was rebuilt (ref :234); head persisted for next tick's step (ref :1517).
         // The valid bits of the rebuilt lists are combined by two ballots and ONE read-modify-write of the header word: an LDS
         // atomic or / and per lane on that one word is expanded by the compiler's atomic optimizer into a scalar loop over the
         // active lanes (s_ff1 / v_readlane / ... : ~7 instructions x 12 lanes on the first wave's path, every tick)
-        const bool rebuilt = t < NL && sh.hd.lane_start[t < NL ? t + 1 : 0] > sh.hd.lane_start[t < NL ? t : 0];
+        const bool rebuilt = t < NL && sh.hd.lane_start[t < NL ? t + 1 : 0] > sh.hd.lane_start[t < NL ? t : 0] &&
+                             (!Sh::HOME || (t >= d0 && t < d1));
         bool hvalid = false;
         if (rebuilt) {
-            const int base = sh.loff[t];
+            const int base = sh.loff[t] - gb;
             if (sh.nfin[t] > 0) {
                 const int hr = Sh::DIRECT ? sh.s_slot[Sh::DIRECT ? base : 0] : sh.u_slot[sidx_at(sh.s_idx, base)];
                 hvalid = true;
@@ -1239,8 +1324,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 #endif
         if (!r.dctl) return;
         const int sl = r.ds, lane = r.dlane;
+        if constexpr (Sh::HOME) { if (lane < d0 || lane >= d1) return; }   // (another pass's list)
         const double ps = r.dp;
-        const int base = sh.loff[lane], n = sh.nfin[lane];    // (entries with a finite distance: the sorted list)
+        const int base = sh.loff[lane] - gb, n = sh.nfin[lane];   // (entries with a finite distance: the sorted list)
         int pr; double pvd;
         walk_window(sh, base, n, sh.mypos[sl], ps, r, pr, pvd);
         // ref :1348-1354
@@ -1314,6 +1400,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 #endif
         r.del = 0; r.fin = 0; r.coll_seen = 0; r.coll_fin = 0;
         int code = 0;                                     // what happens to the vehicle's reward (held by its dense thread)
+        if constexpr (Sh::HOME) r.p = sh.p[t];            // (S3's publish: no register from S3 to here; unconditional: no merge with an older value)
         if (r.alive) {
             const int cc = sh.cnt[t];                     // hits: the vehicle's own one and those of the vehicles before it |
             sh.cnt[t] = 0;                                // those of the vehicles behind it << 16 (the cell is re-used by LOCK)
@@ -1321,8 +1408,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             r.coll_seen = prev + (cc & 0xffff);                                   // ref :337-340
             r.coll_fin = r.coll_seen + (cc >> 16);
             if (r.ctl) {
+                if constexpr (Sh::HOME) sh.h_count[t] += 1;                       // ref :292 (jerk_sum: S3)
+                else {
                 r.count += 1;                                                     // ref :292
                 r.jerk_sum += fabs(r.jerk * c.inv_dt);                            // ref :321
+                }
                 if (r.coll_seen > 0) lds_add(&sh.acc_collisions, r.coll_seen);    // ref :337
             }
             if (r.p < c.exit_p || r.coll_seen > 0) {                              // ref :341-349
@@ -1371,15 +1461,22 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             if (rec1 < P.rows) r.next_arr = P.arrivals[(size_t)env * P.arr_env_stride + (size_t)rec1 * lane_num + t];
         }
     }
-    static PVE_HD void ph_lock(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_lock(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r, bool last = false)
     {
+        if constexpr (Sh::HOME) { if (r.dctl && last) sh.act_next[r.ds] = r.djerk; }   // (this tick's jerk back to the slot: ph_step3)
         if (r.dctl) {                                     // what FX decided for the vehicle's reward (ref :346, :357; reward[-1] -> rew_ovr)
             const int fx = sh.fxcode()[r.ds];
             const bool m10 = (sh.rew_ovr[r.ds] != 0) | (fx == 1);
             r.reward = m10 ? -10.0 : (fx == 2 ? 5.0 : r.reward);
-            ((double *)sh.xy32)[r.ds] = r.dcloser;        // closer_p (ref :302) back to the slot's thread; xy32 is dead after REWARD
+            if constexpr (Sh::HOME) sh.h_closer[r.ds] = r.dcloser;   // closer_p (ref :302) straight to its home
+            else ((double *)sh.xy32)[r.ds] = r.dcloser;   // closer_p (ref :302) back to the slot's thread; xy32 is dead after REWARD
         }
         block_sum(sh.red_reward, t, r.dctl ? r.reward : 0.0);
+        if constexpr (Sh::HOME) {
+            double js = 0;
+            if (r.fin) js = sh.h_jerk_sum[t];             // (FX's update of this very thread)
+            block_sum_sparse(sh.red_jerk, t, r.fin, js);                          // ref :358
+        } else
         block_sum_sparse(sh.red_jerk, t, r.fin, r.jerk_sum);                      // ref :358
         // Dead-lock scan (ref :365-370, :1469-1499), member-parallel: every controlled vehicle follows the
         // virtual-header pointers for <= 10 hops; if the walk returns to itself it is on a cycle.  Cycles are rare:
@@ -1428,10 +1525,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     }
     // LOCK2 (after a barrier): every cycle member files its record at its rank inside the cycle's scratch range
     // (u_vd / u_list are dead after the walk phase) = the reference's record_.sort() (ref :1492)
-    static PVE_HD void ph_lock2(int t, Sh &sh, Regs &r)
+    static PVE_HD void ph_lock2(int t, Sh &sh, Regs &r, bool last = false)
     {
+        if constexpr (Sh::HOME) { r.jerk = 0; if (last && r.alive) r.jerk = sh.act_next[t]; }   // (ph_step3; staged by FIN on the last tick only)
         r.cyc = sh.cnt[t];                                // (0 unless the dense thread of this slot's vehicle found a cycle)
-        if (r.alive && r.ctl) r.closer_p = ((double *)sh.xy32)[t];
+        if constexpr (!Sh::HOME) if (r.alive && r.ctl) r.closer_p = ((double *)sh.xy32)[t];
         if (r.cyc & 1) {
             const int e = sh.cyc_off[r.cyc >> 9] + ((r.cyc >> 5) & 15);
             sh.u_vd[e] = sh.virdis[t];
@@ -1572,7 +1670,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         // ---- per-slot meta
         int meta = 0, hdr_word = -1, new_slot = -1, lockf = 0;
         if (r.alive) {
-            r.v = sh.v[t]; r.a = sh.a[t];                  // back from LDS (S3 published them; dead in registers since then)
+            // back from LDS (S3 published them; dead in registers since then).  (HOME: only STAGE needs them -- ph_home_take reads
+            //  them at the end of FIN, not across the observation rows)
+            if constexpr (!(RES && Sh::HOME)) { r.v = sh.v[t]; r.a = sh.a[t]; }
             int coll = r.coll_fin > M_COLL_MASK ? M_COLL_MASK : r.coll_fin;
             meta = (r.meta & (M_CONTROL | M_FINISH | M_DONE | (M_LANE_MASK << M_LANE_SHIFT))) | M_ALIVE | (coll << M_COLL_SHIFT);
             if (r.cyc & 1) {
@@ -1592,7 +1692,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             }
             if (r.del) meta |= M_DEL;
             fc.meta = meta;
-            r.vir_dis = sh.virdis[t];                      // (kept in LDS since WALK / FX, like the header)
+            if constexpr (!(RES && Sh::HOME)) r.vir_dis = sh.virdis[t];   // (kept in LDS since WALK / FX, like the header)
             hdr_word = pack_lanej(sh, sh.hdr[t]);
             if (mask_test(keep, t)) {
                 new_slot = mask_rank<NW>(keep, t) + __builtin_popcount(sp & ((1u << r.lane) - 1u));
@@ -1600,10 +1700,14 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
                     store_slot(P, env, new_slot, r, meta, hdr_word, new_slot != t, r.ctl || new_slot != t);
                 else if (!still) {         // EARLY staging: these registers die here, as in the single-tick kernel
                     const int s = new_slot;
-                    sh.template stf<Sh::SF_JERK>()[s] = r.jerk; sh.template stf<Sh::SF_JERK_SUM>()[s] = r.jerk_sum;
-                    sh.template stf<Sh::SF_VIR_DIS>()[s] = r.vir_dis; sh.template stf<Sh::SF_CLOSER_P>()[s] = r.closer_p;
-                    sh.template sti<I_ID>()[s] = r.id; sh.template sti<I_SEQ>()[s] = r.seq; sh.template sti<I_VNUM>()[s] = r.vnum;
-                    sh.template sti<I_STEP>()[s] = r.step; sh.template sti<I_COUNT>()[s] = r.count;
+                    if (!Sh::HOME || full) sh.template stf<Sh::SF_JERK>()[s] = r.jerk;   // (HOME: persistent state only, i.e. for FLUSH)
+                    if constexpr (!Sh::HOME) {
+                        sh.template stf<Sh::SF_VIR_DIS>()[s] = r.vir_dis;
+                        sh.template stf<Sh::SF_JERK_SUM>()[s] = r.jerk_sum; sh.template stf<Sh::SF_CLOSER_P>()[s] = r.closer_p;
+                        sh.template sti<I_ID>()[s] = r.id; sh.template sti<I_SEQ>()[s] = r.seq; sh.template sti<I_VNUM>()[s] = r.vnum;
+                        sh.template sti<I_COUNT>()[s] = r.count;
+                    }
+                    sh.template sti<I_STEP>()[s] = r.step;
                     sh.template sti<I_META>()[s] = meta; sh.template sti<I_HDR>()[s] = hdr_word;
                 }
             }
@@ -1845,6 +1949,29 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_park_action(int t, Sh &sh, Regs &r) { sh.act_next[t] = r.act_nx; }   // xy32 is dead after REWARD
     // STAGE (after barrier A: nobody reads this tick's work arrays any more): every kept vehicle moves to its new slot,
     // the spawned ones are born, the header advances in place
+    // HOME: the vehicle in slot t takes its carried fields out of their homes at the very end of FIN (the last reader of the old
+    // arrangement) and puts them at its new slot behind barrier A
+    static PVE_HD void ph_home_take(int t, Sh &sh, Regs &r, const FinCarry &fc, HomeRegs &hr)
+    {
+        if constexpr (Sh::HOME) {
+            hr.jerk_sum = 0; hr.closer = 0; hr.vir_dis = 0; hr.id = 0; hr.sv = 0; hr.count = 0;
+            r.p = sh.p[t]; r.v = sh.v[t]; r.a = sh.a[t];         // (for STAGE's LATE staging, in place; unconditional: fresh values, no merge)
+            if (!fc.still && fc.new_slot >= 0) {
+                hr.jerk_sum = sh.h_jerk_sum[t]; hr.closer = sh.h_closer[t]; hr.vir_dis = sh.virdis[t];
+                hr.id = sh.h_id[t]; hr.sv = sh.h_sv[t]; hr.count = sh.h_count[t];
+            }
+        }
+    }
+    static PVE_HD void ph_home_put(int t, Sh &sh, const FinCarry &fc, const HomeRegs &hr)
+    {
+        if constexpr (Sh::HOME) {
+            if (fc.new_slot >= 0) {
+                const int s = fc.new_slot;
+                sh.h_jerk_sum[s] = hr.jerk_sum; sh.h_closer[s] = hr.closer; sh.virdis[s] = hr.vir_dis;
+                sh.h_id[s] = hr.id; sh.h_sv[s] = hr.sv; sh.h_count[s] = hr.count;
+            }
+        }
+    }
     static PVE_HD void ph_stage(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r, const FinCarry &fc)
     {
         if (fc.new_slot >= 0) {                          // LATE staging (the rest went at the top of FIN)
@@ -1854,11 +1981,20 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (fc.sp_slot >= 0) {                           // t < NL: the vehicle lane t spawns (ref :395-433)
             const int s = fc.sp_slot;
             sh.template stf<Sh::SF_P>()[s] = sel3(c.spawn_p, t % 3); sh.template stf<Sh::SF_V>()[s] = c.v0;
-            sh.template stf<Sh::SF_A>()[s] = 0; sh.template stf<Sh::SF_JERK>()[s] = 0; sh.template stf<Sh::SF_JERK_SUM>()[s] = 0;
-            sh.template stf<Sh::SF_VIR_DIS>()[s] = 100; sh.template stf<Sh::SF_CLOSER_P>()[s] = 150;
-            sh.template sti<I_ID>()[s] = fc.sp_id; sh.template sti<I_SEQ>()[s] = sh.hd.veh_rec[t];
-            sh.template sti<I_VNUM>()[s] = fc.sp_vnum; sh.template sti<I_STEP>()[s] = 0; sh.template sti<I_COUNT>()[s] = 0;
+            sh.template stf<Sh::SF_A>()[s] = 0; sh.template stf<Sh::SF_JERK>()[s] = 0;
+            if constexpr (Sh::HOME) sh.virdis[s] = 100;
+            if constexpr (!Sh::HOME) {
+                sh.template stf<Sh::SF_VIR_DIS>()[s] = 100;
+                sh.template stf<Sh::SF_JERK_SUM>()[s] = 0; sh.template stf<Sh::SF_CLOSER_P>()[s] = 150;
+                sh.template sti<I_ID>()[s] = fc.sp_id; sh.template sti<I_SEQ>()[s] = sh.hd.veh_rec[t];
+                sh.template sti<I_VNUM>()[s] = fc.sp_vnum; sh.template sti<I_COUNT>()[s] = 0;
+            }
+            sh.template sti<I_STEP>()[s] = 0;
             sh.template sti<I_META>()[s] = M_CONTROL | M_ALIVE | (t << M_LANE_SHIFT); sh.template sti<I_HDR>()[s] = -1;
+            if constexpr (Sh::HOME) {                    // (behind barrier A: the old occupant's values were taken at the end of FIN)
+                sh.h_jerk_sum[s] = 0; sh.h_closer[s] = 150; sh.h_id[s] = fc.sp_id;
+                sh.h_sv[s] = (sh.hd.veh_rec[t] << 8) | (fc.sp_vnum & 0xFF); sh.h_count[s] = 0;
+            }
             sh.hd.veh_rec[t] += 1;
             sh.hd.next_arr[t] = r.next_arr;
         }
@@ -1877,7 +2013,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_carry_over(int t, Sh &sh, Regs &r, const FinCarry &fc)
     {
         r.meta = fc.meta;
-        r.act = sh.act_next[t];                           // (parked by this very thread at the top of FIN)
+        if constexpr (!Sh::HOME) r.act = sh.act_next[t];  // (parked by this very thread at the top of FIN; HOME: S1 reads it there)
     }
     // RELOAD (after barrier B): slot t's vehicle from the staging arrays, its action from the prefetch
     static PVE_HD void ph_reload(int t, Sh &sh, Regs &r)
@@ -1888,13 +2024,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         r.p = r.v = r.a = r.jerk_sum = r.vir_dis = r.closer_p = 0;
         r.id = r.seq = r.vnum = r.step = r.count = r.meta = 0;
         if (t < N) {
-            r.p = sh.template stf<Sh::SF_P>()[t]; r.v = sh.template stf<Sh::SF_V>()[t]; r.a = sh.template stf<Sh::SF_A>()[t];
-            r.jerk_sum = sh.template stf<Sh::SF_JERK_SUM>()[t]; r.vir_dis = sh.template stf<Sh::SF_VIR_DIS>()[t];
-            r.closer_p = sh.template stf<Sh::SF_CLOSER_P>()[t];
-            r.id = sh.template sti<I_ID>()[t]; r.seq = sh.template sti<I_SEQ>()[t]; r.vnum = sh.template sti<I_VNUM>()[t];
-            r.step = sh.template sti<I_STEP>()[t]; r.count = sh.template sti<I_COUNT>()[t]; r.meta = sh.template sti<I_META>()[t];
+            if constexpr (!Sh::HOME) {
+                r.p = sh.template stf<Sh::SF_P>()[t]; r.v = sh.template stf<Sh::SF_V>()[t]; r.a = sh.template stf<Sh::SF_A>()[t];
+                r.vir_dis = sh.template stf<Sh::SF_VIR_DIS>()[t];
+                r.jerk_sum = sh.template stf<Sh::SF_JERK_SUM>()[t];
+                r.closer_p = sh.template stf<Sh::SF_CLOSER_P>()[t];
+                r.id = sh.template sti<I_ID>()[t]; r.seq = sh.template sti<I_SEQ>()[t]; r.vnum = sh.template sti<I_VNUM>()[t];
+                r.count = sh.template sti<I_COUNT>()[t];
+            }
+            r.step = sh.template sti<I_STEP>()[t]; r.meta = sh.template sti<I_META>()[t];
         }
-        r.act = sh.act_next[t];
+        if constexpr (!Sh::HOME) r.act = sh.act_next[t];
     }
     // work-array initialisation of a resident tick (what LOAD does besides loading), after the barrier behind RELOAD
     static PVE_HD void ph_tick_init(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
@@ -1913,11 +2053,19 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         if (t < N) {
             P.f64[F_P][g] = sh.template stf<Sh::SF_P>()[t]; P.f64[F_V][g] = sh.template stf<Sh::SF_V>()[t];
             P.f64[F_A][g] = sh.template stf<Sh::SF_A>()[t]; P.f64[F_JERK][g] = sh.template stf<Sh::SF_JERK>()[t];
-            P.f64[F_JERK_SUM][g] = sh.template stf<Sh::SF_JERK_SUM>()[t]; P.f64[F_VIR_DIS][g] = sh.template stf<Sh::SF_VIR_DIS>()[t];
+            if constexpr (!Sh::HOME) P.f64[F_VIR_DIS][g] = sh.template stf<Sh::SF_VIR_DIS>()[t];
+            if constexpr (Sh::HOME) {
+                P.f64[F_VIR_DIS][g] = sh.virdis[t];
+                P.f64[F_JERK_SUM][g] = sh.h_jerk_sum[t]; P.f64[F_CLOSER_P][g] = sh.h_closer[t];
+                const int sv = sh.h_sv[t];
+                P.i32[I_ID][g] = sh.h_id[t]; P.i32[I_SEQ][g] = sv >> 8; P.i32[I_VNUM][g] = sv & 0xFF; P.i32[I_COUNT][g] = sh.h_count[t];
+            } else {
+            P.f64[F_JERK_SUM][g] = sh.template stf<Sh::SF_JERK_SUM>()[t];
             P.f64[F_CLOSER_P][g] = sh.template stf<Sh::SF_CLOSER_P>()[t];
             P.i32[I_ID][g] = sh.template sti<I_ID>()[t]; P.i32[I_SEQ][g] = sh.template sti<I_SEQ>()[t];
-            P.i32[I_VNUM][g] = sh.template sti<I_VNUM>()[t]; P.i32[I_STEP][g] = sh.template sti<I_STEP>()[t];
-            P.i32[I_COUNT][g] = sh.template sti<I_COUNT>()[t]; P.i32[I_META][g] = sh.template sti<I_META>()[t];
+            P.i32[I_VNUM][g] = sh.template sti<I_VNUM>()[t]; P.i32[I_COUNT][g] = sh.template sti<I_COUNT>()[t];
+            }
+            P.i32[I_STEP][g] = sh.template sti<I_STEP>()[t]; P.i32[I_META][g] = sh.template sti<I_META>()[t];
             P.i32[I_HDR][g] = sh.template sti<I_HDR>()[t];
         } else { P.i32[I_META][g] = 0; P.i32[I_ID][g] = -1; }                     // stale slots never look alive
         int *dst = (int *)&P.headers[env];

@@ -44,6 +44,7 @@ template <int CAP> struct SharedGeo {
     // back to the membership scan, with identical results.
     static constexpr int PE = 4 * CAP;
     static constexpr bool DIRECT = false;   // (walk_window: sorted lists are index arrays into the entries)
+    static constexpr bool HOME = false;     // (no LDS homes for the carried fields: Shared<128, false, true> only)
     static constexpr bool HAS_LJ = false;   // (no room for the lane << 16 | j words at 10 workgroups per CU)
     static constexpr bool DENSE = false;    // every phase per slot (the 12-lane kernels run the controlled-vehicle phases on a dense mapping)
     static constexpr bool PIN_READS = false;  // (walk_window's pinned reads: no gain here, measured)

@@ -50,14 +50,21 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
 // k_rollout: the resident multi-tick form, phase by phase exactly as the kernel orders them
 // k_base: first tick of this launch / queue item within the call's output blocks (0 for a chunked launch, whose Params are
 // shifted to its first block already; the item's first tick for the sequentially emulated work queue)
-template <int CAP> static void emu_rollout(const Const &c, const Params &P, const RolloutArgs &R, int k_base = 0)
+// ShT: Shared<CAP> (the default block), or the HOME block of k_rollout<128, 5, ..> (carried fields in LDS homes, entry pool of
+// 3 CAP entries worked in passes; PVE_EMU_HOME=1) -- PVE_EMU_HOME=2 takes a still smaller pool so that ordinary traffic runs
+// through the multi-pass form
+static int g_emu_max_passes = 0, g_emu_max_entries = 0; // (diagnostics of the tests: the most passes / list entries a tick has taken)
+extern "C" int pve_emu_max_passes(void) { const int v = g_emu_max_passes; g_emu_max_passes = 0; return v; }
+extern "C" int pve_emu_max_entries(void) { const int v = g_emu_max_entries; g_emu_max_entries = 0; return v; }
+template <int CAP, class ShT = Shared<CAP>> static void emu_rollout(const Const &c, const Params &P, const RolloutArgs &R, int k_base = 0)
 {
-    typedef Tick<CAP> T;
+    typedef Tick<CAP, ShT> T;
     std::vector<Regs> regs(CAP);
     std::vector<FinCarry> fcs(CAP);
-    Shared<CAP> *shp = new Shared<CAP>();
+    std::vector<HomeRegs> hrs(CAP);
+    ShT *shp = new ShT();
     for (int env = 0; env < P.n_envs; env++) {
-        Shared<CAP> &sh = *shp;
+        ShT &sh = *shp;
         memset(&sh, 0, sizeof(sh));
         int pool_idx = R.pool_tick0;
         const bool idt = R.source == 3;                      // PVE_SRC_TABLE: actions by (tick, vehicle id)
@@ -65,7 +72,14 @@ template <int CAP> static void emu_rollout(const Const &c, const Params &P, cons
         std::vector<double> sp_act(CAP, 0.0);
         for (int t = 0; t < CAP; t++) T::ph_load(c, P, env, t, sh, regs[t]);
         if (idt) for (int t = 0; t < CAP; t++) regs[t].act = regs[t].alive ? tab(pool_idx, regs[t].id) : 0.0;
+        for (int t = 0; t < CAP; t++) T::ph_home_store(t, sh, regs[t]);
+        if (ShT::HOME)                                   // (the kernel's registers hold nothing of these from here on: poison them)
+            for (int t = 0; t < CAP; t++) {
+                Regs &q = regs[t];
+                q.p = q.v = q.a = q.jerk_sum = q.vir_dis = q.closer_p = q.act = NAN; q.id = q.seq = q.vnum = q.count = -12345;
+            }
         for (int k = 0; k < R.n_ticks; k++) {
+            const bool last_tick = k + 1 == R.n_ticks;
             for (int w = 0; w < CAP / 64; w++)      // the emulator's vote() ORs bits: start every tick from empty masks
                 sh.m_alive[w] = sh.m_ctl[w] = sh.m_del[w] = sh.m_fin[w] = sh.m_ctlnow[w] = sh.m_coll[w] = sh.m_lead[w] = sh.m_spawn[w] = 0;
             sh.emu_scan = 0;
@@ -73,16 +87,35 @@ template <int CAP> static void emu_rollout(const Const &c, const Params &P, cons
             for (int t = 0; t < CAP; t++) T::ph_step1(c, P, env, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_step2(c, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_lists_a(c, t, sh);
-            for (int t = 0; t < CAP; t++) T::ph_step3(c, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_step3(c, t, sh, regs[t], last_tick);
             for (int t = 0; t < CAP; t++) T::ph_step3_publish(t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_lists_b(t, sh);
+            if (ShT::HOME) {                         // (k_rollout<128, 5, ..>: BUILD .. WALK in passes over groups of lists)
+                for (int t = 0; t < CAP; t++) T::ph_build_prep(c, t, sh, regs[t]);
+                for (int t = 0; t < CAP; t++) T::ph_scan_init(regs[t]);
+                int pass = 0;
+                for (int d0 = 0; d0 < NL; pass++) {
+                    const int d1 = T::group_end(sh, d0);
+                    for (int t = 0; t < CAP; t++) T::ph_build_fill(c, t, sh, regs[t], d0, d1);
+                    for (int t = 0; t < CAP; t++) T::ph_rank(t, sh, pass, d0, d1);
+                    for (int t = 0; t < CAP; t++) T::ph_scan_lists(c, t, sh, regs[t], d0, d1);
+                    d0 = d1;
+                }
+                if (pass > g_emu_max_passes) g_emu_max_passes = pass;
+                if (sh.loff[NL] > g_emu_max_entries) g_emu_max_entries = sh.loff[NL];
+            } else {
             for (int t = 0; t < CAP; t++) T::ph_build(c, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_rank(t, sh);
             for (int t = 0; t < CAP; t++) T::ph_scan(c, t, sh, regs[t]);
+            }
             for (int t = 0; t < CAP; t++) T::ph_reward(c, t, sh, regs[t]);
             int nx = -1;
             if (k + 1 < R.n_ticks) { pool_idx = (pool_idx + 1 == R.n_pool) ? 0 : pool_idx + 1; nx = pool_idx; }
-            if (idt) for (int t = 0; t < CAP; t++) regs[t].act_nx = (nx >= 0 && regs[t].alive) ? tab(nx, regs[t].id) : 0.0;
+            if (idt) for (int t = 0; t < CAP; t++) {
+                int my_id = regs[t].id;
+                if constexpr (ShT::HOME) my_id = sh.h_id[t];
+                regs[t].act_nx = (nx >= 0 && regs[t].alive) ? tab(nx, my_id) : 0.0;
+            }
             else for (int t = 0; t < CAP; t++) T::ph_prefetch_action(P, R, env, t, nx, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_effects(c, t, sh, regs[t]);
             for (int t = 0; t < CAP; t++) T::ph_prefetch_arrival(P, env, t, sh, regs[t], NL);
@@ -93,20 +126,22 @@ template <int CAP> static void emu_rollout(const Const &c, const Params &P, cons
                 for (int t = 0; t < NL; t++)
                     sp_act[t] = (((sp >> t) & 1) && nx >= 0) ? tab(nx, sh.hd.id_seq + __builtin_popcount(sp & ((1u << t) - 1u))) : 0.0;
             }
-            for (int t = 0; t < CAP; t++) T::ph_lock(c, t, sh, regs[t]);
-            for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_lock(c, t, sh, regs[t], last_tick);
+            for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t], last_tick);
             for (int t = 0; t < CAP; t++) T::ph_keep_prefix(t, sh);
-            if (!idt) for (int t = 0; t < CAP; t++) T::ph_park_action(t, sh, regs[t]);
+            if (!idt && !(ShT::HOME && last_tick)) for (int t = 0; t < CAP; t++) T::ph_park_action(t, sh, regs[t]);
             const Outputs O = T::tick_outputs(P, R, k_base + k);
             for (int t = 0; t < CAP; t++)
                 T::template ph_final<true>(c, P, O, env, t, sh, regs[t], fcs[t], k + 1 == R.n_ticks || O.state_pre != nullptr);
             if (idt) for (int t = 0; t < CAP; t++) if (fcs[t].new_slot >= 0) sh.act_next[fcs[t].new_slot] = regs[t].act_nx;
+            for (int t = 0; t < CAP; t++) T::ph_home_take(t, sh, regs[t], fcs[t], hrs[t]);
             if (fcs[0].still) {                       // (uniform) nobody moves: the registers carry over
                 for (int t = 0; t < CAP; t++) T::ph_stage_header(t, sh, fcs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_carry_over(t, sh, regs[t], fcs[t]);
             } else {
                 if (O.state_pre) for (int t = 0; t < CAP; t++) T::ph_state(P, O, env, t, sh, regs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_stage(c, t, sh, regs[t], fcs[t]);
+                for (int t = 0; t < CAP; t++) T::ph_home_put(t, sh, fcs[t], hrs[t]);
                 if (idt) for (int t = 0; t < NL; t++) if (fcs[t].sp_slot >= 0) sh.act_next[fcs[t].sp_slot] = sp_act[t];
                 if (k + 1 < R.n_ticks) for (int t = 0; t < CAP; t++) T::ph_reload(t, sh, regs[t]);
             }
@@ -294,8 +329,15 @@ struct Backend {
     static int launch_rollout(const Const &c, const Params &P_in, const RolloutArgs &R, int cap, void *, std::string &err)
     {
         if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2) return 1;
+        // PVE_EMU_HOME (tests): the HOME block of k_rollout<128, 5, ..> for every 128-slot roll-out without training outputs
+        // (1 = the kernel's pool of 3 CAP entries, 2 = a pool of 296 entries: ordinary traffic takes several passes)
+        const char *hm = getenv("PVE_EMU_HOME");
+        const int home = (hm && cap == 128 && !P_in.out.obs_pre && !P_in.out.state_pre) ? atoi(hm) : 0;
         const int rc = run_launch(c, P_in, R, cap, [&](const Const &cc, const Params &P, const RolloutArgs &Rk, int kb) {
-            if (cap == 64) emu_rollout<64>(cc, P, Rk, kb); else emu_rollout<128>(cc, P, Rk, kb); });
+            if (cap == 64) emu_rollout<64>(cc, P, Rk, kb);
+            else if (home == 1) emu_rollout<128, Shared<128, false, true>>(cc, P, Rk, kb);
+            else if (home >= 2) emu_rollout<128, Shared<128, false, true, 296>>(cc, P, Rk, kb);
+            else emu_rollout<128>(cc, P, Rk, kb); });
         if (rc < 0) err = "emulated work queue: inconsistent item schedule";
         return rc;
     }

@@ -485,7 +485,7 @@ def check_pipelined_equals_single(backend, n_envs=7, n_sub=3, capacity=128, tick
 
 
 def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1, 7, 40, 3, 60), rate=1100.0,
-                    prefill=0, trajectory_chunk=12, arrivals=None, persistent=False):
+                    prefill=0, trajectory_chunk=12, arrivals=None, persistent=False, cfg=None, act_lo=-3.0, act_hi=3.0):
     """pve_step_many (n ticks per call, action source on the device) == n single-tick calls, bit for bit: persistent
     state, headers, observation rows, last-tick outputs and -- trajectory mode -- the outputs of every tick.
     persistent=True: the calls that are split into several chunks run as ONE launch whose workgroups pull (intersection,
@@ -496,10 +496,11 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
     total = prefill + sum(chunks) + trajectory_chunk
     arr = arrivals if arrivals is not None else synthetic_arrivals(n_envs, rate=rate, horizon_s=total * 0.1 + 30, seed=seed)
     outs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out", "lanej")
-    one = make_batch(arr, n_envs, capacity, backend, outputs=outs)
-    many = make_batch(arr, n_envs, capacity, backend, outputs=outs)
+    cfg = cfg or {}                                         # constructor arguments (vm, dis_ctl, ...: ref :21-23)
+    one = make_batch(arr, n_envs, capacity, backend, outputs=outs, **cfg)
+    many = make_batch(arr, n_envs, capacity, backend, outputs=outs, **cfg)
     one.reset(); many.reset()
-    pool = torch.as_tensor(rng.uniform(-3, 3, size=(n_pool, n_envs, capacity))).to(one.device)
+    pool = torch.as_tensor(rng.uniform(act_lo, act_hi, size=(n_pool, n_envs, capacity))).to(one.device)
     if source == "pool":
         many.set_action_pool(pool)
     if source == "actor":
@@ -507,7 +508,7 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
         w = flat_weights(load_weights())
         one.set_actor(w); many.set_actor(w)
     if source == "table":                                   # actions by (tick, vehicle id); few columns: ids beyond them share the last
-        table = torch.as_tensor(rng.uniform(-3, 3, size=(23, 150)))
+        table = torch.as_tensor(rng.uniform(act_lo, act_hi, size=(23, 150)))
         one.set_action_table(table); many.set_action_table(table)
 
     def single():
@@ -559,10 +560,11 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
     for k in m1:
         assert m1[k] == m2[k], (k, m1[k], m2[k])
     assert m1["ctl_steps"] > 0
+    stats = dict(m1, max_alive=int(max(one.read_env(e).n_alive for e in range(n_envs))))
     assert many.step_many(0, source=source) is not None          # zero ticks: a no-op
     batches_equal(one, many, "after a zero-tick call")
     # misuse
-    bad = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "state_pre", "flags"))
+    bad = make_batch(arr, n_envs, capacity, backend, outputs=("obs_post", "obs_pre", "state_pre", "flags"), **cfg)
     bad.reset()
     for fn in (lambda: bad.step_many(2, source="zero"), lambda: one.step_many(2, source="pool"),
                lambda: many.step_many(2, source="nope")):
@@ -571,6 +573,7 @@ def check_step_many(backend, source, n_envs=5, capacity=128, seed=71, chunks=(1,
             raise AssertionError("misuse accepted")
         except PveError:
             pass
+    return stats
 
 
 def check_step_many_geo(backend, lane_num, n_envs=5, capacity=128, seed=75, chunks=(1, 7, 40, 3, 60), rate=None,

@@ -1,0 +1,72 @@
+"""CPU parity of the HOME block of k_rollout<128, 5, ..> (csrc/pve_tick_core.h: Shared<128, false, true>): the 96-register /
+10-workgroups-per-CU build of the resident kernel keeps the carried per-slot fields (jerk_sum, closer_p, id, seq | vnum,
+count, vir_dis, p / v / a, the next action) in LDS instead of registers and works the virtual-lane lists in passes over an
+entry pool of 3 CAP entries.  The emulator (tests/emu) runs the same phase bodies with that block when PVE_EMU_HOME is set
+(1 = the kernel's pool, 2 = a pool of 296 entries so that ordinary traffic takes several passes) -- every roll-out must still
+equal single ticks of k_tick bit for bit (ref traffic_interaction_scene.py:1501-1539, :222-376, :435-444)."""
+import ctypes as C
+
+import pytest
+
+from tests import scenarios
+from tests.hip_adapter import emulator_lib
+
+BACKEND = "emu"
+
+
+def _passes():
+    lib = emulator_lib()
+    lib.pve_emu_max_passes.restype = C.c_int
+    return int(lib.pve_emu_max_passes())
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("source", ["table", "pool", "zero"])
+def test_home_block_step_many_equals_single_ticks(monkeypatch, mode, source):
+    monkeypatch.setenv("PVE_EMU_HOME", str(mode))
+    _passes()
+    # (mode 2: > 296 list entries need ~85 controlled vehicles: slow traffic that does not collide fills the intersection)
+    kw = dict(prefill=200, rate=1600.0, cfg=dict(vm=2.0, collision_thr=0.01)) if mode == 2 else {}
+    scenarios.check_step_many(BACKEND, source, n_envs=3, chunks=(1, 7, 40, 3, 60), trajectory_chunk=12, seed=171 + mode, **kw)
+    p = _passes()
+    assert p >= 1, "the HOME block did not run"
+    if mode == 2:
+        assert p >= 2, "a pool of 296 entries must take several passes with a full intersection"
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("source", ["table", "pool"])
+def test_home_block_through_the_work_queue(monkeypatch, mode, source):
+    """the persistent form's item schedule (items of different lengths: the `last tick` of every item stages the jerks)"""
+    monkeypatch.setenv("PVE_EMU_HOME", str(mode))
+    _passes()
+    kw = dict(prefill=200, rate=1600.0, cfg=dict(vm=2.0, collision_thr=0.01)) if mode == 2 else {}
+    scenarios.check_step_many(BACKEND, source, n_envs=4, chunks=(20, 9, 33, 50), trajectory_chunk=14, seed=181, persistent=True, **kw)
+    assert _passes() >= mode
+
+
+def test_home_block_full_intersection_takes_several_passes_of_the_kernel_pool(monkeypatch):
+    """3000 veh/h/lane, vm = 3 m/s, full braking and (almost) no collisions: the 128 slots fill up with controlled vehicles
+    and the lists need more than 3 CAP entries -- the multi-pass form with the pool size the HIP kernel has (and deferred
+    spawns / a full intersection on the table source's late spawn-action gather)."""
+    monkeypatch.setenv("PVE_EMU_HOME", "1")
+    _passes()
+    st = scenarios.check_step_many(BACKEND, "table", n_envs=2, chunks=(250, 40, 7, 60), trajectory_chunk=10, seed=191, rate=3000.0,
+                                   cfg=dict(vm=3.0, collision_thr=0.01), act_lo=-3.0, act_hi=-2.0)
+    assert st["max_alive"] >= 120 and st["overflow"] > 0, st
+    assert _passes() >= 2, "a full intersection must overflow the 3 CAP entry pool"
+
+
+def test_home_block_symmetric_lanes_equal_distances(monkeypatch):
+    """runs of equal virtual distances (the claim / fix-up of RANK) inside passes"""
+    for mode in ("1", "2"):
+        monkeypatch.setenv("PVE_EMU_HOME", mode)
+        arr = scenarios.symmetric_arrivals(2, gap_s=3.4, rows=40, lane_groups=[[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]])
+        scenarios.check_step_many(BACKEND, "zero", n_envs=2, chunks=(1, 30, 90), trajectory_chunk=10, arrivals=arr)
+
+
+def test_home_block_driver_shape_vs_oracle(monkeypatch):
+    """the bench's call shape (prefill + short persistent calls) against the sequential oracle, every tick"""
+    monkeypatch.setenv("PVE_EMU_HOME", "1")
+    m, _ = scenarios.check_driver_shape_vs_oracle(BACKEND, n_envs=6, n_sub=1, n_sample=6, calls=(30, 30, 5, 20))
+    assert m["ctl_steps"] > 0
