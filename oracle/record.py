@@ -146,9 +146,25 @@ def make_policy_sin(amp):
     return pol
 
 
+def make_policy_rand(amp):
+    """a = float32(A * u), u in [-1, 1) from an integer hash of (vehicle id, tick): a reproducible "random" tape that needs no
+    generator state (the same value wherever it is evaluated), for controlled vehicles, 0 otherwise."""
+    def pol(tick, veh_id, control, obs0=None):
+        x = (np.asarray(veh_id, np.uint64) * np.uint64(2654435761) + np.uint64(int(tick)) * np.uint64(40503) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(15); x = (x * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(13); x = (x * np.uint64(3266489917)) & np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(16)
+        u = x.astype(np.float64) / 2147483648.0 - 1.0
+        a = (amp * u).astype(np.float32).astype(np.float64)
+        return np.where(np.asarray(control) != 0, a, 0.0)
+    return pol
+
+
 def get_policy(name):
     if name == "zero":
         return policy_zero
     if name.startswith("sin"):
         return make_policy_sin(float(name[3:]))
+    if name.startswith("rand"):
+        return make_policy_rand(float(name[4:]))
     raise KeyError(name)

@@ -35,9 +35,31 @@ CASES = [
     ("s400_sin2", "400", "sin2", 1500, {}),
     ("s1000_sin3", "1000", "sin3", 600, {}),
     ("s1000_sin1_vm6", "1000", "sin1", 600, {"vm": 6}),
+    # every constructor argument the C ABI exposes (pve_config; ref :21-23) away from its default, together, under a
+    # pseudo-random +-3 tape
+    # the pretrained actor (the reference's own graph) driving the LIVE reference env, main.py:397-441
+    ("s1000_actor", "1000", "actor_tape", 1000, {}),
+    ("s1000_rand_kw", "1000", "rand3", 300, {"dis_ctl": 120, "lane_cw": 3, "collision_thr": 3, "vM": 15, "v0": 9, "am": -2.5,
+                                             "aM": 2.5, "deltaT": 0.2, "vm": 6}),
 ]
 DENSE_FIELDS = ("ids", "nbr", "reward", "obs0", "coll_pv", "deleted", "jerks", "veh_i", "veh_f",
                 "heads", "veh_num", "veh_rec")
+
+
+def graph_actor_policy():
+    """SURVEY 8(c) policy (iii): the PRETRAINED actor -- the reference's own shipped graph (model_data/baseline/66.cptk.meta,
+    decoded and evaluated op by op in float32 by tests/golden/gen_actor_golden.py:GraphActor) -- fed with veh["state"][0] of
+    every controlled vehicle as main.py:398-406 does.  The ACTIONS are recorded as a tape; parity tests replay the tape."""
+    from tests.golden.gen_actor_golden import GraphActor
+    actor = GraphActor()
+
+    def pol(tick, veh_id, control, obs0=None):
+        a = np.zeros(len(veh_id), np.float64)
+        c = np.asarray(control) != 0
+        if c.any():
+            a[c] = actor.run(np.asarray(obs0, np.float64)[c].astype(np.float32), np.float32).astype(np.float64).reshape(-1)
+        return a
+    return pol
 
 
 def dense_tick_set(ticks):
@@ -49,8 +71,10 @@ def dense_tick_set(ticks):
 
 def gen_case(name, stream, pol, ticks, kw):
     arr = rh.load_stream(stream)
-    policy = get_policy(pol)
+    policy = graph_actor_policy() if pol == "actor_tape" else get_policy(pol)
     ref = rh.RefRunner(arr, policy, want_state=True, **kw)
+    tape_vals, tape_off = [], [0]                  # "actor_tape": the actions fed on every tick, alive vehicles in (lane, j) order
+    agg = dict(alive_steps=0, ctl_steps=0, collided=0, locks=0, sum_reward=0.0, n_reward=0, sum_jerks=0.0)
     dense = dense_tick_set(ticks)
     state_ticks = [t for t in (3, ticks // 2, ticks - 1) if t in dense or True][:3]
     out = {}
@@ -59,6 +83,11 @@ def gen_case(name, stream, pol, ticks, kw):
     for t in range(ticks):
         rec = ref.tick()
         dig_i[t], dig_f[t] = digest(rec)
+        tape_vals.append(np.asarray(ref.tape, np.float64)); tape_off.append(tape_off[-1] + len(ref.tape))
+        agg["alive_steps"] += len(rec["veh_i"]); agg["ctl_steps"] += len(rec["ids"])
+        agg["collided"] += int((rec["coll_pv"] > 0).sum()); agg["locks"] += int(rec["lock"])     # main.py:410-412, :413-415
+        agg["sum_reward"] += float(np.sum(rec["reward"])); agg["n_reward"] += len(rec["reward"])
+        agg["sum_jerks"] += float(np.sum(rec["jerks"]))
         if t in dense or t in state_ticks:
             for f in DENSE_FIELDS:
                 out["t%d_%s" % (t, f)] = rec[f]
@@ -75,6 +104,17 @@ def gen_case(name, stream, pol, ticks, kw):
     out["dense_ticks"] = np.array(sorted(set(dense) | set(state_ticks)), np.int32)
     out["state_ticks"] = np.array(state_ticks, np.int32)
     out["guard_hits"] = np.array(ref.guard_hits, np.int32)
+    if pol == "actor_tape":
+        tv = np.concatenate(tape_vals)
+        assert np.array_equal(tv.astype(np.float32).astype(np.float64), tv), "actor outputs are float32 values"
+        out["tape_vals"] = tv.astype(np.float32)
+        out["tape_off"] = np.asarray(tape_off, np.int64)
+        # the aggregates main.py:test() prints (main.py:523-526), from the LIVE reference under its own policy
+        agg.update(id_seq=int(rec["id_seq"]), passed=int(rec["passed"]), passed_step_total=int(rec["passed_step_total"]),
+                   pT_m=float(rec["passed_step_total"] / (rec["passed"] + 1e-4) * 0.1),
+                   reward_mean=agg["sum_reward"] / max(1, agg["n_reward"]), jerk_per_veh=agg["sum_jerks"] / max(1, int(rec["passed"])))
+        out["aggregates"] = np.array(json.dumps(agg))
+        print("   aggregates:", agg)
     import scipy
     out["meta"] = np.array(json.dumps(dict(name=name, stream=stream, policy=pol, ticks=ticks, ctor=kw,
                                            numpy=np.__version__, scipy=scipy.__version__,

@@ -171,7 +171,12 @@ class RefRunner(ObjRunner):
 
     def __init__(self, arrive_time, policy, want_state=False, **ctor_kw):
         tis = import_reference()
-        env = tis.TrafficInteraction(arrive_time, 150, default_args(), show_col=False,
+        # the constructor's positional dis_ctl (ref :21; callers pass 150, main.py:394) and args.collision_thr (ref :32)
+        ctor_kw = dict(ctor_kw)
+        dis_ctl = ctor_kw.pop("dis_ctl", 150)
+        args = default_args()
+        args.collision_thr = ctor_kw.pop("collision_thr", args.collision_thr)
+        env = tis.TrafficInteraction(arrive_time, dis_ctl, args, show_col=False,
                                      virtual_l=True, lane_num=12, **ctor_kw)
         ObjRunner.__init__(self, env, policy, want_state, guard=True)
         orig = env.virtual_lane_search_closer

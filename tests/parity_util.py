@@ -8,7 +8,7 @@ from oracle.record import (DIGEST_F_COLS, DIGEST_I_COLS, compare_records, digest
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASE_NAMES = ["s1000_zero", "s1000_sin1", "s200_sin1", "s1200_sin1", "s1200_zero", "s400_sin2",
-              "s1000_sin3", "s1000_sin1_vm6"]
+              "s1000_sin3", "s1000_sin1_vm6", "s1000_rand_kw", "s1000_actor"]
 # 4- / 8-lane geometries: synthetic streams + intention draws stored in the fixture
 GEO_CASE_NAMES = ["geo_g4_zero", "geo_g4_sin2", "geo_g4_sin3", "geo_g8_zero", "geo_g8_sin2", "geo_g8_sin3"]
 DENSE_FIELDS = ("ids", "nbr", "reward", "obs0", "coll_pv", "deleted", "jerks", "veh_i", "veh_f",
@@ -25,11 +25,24 @@ class GoldenCase:
         self.dig_f = self.z["dig_f"]
         self.ticks = int(self.meta["ticks"])
         self.ctor = dict(self.meta["ctor"])
-        self.policy = get_policy(self.meta["policy"])
+        if self.meta["policy"] == "actor_tape":
+            # the recorded actions of the pretrained actor on the live reference env (gen_golden.py); the tape,
+            # not the network, is what is replayed
+            self.tape_vals = self.z["tape_vals"].astype(np.float64)
+            self.tape_off = self.z["tape_off"]
+            self.aggregates = json.loads(str(self.z["aggregates"]))
+            self.policy = self._tape_policy
+        else:
+            self.policy = get_policy(self.meta["policy"])
         self.dense_ticks = set(int(t) for t in self.z["dense_ticks"])
         self.state_ticks = set(int(t) for t in self.z["state_ticks"])
         self.lane_num = int(self.meta.get("lane_num", 12))
         self.choice = np.ascontiguousarray(self.z["choice"], np.int32) if "choice" in self.z.files else None
+
+    def _tape_policy(self, tick, veh_id, control, obs0=None):
+        a = self.tape_vals[self.tape_off[tick]:self.tape_off[tick + 1]]
+        assert len(a) == len(veh_id), "%s tick %d: the tape holds %d actions for %d alive vehicles" % (self.name, tick, len(a), len(veh_id))
+        return a
 
     def dense_record(self, t):
         z = self.z

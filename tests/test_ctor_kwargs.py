@@ -1,0 +1,104 @@
+"""Parity under NON-DEFAULT constructor arguments -- every field of `pve_config` the C ABI exposes (include/pve_env.h), i.e.
+`TrafficInteraction(arrive_time, dis_ctl, args, deltaT, vm, vM, am, aM, v0, ..., lane_cw)` + `args.collision_thr`
+(ref traffic_interaction_scene.py:21-23, :32; callers only ever pass vm = 6: main.py:230).  The host derives the geometry
+(lane_info, exit_p, the virtual-distance table) from lane_cw / dis_ctl and the exact constant divisions of the brake test from
+|am|, so each argument is moved on its own and all of them together, under a pseudo-random +-3 tape that provokes collisions
+and dead-locks:
+  * live reference <-> C oracle, every tick, every field, 1e-12            (-m reference: build container only)
+  * C oracle <-> the kernels' phase bodies on the CPU emulator, 1e-9      (CPU)
+  * C oracle <-> the HIP kernels through the C ABI, 1e-9                  (-m gpu); + pve_step_many == single ticks
+  * the committed fixture tests/golden/s1000_rand_kw.npz (all arguments together, generated from the live reference by
+    tests/golden/gen_golden.py) is replayed by the CASE_NAMES-parametrised golden tests of the oracle / emulator / GPU suites."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleEnv
+from oracle.record import compare_records, get_policy
+from tests import scenarios
+from tests.parity_util import GOLDEN_DIR
+
+ALL_KW = {"dis_ctl": 120, "lane_cw": 3, "collision_thr": 3, "vM": 15, "v0": 9, "am": -2.5, "aM": 2.5, "deltaT": 0.2, "vm": 6}
+VARIANTS = [
+    ("dis_ctl", {"dis_ctl": 120}),
+    ("lane_cw", {"lane_cw": 3}),
+    ("collision_thr", {"collision_thr": 3}),
+    ("speeds", {"vM": 15, "v0": 9}),
+    ("accel", {"am": -2.5, "aM": 2.5}),
+    ("deltaT", {"deltaT": 0.2}),
+    ("all", ALL_KW),
+]
+TICKS = 300
+
+
+def stream_1000():
+    """the reference's own 1000 veh/h stream (data file committed under tests/golden/streams, read by the product's reader)"""
+    from pve_mcc_amd.arrivals import load_arrival_mat
+    return np.ascontiguousarray(load_arrival_mat(os.path.join(GOLDEN_DIR, "streams", "arvTimeNewVeh_new_1000_12.mat")), np.float64)
+
+
+class KwCase:
+    """what scenarios.check_split_vs_oracle needs of a golden case, without a fixture"""
+
+    def __init__(self, name, kw, ticks=TICKS):
+        self.name = "kw_" + name
+        self.arrive = stream_1000()
+        self.ctor = dict(kw)
+        self.policy = get_policy("rand3")
+        self.ticks = ticks
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("name,kw", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_oracle_vs_live_reference_under_ctor_kwargs(name, kw):
+    from tests.golden import ref_harness as rh
+    arr = rh.load_stream("1000")
+    policy = get_policy("rand3")
+    ref = rh.RefRunner(arr, policy, want_state=True, **kw)
+    orc = OracleEnv(arr, **kw)
+    coll = locks = 0
+    for t in range(TICKS):
+        vid, ctl, obs0 = ref.alive_view()
+        vid2, ctl2, obs02 = orc.alive_view()
+        assert np.array_equal(vid, vid2) and np.array_equal(ctl, ctl2)
+        assert np.allclose(obs0, obs02, rtol=0, atol=1e-12)
+        acts = policy(t, vid, ctl, obs0)
+        ra = ref.tick(acts)
+        rb = orc.tick(acts, want_state=True)
+        compare_records(ra, rb, tol=1e-12, label="kw_" + name)
+        coll += rb["collisions"]; locks += rb["lock"]
+    assert orc.ref_would_raise == 0
+    assert coll > 0 and locks > 0, "the tape must provoke collisions and dead-locks (%d, %d)" % (coll, locks)
+
+
+@pytest.mark.parametrize("name,kw", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_emulated_kernels_vs_oracle_under_ctor_kwargs(name, kw):
+    scenarios.check_split_vs_oracle(KwCase(name, kw), "emu", ticks=TICKS)
+
+
+def test_emulated_step_many_under_ctor_kwargs():
+    """the resident loop (and, PVE_EMU_HOME, the HOME block) with every argument moved: == single ticks"""
+    scenarios.check_step_many("emu", "table", n_envs=3, chunks=(1, 7, 40, 3, 60), trajectory_chunk=12, seed=201, cfg=ALL_KW)
+    os.environ["PVE_EMU_HOME"] = "1"
+    try:
+        scenarios.check_step_many("emu", "pool", n_envs=3, chunks=(9, 40, 33), trajectory_chunk=12, seed=202, cfg=ALL_KW, persistent=True)
+    finally:
+        del os.environ["PVE_EMU_HOME"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_gpu_kernels_vs_oracle_under_ctor_kwargs(name, kw):
+    scenarios.check_split_vs_oracle(KwCase(name, kw), "hip", ticks=TICKS)
+    if name in ("accel", "all"):                       # the capacity-64 kernels too (their own instantiation of every phase)
+        scenarios.check_split_vs_oracle(KwCase(name, kw, ticks=150), "hip", ticks=150, capacity=64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source,persistent", [("table", True), ("pool", True), ("zero", False), ("table", False)])
+def test_gpu_step_many_under_ctor_kwargs(source, persistent):
+    """k_rollout (plain / queue form; the HOME build for the 128-slot queue form) with every argument moved == single ticks of
+    k_tick, which the test above holds to the oracle"""
+    scenarios.check_step_many("hip", source, n_envs=5, chunks=(1, 7, 40, 3, 60), trajectory_chunk=12, seed=203, cfg=ALL_KW,
+                              persistent=persistent)
