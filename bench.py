@@ -199,8 +199,21 @@ def binding_profile(mode, ticks_per_launch, cap, other, pkey=None):
     return t, os.path.relpath(f, ROOT)
 
 
+def sample_envs(n_envs, n_sample, seed):
+    """The envs a verification leg replays: drawn afresh for every run from `seed` (printed in the line; --verify-seed pins it),
+    always with the rank's first and last env."""
+    rng = np.random.default_rng(seed)
+    n = min(n_sample, n_envs)
+    pick = set([0, n_envs - 1][:n])
+    for e in rng.permutation(n_envs):
+        if len(pick) >= n:
+            break
+        pick.add(int(e))
+    return sorted(pick)
+
+
 def verify_against_oracle(locate, last_outputs, arr, pool_np, total_ticks, lane_num, choice, n_sample=VERIFY_ENVS, table_np=None,
-                          skip_overflowed=False):
+                          skip_overflowed=False, seed=0):
     """Outside the timed region: `n_sample` of the envs this rank just timed are replayed from reset by the CPU oracle
     (the checker; oracle/README.md) on the same arrival stream and the same action pool for the same number of ticks;
     the final persistent state (ints exact, floats 1e-9) and the last tick's outputs (controlled set, rewards, collision /
@@ -208,23 +221,30 @@ def verify_against_oracle(locate, last_outputs, arr, pool_np, total_ticks, lane_
     from oracle.oracle import OracleEnv
     from oracle.record import close
     n_envs = arr.shape[0]
-    sample = sorted(set(np.linspace(0, n_envs - 1, n_sample).astype(int).tolist()))
-    res = dict(verified=True, envs=sample, ticks_replayed=int(total_ticks), tol=VERIFY_TOL, checker="oracle (CPU restatement)",
+    sample = sample_envs(n_envs, n_sample, seed)
+    if skip_overflowed:
+        # a leg that runs ON a rate at which some intersections fill up: compare n_sample envs that never deferred a spawn --
+        # candidates in the seed's order until enough are found (at most 8 x n_sample looked at)
+        sample = [int(e) for e in np.random.default_rng(seed).permutation(n_envs)[:8 * n_sample]]
+    res = dict(verified=True, envs=sample, seed=int(seed), ticks_replayed=int(total_ticks), tol=VERIFY_TOL, checker="oracle (CPU restatement)",
                compared="final state of every vehicle (13 int fields exact, p v a jerk jerk_sum at tol) + last tick: "
                         "controlled set, rewards, collision and dead-lock counters")
     if total_ticks < 1:
         res.update(verified=None, reason="no tick executed")
         return res
-    skipped = []
+    skipped, compared = [], []
     try:
         for e in sample:
             if skip_overflowed:
                 # a full intersection defers its spawns (the build's one documented deviation; the reference has no capacity):
                 # such an env has left the oracle's trajectory and is reported, not compared
+                if len(compared) >= n_sample:
+                    break
                 b0, le0 = locate(e)
                 if b0.read_env(le0).overflow > 0:
                     skipped.append(e)
                     continue
+            compared.append(e)
             if lane_num == 12:
                 o = OracleEnv(arr[e])
             else:
@@ -265,9 +285,10 @@ def verify_against_oracle(locate, last_outputs, arr, pool_np, total_ticks, lane_
     except AssertionError as ex:
         res.update(verified=False, mismatch=str(ex))
     if skip_overflowed:
-        res.update(envs_compared=[e for e in sample if e not in skipped], envs_skipped_overflowed=skipped)
-        if len(skipped) == len(sample):
-            res.update(verified=None, reason="every sampled env deferred a spawn")
+        res.update(envs=compared, envs_compared=len(compared), envs_skipped_overflowed=skipped)
+        if len(compared) < n_sample and res["verified"]:
+            # (a parity statement must rest on the full sample: fewer comparable envs than asked for is "not verified", not "verified")
+            res.update(verified=None, reason="only %d of the %d envs looked at never deferred a spawn (%d wanted)" % (len(compared), len(sample), n_sample))
     return res
 
 
@@ -275,7 +296,7 @@ ACTION_TOL = 5e-4       # |a_device - a_numpy| on actions in [-3, 3]: two float3
 STATE_FIELDS = ("p", "v", "a", "jerk", "jerk_sum", "vir_dis", "closer_p", "id", "seq", "vnum", "step", "count", "meta", "hdr")
 
 
-def verify_closed_loop(torch, dev, locate, arr, total_ticks, cap, obs_dtype, weights, n_sample=2 * VERIFY_ENVS, lane_num=12, choice=None):
+def verify_closed_loop(torch, dev, locate, arr, total_ticks, cap, obs_dtype, weights, n_sample=2 * VERIFY_ENVS, lane_num=12, choice=None, seed=0):
     """Closed loop (BASELINE config 5), outside the timed region: `n_sample` of the envs this rank just timed are replayed
     from reset on the GPU as ONE small batch in the two-launch form (step_with_actor: actor kernel + tick kernel per tick,
     whose tick is the kernel the oracle certifies) for the same number of ticks.  The timed path (the actor inside the
@@ -287,8 +308,8 @@ def verify_closed_loop(torch, dev, locate, arr, total_ticks, cap, obs_dtype, wei
     import pve_mcc_amd
     from oracle.actor_np import actor_forward
     n_envs = arr.shape[0]
-    sample = sorted(set(np.linspace(0, n_envs - 1, n_sample).astype(int).tolist()))
-    res = dict(verified=True, envs=sample, ticks_replayed=int(total_ticks), action_tol=ACTION_TOL,
+    sample = sample_envs(n_envs, n_sample, seed)
+    res = dict(verified=True, envs=sample, seed=int(seed), ticks_replayed=int(total_ticks), action_tol=ACTION_TOL,
                checker="the same streams as a %d-env batch in the two-launch form (k_actor_h + k_tick per tick) on the GPU, bit for "
                        "bit; actions on the final rows vs oracle/actor_np.py" % len(sample),
                compared="every persistent field of every live slot + observation rows of the controlled vehicles (exact); "
@@ -333,7 +354,7 @@ def actor_weights():
     return {k: z[k] for k in z.files}       # the reference's pretrained actor (model_data/baseline/66.cptk)
 
 
-def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
+def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True, vseed=0):
     """A second BASELINE configuration timed OUTSIDE the headline region, on envs of its own, with the headline's protocol
     in small (300 un-timed prefill ticks, W warm-up ticks, exactly K timed ticks between synchronisations, the launch
     shape the headline would use at this K) -- so that the driver's single `bench.py` line carries driver-timed numbers
@@ -393,11 +414,11 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
     if not verify:
         ver = dict(verified=None, reason="skipped (--no-verify)")
     elif closed:
-        ver = verify_closed_loop(torch, dev, locate, arr, total, cap, obs_dtype, w)
+        ver = verify_closed_loop(torch, dev, locate, arr, total, cap, obs_dtype, w, seed=vseed)
     else:
         ver = verify_against_oracle(locate, lambda e: {n: locate(e)[0].out[n][locate(e)[1]].cpu().numpy() for n in ("flags", "reward", "env_out")},
                                     arr, None, total, 12, None, table_np=table_np, n_sample=(2 * VERIFY_ENVS if on_spec else VERIFY_ENVS),
-                                    skip_overflowed=on_spec)
+                                    skip_overflowed=on_spec, seed=vseed)
     b_nom = B_ALG_OBS_F32 if closed else B_ALG_FP64
     # ticks per launch / per queue item: the state crosses HBM once per that many ticks
     tpl = (K / float(persistent_items(K, chunk))) if pers else (chunk if chunk > 0 else K)
@@ -413,7 +434,8 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
            "ms_per_step": dt / K * 1e3, "value": float(cap) * n_envs * K / dt, "unit": "env-steps/s", "steps": K, "warmup": W,
            "prefill_ticks": prefill, "ticks_per_launch": K if (pers or chunk == 0) else chunk, "ticks_per_item": tpl,
            "sub_batches": n_sub, "launch": "persistent work queue" if pers else "one launch per chunk and sub-batch",
-           "verified": ver["verified"], "verification": ver,
+           "verified": ver["verified"], "envs_compared": ver.get("envs_compared", len(ver.get("envs", []))),
+           "envs_skipped_overflowed": len(ver.get("envs_skipped_overflowed", [])), "verification": ver,
            "overflow": m1["overflow"], "mean_alive_per_env": (m1["alive_steps"] - m0["alive_steps"]) / float(K * n_envs),
            "mean_ctl_per_env": (m1["ctl_steps"] - m0["ctl_steps"]) / float(K * n_envs),
            "hbm_frac": b_alg * cap * n_envs / (dt / K) / 1e9 / HBM_PEAK_GBS}
@@ -422,7 +444,7 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True):
     return res
 
 
-def run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=None, verify=True):
+def run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=None, verify=True, vseed=0):
     """BASELINE config 4 beside the weak-scaled headline of a multi-rank run: 64-slot intersections sharded env-parallel,
     n_envs per rank -- with the default 4096 per rank and 8 ranks that is exactly 32 768 x 64 over 8 GPUs, rank k owning the
     global envs shard_range(32768, k, 8) with arrival seeds 20250213 + 32452843 + global env index.  Same protocol as the
@@ -495,7 +517,7 @@ def run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=None, v
         sync()
         try:
             ver = verify_against_oracle(locate, lambda e: {n: locate(e)[0].out[n][locate(e)[1]].cpu().numpy() for n in ("flags", "reward", "env_out")},
-                                        arr, None, prefill + W + K, 12, None, table_np=table_np, n_sample=min(4, n_envs))
+                                        arr, None, prefill + W + K, 12, None, table_np=table_np, n_sample=min(4, n_envs), seed=vseed + rank)
         except Exception as ex:                           # noqa: BLE001 (every rank must reach the collective below)
             ver = dict(verified=False, mismatch="%s: %s" % (type(ex).__name__, ex))
     else:
@@ -518,13 +540,21 @@ def run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=None, v
     return res
 
 
-def persistent_items(K, T):
-    """Items per intersection of a persistent call of K ticks with items of at most T ticks (pve_capi.inc: the call ends with a
-    geometric taper of 3, 6, 12 .. ticks below T, the ticks in front of it are dealt into the fewest equal items)."""
-    n_tail, left, sz = 0, K, 3
-    while K >= 8 and sz < T and n_tail < 4 and left - sz >= sz:
-        n_tail, left, sz = n_tail + 1, left - sz, sz * 2
-    return -(-left // T) + n_tail
+def item_schedule(K, T, lib=None):
+    """The items per intersection of a persistent call of K ticks with items of at most T ticks, as pve_step_many lays them out
+    (pve_debug_item_schedule: the library's own schedule function -- host only, no device needed) -> list of item lengths."""
+    import ctypes as C
+    if lib is None:
+        from pve_mcc_amd import _capi
+        lib = _capi.load_library()
+    out = (C.c_int32 * 12)()
+    if lib.pve_debug_item_schedule(int(K), int(T), out) != 0:
+        raise ValueError("no persistent schedule for K = %d, T = %d" % (K, T))
+    return [out[0]] * out[1] + [out[3 + k] for k in range(out[2])]
+
+
+def persistent_items(K, T, lib=None):
+    return len(item_schedule(K, T, lib))
 
 
 def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=4096):
@@ -635,6 +665,8 @@ def main(argv=None, env_factory=None):
                          "measured; the default line times K ticks of it behind the headline region: `tape_slot_pool`)")
     ap.add_argument("--no-companion", action="store_true",
                     help="skip the second timed region (per-tick outputs retained) behind the headline roll-out")
+    ap.add_argument("--verify-seed", type=int, default=None,
+                    help="seed of the envs the self-check replays (default: drawn afresh every run and printed as verification.seed)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle replay of %d sampled envs after the timed region" % VERIFY_ENVS)
     ap.add_argument("--obs-f64", action="store_true",
@@ -682,6 +714,7 @@ def main(argv=None, env_factory=None):
     from pve_mcc_amd.distributed import gather_metrics
 
     cap, n_envs, lane_num = args.capacity, args.envs, args.lane_num
+    vseed = args.verify_seed if args.verify_seed is not None else int.from_bytes(os.urandom(4), "little")
     # capacity 64: 350 veh/h/lane keeps the peak population of 4096 envs x 2300 ticks at 57 of 64 slots (oracle run): no deferred
     # spawn ever enters a timed run (400 peaks at 62, 450 at 64+, 500 overflowed 4539 times in round 1)
     # closed loop: the pretrained actor keeps ~7 % more vehicles in the box than the sin tape; 1000 veh/h/lane keeps every
@@ -887,7 +920,7 @@ def main(argv=None, env_factory=None):
         return subs[k], le
     if args.actor and not args.no_verify and not emu:
         sync()
-        verify = verify_closed_loop(torch, dev, locate, arr, tick[0], cap, obs_dtype, actor_weights(), lane_num=lane_num, choice=choice)
+        verify = verify_closed_loop(torch, dev, locate, arr, tick[0], cap, obs_dtype, actor_weights(), lane_num=lane_num, choice=choice, seed=vseed)
     elif args.actor:
         verify = dict(verified=None, reason="closed loop: skipped (--no-verify) or no GPU replay available")
     elif not args.no_verify:
@@ -902,7 +935,7 @@ def main(argv=None, env_factory=None):
             return {n: b.out[n][le].cpu().numpy() for n in ("flags", "reward", "env_out")}
         if all(n in outputs for n in ("flags", "reward", "env_out")):
             sync()
-            verify = verify_against_oracle(locate, last_outputs, arr, pool_np, tick[0], lane_num, choice, table_np=table_np)
+            verify = verify_against_oracle(locate, last_outputs, arr, pool_np, tick[0], lane_num, choice, table_np=table_np, seed=vseed + rank)
         else:
             verify = dict(verified=None, reason="needs the flags, reward and env_out outputs")
     # ---- companion figure: the headline roll-out overwrites each tick's outputs with the next tick's; the same K
@@ -934,7 +967,7 @@ def main(argv=None, env_factory=None):
             n_calls = -(-K // tl)
             last_buf, last_k = ring2[(n_calls - 1) & 1], (K - (n_calls - 1) * tl) - 1
             cv = verify_against_oracle(locate, lambda e: {n: last_buf[n][last_k, locate(e)[1]].cpu().numpy() for n in ("flags", "reward", "env_out")},
-                                       arr, pool_np, tick[0], lane_num, choice, table_np=table_np)
+                                       arr, pool_np, tick[0], lane_num, choice, table_np=table_np, seed=vseed + 1)
             companion.update(verified=cv["verified"], verification=cv)
         del ring2
     # ---- the slot-indexed sin pool (the headline of rounds 1-4) beside BASELINE.md 3's id-indexed tape, or the other way round
@@ -969,14 +1002,14 @@ def main(argv=None, env_factory=None):
             and cap == 128 and not args.no_companion and K > 0:
         del env
         torch.cuda.empty_cache()
-        closed_loop = run_companion(torch, dev, "closed_loop", K, W, rank, n_envs, verify=not args.no_verify)
-        cap64 = run_companion(torch, dev, "cap64", K, W, rank, n_envs, verify=not args.no_verify)
-        cap64_on_spec = run_companion(torch, dev, "cap64_on_spec", K, W, rank, n_envs, verify=not args.no_verify)
+        closed_loop = run_companion(torch, dev, "closed_loop", K, W, rank, n_envs, verify=not args.no_verify, vseed=vseed + 2)
+        cap64 = run_companion(torch, dev, "cap64", K, W, rank, n_envs, verify=not args.no_verify, vseed=vseed + 3)
+        cap64_on_spec = run_companion(torch, dev, "cap64_on_spec", K, W, rank, n_envs, verify=not args.no_verify, vseed=vseed + 4)
     # ---- multi-rank runs carry BASELINE config 4 (64-slot intersections sharded over the ranks) beside the weak-scaled headline
     config4 = None
     if world > 1 and lane_num == 12 and not args.no_companion and K > 0 and (mode == "rollout" or emu):
         del env
-        config4 = run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=env_factory, verify=not args.no_verify)
+        config4 = run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=env_factory, verify=not args.no_verify, vseed=vseed + 5)
     ok_flag = 0.0 if (verify["verified"] is False or any(c and c.get("verified") is False for c in (closed_loop, cap64, cap64_on_spec, config4, companion))) else 1.0
     if world > 1:
         tv = torch.tensor([ok_flag], dtype=torch.float64, device=dev)
@@ -1009,6 +1042,8 @@ def main(argv=None, env_factory=None):
                  ("k_rollout_geo<%d>" if mode == "rollout" else "k_tick_geo<%d>")) % cap
         if pers:
             kname += " persistent (PERS: work queue)"
+            if lane_num == 12 and cap == 128 and not args.actor and not traj_on and not any(n in outputs for n in ("obs_pre", "state_pre")):
+                kname = "k_rollout<128, 5, ..> persistent (PERS: work queue; HOME: carried per-slot fields in LDS homes, 10 workgroups per CU)"
         if args.actor:
             kname += " with the actor inside (ACT)" if mode == "rollout" else " + k_actor_h"
         # (another kernel variant than the profiled one: the committed counter passes are those of the default = id-sin command)
@@ -1102,7 +1137,13 @@ def main(argv=None, env_factory=None):
                                        "launch (a persistent launch = the whole timed call: rocprofv3's LAST dispatch of the kernel); "
                                        "achieved_counter_bytes = HBM bytes the PMC counters saw (traffic, profiled on this "
                                        "very build and config, else null) / wall-clock per tick; peak_measured = 1 GiB "
-                                       "device copy, read + write; binding = the roofline that actually limits the kernel"},
+                                       "device copy, read + write; binding = the roofline that actually limits the kernel.  "
+                                       "TWO READINGS of north_star's `>= 40 % HBM roofline`: `frac` answers SURVEY 8d's accounting "
+                                       "(algorithmic bytes the mode must move / time / 8 TB/s: what a byte-minimal implementation "
+                                       "of the same interface would have to stream); `frac_counter_bytes` answers the literal one "
+                                       "(`rocprof achieved-HBM-GB/s against the chip's peak`: bytes the memory system actually "
+                                       "moved, ~half the algorithmic ones because empty slots, uncontrolled rows and unchanged "
+                                       "fields are never written) -- the kernel is bound by `binding`, not by either"},
         }
         if args.actor:
             line["roofline"]["note"] = "closed loop: actor + tick per step; achieved uses the tick's algorithmic bytes only"

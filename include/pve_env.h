@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PVE_ABI_VERSION 7
+#define PVE_ABI_VERSION 8
 #define PVE_LANES 12          /* physical lanes: lane_num = 4, 8 or 12 (arrays are padded to 12) */
 #define PVE_MAX_DIRS 16       /* virtual-lane lists (routes): 12 for lane_num 4 / 12, 16 for lane_num 8 (ref :86, :132, :167) */
 #define PVE_OBS_WIDTH 28      /* (o_agent_num + 1) * 4, ref :1295 */
@@ -289,6 +289,11 @@ int pve_debug_phase_cycles(pve_handle h, uint64_t *dev_counters16);
 enum { PVE_LAUNCH_NONE = 0, PVE_LAUNCH_TICK = 1 /* one launch per tick */, PVE_LAUNCH_RESIDENT = 2 /* one k_rollout launch per chunk */,
        PVE_LAUNCH_PERSISTENT = 3 /* ONE launch for the call, items pulled from the work queue */ };
 int pve_debug_last_launch(pve_handle h);
+
+/* Diagnostics: the item schedule pve_step_many lays out for a persistent call of n_ticks ticks with items of at most chunk_ticks
+ * ticks (the per-episode loop `for i in range(1000)` of main.py:397 cut into queue items): out[0] = ticks per full item, out[1] =
+ * full items, out[2] = tapered items behind them, out[3 .. 10] = their lengths, out[11] = items per intersection.  Host only. */
+int pve_debug_item_schedule(int n_ticks, int chunk_ticks, int32_t out[12]);
 
 /* Diagnostics: every later pve_step_all / pve_scene_update launch of the 12-lane kernel (k_tick) RETURNS behind phase n
  * (0 load, 1 step1, 2 step2, 3 step3, 4 build, 5 rank, 6 walk + reward, 7 effects, 8 lock) without writing any state, so

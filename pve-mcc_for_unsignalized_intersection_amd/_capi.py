@@ -22,7 +22,7 @@ PVE_NBR = 6
 PVE_N_METRICS = 12
 PVE_ENV_OUT_N = 8
 PVE_ACTOR_N_WEIGHTS = 6393
-ABI_VERSION = 7
+ABI_VERSION = 8
 SRC_ZERO, SRC_POOL, SRC_ACTOR, SRC_TABLE = 0, 1, 2, 3
 
 F_ALIVE, F_CTL, F_DONE, F_DELETED, F_FINISHED, F_LOCK = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
@@ -76,7 +76,7 @@ EXPORTS = ("pve_abi_version", "pve_last_error", "pve_default_config", "pve_works
            "pve_scene_update", "pve_compact", "pve_read_env", "pve_read_vehicles", "pve_get_metrics",
            "pve_state_field", "pve_synchronize", "pve_debug_phase_cycles", "pve_actor_forward",
            "pve_step_all_actor", "pve_debug_traffic_probe", "pve_set_intentions", "pve_step_many", "pve_set_actor",
-           "pve_debug_stop_phase", "pve_debug_last_launch")
+           "pve_debug_stop_phase", "pve_debug_last_launch", "pve_debug_item_schedule")
 LAUNCH_NONE, LAUNCH_TICK, LAUNCH_RESIDENT, LAUNCH_PERSISTENT = 0, 1, 2, 3      # pve_debug_last_launch
 
 
@@ -104,6 +104,7 @@ def _declare(L):
     L.pve_debug_phase_cycles.argtypes = [vp, vp]
     L.pve_debug_stop_phase.argtypes = [vp, C.c_int]
     L.pve_debug_last_launch.argtypes = [vp]
+    L.pve_debug_item_schedule.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32)]
     L.pve_debug_traffic_probe.argtypes = [vp, vp]
     L.pve_set_actor.argtypes = [vp, vp]
     L.pve_actor_forward.argtypes = [vp, vp, vp, vp]

@@ -473,7 +473,10 @@ class BatchedIntersections:
     def last_launch(self):
         """What the last stepping call launched: "tick" (one launch per tick), "resident" (one k_rollout launch per chunk),
         "persistent" (one launch for the call, items pulled from the work queue) or "none" (pve_debug_last_launch)."""
-        return ("none", "tick", "resident", "persistent")[self.lib.pve_debug_last_launch(self._h)]
+        k = self.lib.pve_debug_last_launch(self._h)
+        if k < 0 or k > 3:                              # (a negative PVE_ERR_* must not index the tuple from its end)
+            check(self.lib, k if k < 0 else -1, "pve_debug_last_launch")
+        return ("none", "tick", "resident", "persistent")[k]
 
     # ------------------------------------------------------------------ host read-back
     def read_env(self, env=0):

@@ -141,3 +141,21 @@ def test_actor_and_rollout_argument_validation():
     cfg.am = -1e-9
     h = C.c_void_p()
     assert lib.pve_create(C.byref(cfg), 2, 64, 0, None, None, C.byref(h)) == -1 and b"|am|" in lib.pve_last_error()
+
+
+def test_item_schedule_of_the_persistent_call_has_no_tiny_items():
+    """pve_debug_item_schedule (the function pve_step_many uses): the items of every call add up to the call, none is longer than
+    chunk_ticks, and for calls of >= 8 ticks none is shorter than 2 ticks (the K = 1000, T = 10 default of the steady
+    bench shape used to end in 1, 6, 3 -- an item of one tick cannot hide its load and flush)."""
+    import bench
+    lib = emulator_lib()
+    assert bench.item_schedule(20, 12, lib) == [11, 6, 3]
+    assert bench.item_schedule(1000, 10, lib)[-4:] == [6, 5, 6, 3] and min(bench.item_schedule(1000, 10, lib)) >= 3
+    for T in (4, 5, 6, 7, 10, 12, 25, 64, 255):
+        for K in range(T + 1, 1400):
+            items = bench.item_schedule(K, T, lib)
+            assert sum(items) == K and max(items) <= T, (K, T, items)
+            if K >= 8:
+                assert min(items) >= 2, (K, T, items)
+    out = (C.c_int32 * 12)()
+    assert lib.pve_debug_item_schedule(10, 10, out) == -1 and lib.pve_debug_item_schedule(10, 0, out) == -1

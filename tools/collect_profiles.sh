@@ -71,8 +71,6 @@ PMC_BENCH_ARGS="--steps 20 --warmup 5" bash tools/pmc_sq.sh persist_short > /dev
 PMC_BENCH_ARGS="--persistent 0" bash tools/pmc_sq.sh rollout > /dev/null 2>&1
 PMC_BENCH_ARGS="--mode step" bash tools/pmc_sq.sh step > /dev/null 2>&1
 PMC_BENCH_ARGS="--actor" bash tools/pmc_sq.sh actor > /dev/null 2>&1
-# ---- address unit / vector L1 counters of the headline command (the 16-byte pieces of the observation rows)
-bash tools/pmc_ta.sh persist > /dev/null 2>&1; cp gpurun_out/pmc_ta_persist.txt $O/ 2>/dev/null
 cp gpurun_out/pmc_sq_persist.txt gpurun_out/pmc_sq_persist_short.txt gpurun_out/pmc_sq_rollout.txt gpurun_out/pmc_sq_step.txt gpurun_out/pmc_sq_actor.txt $O/ 2>/dev/null
 # ---- per-phase counters of the 12-lane tick (truncated launches), phase profiles, launch-shape A/B
 bash tools/phase_counters.sh > /dev/null 2>&1; cp gpurun_out/phase_counters.txt $O/ 2>/dev/null
@@ -88,6 +86,10 @@ make -s -C pve-mcc_for_unsignalized_intersection_amd/csrc knobs > /dev/null 2>&1
 # ---- per-item timeline of one persistent call (diagnostics build of the library: -DPVE_QUEUE_TRACE)
 make -s -C pve-mcc_for_unsignalized_intersection_amd/csrc trace > /dev/null 2>&1 && \
   PVE_LIBRARY_PATH=$(pwd)/build/libpveenv_trace.so python tools/persistent_trace.py 2>&1 | grep -v amdgpu.ids > $O/persistent_trace.txt
+# ---- address unit / vector L1 counters of the headline command (the 16-byte pieces of the observation rows).  LAST, and opt-in
+# (TA=1): a TA_* group has aborted rocprofv3 and hung in finalisation on this pool before (tools/pmc_mem.sh) -- five passes under
+# `timeout 200` each must not starve the artefacts above
+[ "${TA:-0}" = "1" ] && { bash tools/pmc_ta.sh persist > /dev/null 2>&1; cp gpurun_out/pmc_ta_persist.txt $O/ 2>/dev/null; }
 # keep what comes back small (gpurun merges <= 64 MiB): only the rocpd databases of the raw rocprofv3 directories are needed
 find $O gpurun_out/pmc_sq_* gpurun_out/phase_counters -type f \( -name "*.csv" -o -name "*.json" -o -name "*.log" -o -name "*.txt" \) -path "*_p[0-9]*" -size +200k -delete 2>/dev/null
 rm -rf gpurun_out/pmc_sq_*/p*/ gpurun_out/pmc_ta_*/ gpurun_out/phase_counters/s* 2>/dev/null
