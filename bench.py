@@ -367,13 +367,14 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True, vseed=0):
     from pve_mcc_amd.arrivals import synthetic_arrivals
     closed = kind == "closed_loop"
     on_spec = kind == "cap64_on_spec"
-    cap, rate = (128, 1000.0) if closed else (64, 500.0 if on_spec else 350.0)
+    full_rate = kind == "config2_rate_128slots"           # config 2's STATED rate with room for every vehicle: no deviation
+    cap, rate = (128, 1000.0) if closed else ((128, 500.0) if full_rate else (64, 500.0 if on_spec else 350.0))
     prefill = PREFILL_MIN
-    seed = 20250213 + (104729 if closed else (15485863 if on_spec else 1299709)) + rank * n_envs
+    seed = 20250213 + (104729 if closed else (15485863 if (on_spec or full_rate) else 1299709)) + rank * n_envs   # (full_rate: cap64_on_spec's streams)
     arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=(prefill + W + K) * 0.1 + 20.0, seed=seed, lane_num=12)
     obs_dtype = torch.float32 if closed else torch.float64
     outputs = ("obs_post", "reward", "flags", "nbr", "new_slot", "env_out")
-    n_sub, chunk, pers = launch_shape(cap, K, 12, closed, n_envs=n_envs)
+    n_sub, chunk, pers = launch_shape(cap, K, 12, closed, table=not closed, n_envs=n_envs)
     if n_sub == 1:
         env = pve_mcc_amd.BatchedIntersections(n_envs, cap, arr, device=dev, outputs=outputs, obs_dtype=obs_dtype)
     else:
@@ -429,6 +430,10 @@ def run_companion(torch, dev, kind, K, W, rank, n_envs, verify=True, vseed=0):
                      "intersections fill all 64 slots and defer spawns (`overflow`, the build's documented deviation from the "
                      "reference, which has no capacity): throughput is reported as measured, parity on the sampled envs that never "
                      "overflowed" if on_spec else
+                     "BASELINE config 2's workload WITHOUT a deviation: %d intersections at its stated 500 veh/h/lane (cap64_on_spec's very "
+                     "streams) in %d-slot intersections -- the oracle, which like the reference has no capacity, peaks at 74 vehicles over "
+                     "4096 envs x 2300 ticks of these streams (tools/peak_population.py: 189 envs need more than 64 slots, none more than "
+                     "96), so no spawn is ever deferred (overflow 0) and every sampled env is held to the oracle" if full_rate else
                      "BASELINE config 2: %d x %d, BASELINE.md 3's tape a = float32(sin(0.37 id + 0.05 tick)) by vehicle id, 350 veh/h/lane "
                      "(BASELINE.md's 500 overflows 64 slots in 4096 envs: the `cap64_on_spec` leg)")) % (n_envs, cap),
            "ms_per_step": dt / K * 1e3, "value": float(cap) * n_envs * K / dt, "unit": "env-steps/s", "steps": K, "warmup": W,
@@ -997,7 +1002,7 @@ def main(argv=None, env_factory=None):
         else:
             tape_id_sin = comp
     # ---- BASELINE configs 5 and 2 beside the headline (config 3), each on envs of its own, timed outside the headline region
-    closed_loop = cap64 = cap64_on_spec = None
+    closed_loop = cap64 = cap64_on_spec = config2_rate_128slots = None
     if mode == "rollout" and not traj_on and not args.actor and not emu and world == 1 and lane_num == 12 \
             and cap == 128 and not args.no_companion and K > 0:
         del env
@@ -1005,12 +1010,13 @@ def main(argv=None, env_factory=None):
         closed_loop = run_companion(torch, dev, "closed_loop", K, W, rank, n_envs, verify=not args.no_verify, vseed=vseed + 2)
         cap64 = run_companion(torch, dev, "cap64", K, W, rank, n_envs, verify=not args.no_verify, vseed=vseed + 3)
         cap64_on_spec = run_companion(torch, dev, "cap64_on_spec", K, W, rank, n_envs, verify=not args.no_verify, vseed=vseed + 4)
+        config2_rate_128slots = run_companion(torch, dev, "config2_rate_128slots", K, W, rank, n_envs, verify=not args.no_verify, vseed=vseed + 6)
     # ---- multi-rank runs carry BASELINE config 4 (64-slot intersections sharded over the ranks) beside the weak-scaled headline
     config4 = None
     if world > 1 and lane_num == 12 and not args.no_companion and K > 0 and (mode == "rollout" or emu):
         del env
         config4 = run_config4(torch, dist, dev, K, W, rank, world, n_envs, env_factory=env_factory, verify=not args.no_verify, vseed=vseed + 5)
-    ok_flag = 0.0 if (verify["verified"] is False or any(c and c.get("verified") is False for c in (closed_loop, cap64, cap64_on_spec, config4, companion))) else 1.0
+    ok_flag = 0.0 if (verify["verified"] is False or any(c and c.get("verified") is False for c in (closed_loop, cap64, cap64_on_spec, config2_rate_128slots, config4, companion))) else 1.0
     if world > 1:
         tv = torch.tensor([ok_flag], dtype=torch.float64, device=dev)
         dist.all_reduce(tv, op=dist.ReduceOp.MIN)
@@ -1086,7 +1092,8 @@ def main(argv=None, env_factory=None):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "synthetic (injected test environment: timings meaningless)",
             "verified": verify["verified"], "verification": verify,
             "retained_outputs": companion, "tape_id_sin": tape_id_sin, "tape_slot_pool": tape_slot_pool,
-            "closed_loop": closed_loop, "cap64": cap64, "cap64_on_spec": cap64_on_spec, "config4": config4,
+            "closed_loop": closed_loop, "cap64": cap64, "cap64_on_spec": cap64_on_spec, "config2_rate_128slots": config2_rate_128slots,
+            "config4": config4,
             "config": {"workload": "%d parallel %d-lane intersections x %d vehicle slots per GPU, synthetic Poisson "
                                    "arrivals %.0f veh/h/lane, %s, fused step+scene_update+delete tick"
                                    % (n_envs, lane_num, cap, rate, "on-device MADDPG actor (pretrained 66.cptk weights) closing the loop"
@@ -1159,7 +1166,7 @@ def main(argv=None, env_factory=None):
         dist.destroy_process_group()
     if ok_flag < 1.0:
         bad = [v.get("mismatch") for v in [verify] + [c.get("verification") or c.get("verification_rank0") or {}
-                                                      for c in (closed_loop, cap64, cap64_on_spec, config4, companion) if c] if v.get("verified") is False]
+                                                      for c in (closed_loop, cap64, cap64_on_spec, config2_rate_128slots, config4, companion) if c] if v.get("verified") is False]
         sys.exit("bench.py: the timed environments do NOT match the checker (%s)" % "; ".join(str(b) for b in bad))
 
 

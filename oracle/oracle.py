@@ -44,7 +44,7 @@ def lib():
     L.pvo_delete_vehicle.argtypes = [vp]
     L.pvo_tick_actions.argtypes = [vp, dp]
     for name in ("pvo_n_ctl", "pvo_collisions", "pvo_lock", "pvo_n_jerks", "pvo_n_deleted",
-                 "pvo_ref_would_raise", "pvo_n_alive"):
+                 "pvo_ref_would_raise", "pvo_n_alive", "pvo_peak_alive"):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [vp]
     for name in ("pvo_ids", "pvo_nbr", "pvo_coll_pv", "pvo_deleted"):
@@ -121,6 +121,11 @@ class OracleEnv:
     @property
     def ref_would_raise(self):
         return self._L.pvo_ref_would_raise(self._h)
+
+    @property
+    def peak_alive(self):
+        """most vehicles alive at the start of a tick of run() (the slots a capacity-bound build would need)"""
+        return self._L.pvo_peak_alive(self._h)
 
     def lane_counts(self):
         out = np.zeros(12, np.int32)

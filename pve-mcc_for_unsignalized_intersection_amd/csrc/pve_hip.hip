@@ -423,6 +423,20 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const PVE_AS4 RolloutArgs &R = *(const PVE_AS4 RolloutArgs *)(ka + OFF_R);
         lds_barrier();
         PVE_PHASE_MARK(0)
+        if constexpr (CAP == 64 && !PERS) {
+            // One wave per intersection, every intersection of the launch resident at once: the launch lasts as long as its
+            // SLOWEST intersection (the one with the most vehicles: +-15 % over the 20 ticks of a short call), and nothing can be
+            // re-balanced between workgroups.  So the waves of the crowded intersections get the issue slots first (uniform, one
+            // scalar instruction per tick): they run at nearly their solo speed, the light ones -- which finish early anyway --
+            // yield.  Thresholds: quartiles of the population at BASELINE config 2's load (31 vehicles on average).
+            const int na = __builtin_amdgcn_readfirstlane(sh.hd.n_alive);
+#ifndef PVE_NO_LOAD_PRIO                          // (A/B build knob)
+            if (na > 38) __builtin_amdgcn_s_setprio(3);
+            else if (na > 32) __builtin_amdgcn_s_setprio(2);
+            else if (na > 26) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#endif
+        }
         if (k > 0) T::ph_tick_init(c, t, sh, r);
         T::ph_step1(c, P, env, t, sh, r);
         lds_barrier();

@@ -32,18 +32,18 @@ VARIANTS = [
 TICKS = 300
 
 
-def stream_1000():
-    """the reference's own 1000 veh/h stream (data file committed under tests/golden/streams, read by the product's reader)"""
+def stream(name="1000"):
+    """the reference's own 1000 / 200 veh/h streams (data files committed under tests/golden/streams, read by the product's reader)"""
     from pve_mcc_amd.arrivals import load_arrival_mat
-    return np.ascontiguousarray(load_arrival_mat(os.path.join(GOLDEN_DIR, "streams", "arvTimeNewVeh_new_1000_12.mat")), np.float64)
+    return np.ascontiguousarray(load_arrival_mat(os.path.join(GOLDEN_DIR, "streams", "arvTimeNewVeh_new_%s_12.mat" % name)), np.float64)
 
 
 class KwCase:
     """what scenarios.check_split_vs_oracle needs of a golden case, without a fixture"""
 
-    def __init__(self, name, kw, ticks=TICKS):
+    def __init__(self, name, kw, ticks=TICKS, stream_name="1000"):
         self.name = "kw_" + name
-        self.arrive = stream_1000()
+        self.arrive = stream(stream_name)
         self.ctor = dict(kw)
         self.policy = get_policy("rand3")
         self.ticks = ticks
@@ -91,8 +91,9 @@ def test_emulated_step_many_under_ctor_kwargs():
 @pytest.mark.parametrize("name,kw", VARIANTS, ids=[v[0] for v in VARIANTS])
 def test_gpu_kernels_vs_oracle_under_ctor_kwargs(name, kw):
     scenarios.check_split_vs_oracle(KwCase(name, kw), "hip", ticks=TICKS)
-    if name in ("accel", "all"):                       # the capacity-64 kernels too (their own instantiation of every phase)
-        scenarios.check_split_vs_oracle(KwCase(name, kw, ticks=150), "hip", ticks=150, capacity=64)
+    if name in ("accel", "all"):                       # the capacity-64 kernels too (their own instantiation of every phase;
+        # the 200 veh/h stream: the 1000 one needs more than 64 slots)
+        scenarios.check_split_vs_oracle(KwCase(name, kw, ticks=400, stream_name="200"), "hip", ticks=400, capacity=64)
 
 
 @pytest.mark.gpu

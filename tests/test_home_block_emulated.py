@@ -68,5 +68,6 @@ def test_home_block_symmetric_lanes_equal_distances(monkeypatch):
 def test_home_block_driver_shape_vs_oracle(monkeypatch):
     """the bench's call shape (prefill + short persistent calls) against the sequential oracle, every tick"""
     monkeypatch.setenv("PVE_EMU_HOME", "1")
-    m, _ = scenarios.check_driver_shape_vs_oracle(BACKEND, n_envs=6, n_sub=1, n_sample=6, calls=(30, 30, 5, 20))
+    m, _ = scenarios.check_driver_shape_vs_oracle(BACKEND, n_envs=6, n_sub=1, n_sample=6, calls=(30, 30, 5, 20), chunk=12, persistent=True,
+                                                  table=True)
     assert m["ctl_steps"] > 0
