@@ -576,7 +576,7 @@ def launch_shape(cap, K, lane_num, actor, table=False, trajectory=False, n_envs=
         gives the queue nothing to balance)."""
     if lane_num == 12 and not actor and n_envs >= 4096:     # (the queue balances a batch of >= 2x the workgroups the chip holds)
         if cap == 128:
-            return 1, (12 if K < 100 else 10), True      # (a 20-tick call becomes items of 11, 6 and 3 ticks)
+            return 1, (12 if K < 100 else 10), True      # (a 20-tick call becomes items of 9, 7 and 4 ticks)
         return 1, 0, False
     if lane_num == 12 and actor and cap == 128 and n_envs >= 4096:
         return 1, (25 if K >= 100 else 12), True     # closed loop: 34.6 against 35.9 us per tick (long call), 41.7 against 43.6 (20 ticks)
