@@ -124,7 +124,7 @@ def cpu_baseline(arr, pool, cap, lane_num=12, choice=None, id_sin=False):
 
 # (launch-shape knobs exist in the `make knobs` build of the library only; a run with one of them set measures another kernel)
 KNOBS = ("PVE_NO_ROLLOUT_KERNEL", "PVE_NO_ROLLOUT_ACTOR", "PVE_ROLLOUT_GEO_WPE5", "PVE_ACTOR_GRID",
-         "PVE_LIBRARY_PATH", "PVE_NO_PERSISTENT", "PVE_TAPER_TAIL", "PVE_PERSISTENT_GRID")
+         "PVE_LIBRARY_PATH", "PVE_NO_PERSISTENT", "PVE_TAPER_TAIL", "PVE_PERSISTENT_GRID", "PVE_ROLLOUT_WPE5")
 
 
 def csrc_sha():

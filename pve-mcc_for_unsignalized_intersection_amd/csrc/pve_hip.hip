@@ -313,6 +313,8 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     constexpr size_t OFF_P = (sizeof(Const) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     // (WPE = 5, the 96-VGPR experiment: the block without the lane << 16 | j words is 16 368 B -> 10 workgroups per CU)
     // (WPE = 5 also: HOME -- the carried per-slot fields live in LDS instead of registers, pve_tick_core.h)
+    // (the HOME block without the lane << 16 | j words: with them it is 16 896 B = 9 workgroups per CU, measured 24.75 against
+    //  24.78 us -- 9 and 10 resident workgroups per CU run at the same rate, the words buy nothing there)
     typedef Shared<CAP, (CAP == 128 && WPE == 4), (WPE == 5)> ShT;
     __shared__ ShT sh;
     __shared__ __attribute__((aligned(64))) float aprm[ACT ? PV_TOTAL : 1];
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             adst = -1;
             T::template ph_final<true>(c, P, O, env, t, sh, r, fc, true, &adst);
             adsts[t] = (uint8_t)(adst < 0 ? 255 : adst);  // (dense thread t; threads >= n_ctl: 255)
-        } else T::template ph_final<true, !TRAIN && WPE == 4>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
+        } else T::template ph_final<true, !TRAIN>(c, P, O, env, t, sh, r, fc, k + 1 == n_ticks || (TRAIN && O.state_pre != nullptr));
         PVE_PHASE_MARK(9)
         if constexpr (IDT) {
             if (fc.new_slot >= 0) sh.act_next[fc.new_slot] = r.act_nx;   // (act_next = xy32: dead since REWARD)

@@ -85,8 +85,9 @@ try:
     # (tag, kernel name prefix, profile key, ticks of the counted launch, envs per launch, which launch)
     for tag, kkey, mode, tpl, envs, field in (
             # (the default command gathers BASELINE.md 3's tape by vehicle id: the IDT variants)
-            ("persist", "void k_rollout<128, 4, false, false, false, true, true>", "persist", 100, 4096, "last"),
-            ("persist_short", "void k_rollout<128, 4, false, false, false, true, true>", "persist_short", 20, 4096, "last"),
+            # (round 6: the HOME build k_rollout<128, 5, ..> is what the queue form launches for 128 slots)
+            ("persist", "void k_rollout<128, 5, false, false, false, true, true>", "persist", 100, 4096, "last"),
+            ("persist_short", "void k_rollout<128, 5, false, false, false, true, true>", "persist_short", 20, 4096, "last"),
             ("rollout", "void k_rollout<128, 4, false, false, false, true, false>", "rollout", 25, 2048, "mean/launch"),
             ("step", "void k_tick<128>", "step", 1, 2048, "mean/launch"),
             ("actor", "void k_rollout<128, 4, false, true, false, false, true>", "actor_persist", 100, 4096, "last")):
