@@ -65,6 +65,9 @@ def lib():
     L.pvo_run.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_long)]
     L.pvo_run_pool.restype = C.c_long
     L.pvo_run_pool.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
+    L.pvo_run_many.restype = C.c_long
+    L.pvo_run_many.argtypes = [C.POINTER(vp), ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, C.c_int, C.c_int, C.c_int,
+                               C.POINTER(C.c_long)]
     _lib = L
     return L
 
@@ -211,3 +214,26 @@ class OracleEnv:
                                      pool.shape[0], pool.shape[1], int(tick0), C.byref(ctl))
         self.tick_no += ticks
         return int(alive), int(ctl.value)
+
+
+def run_many(envs, env_index, n_threads, ticks, policy=1, amp=1.0, tick0=0, pool=None):
+    """bench.py's cpu_baseline on all host cores: `envs` (OracleEnv objects) dealt to n_threads POSIX threads inside ONE C call
+    (pvo_run_many) -- no Python, no GIL in the timed loop.  pool: [n_pool, n_envs_total, cap] float64 (env_index[i] = the row of
+    envs[i] in it) for the slot-indexed tape, None for policy 0 (zero) / 1 (a = amp sin(0.37 id + 0.05 tick)).
+    -> (alive_steps, ctl_steps)"""
+    L = lib()
+    hs = (C.c_void_p * len(envs))(*[e._h for e in envs])
+    idx = np.ascontiguousarray(env_index, dtype=np.int32)
+    ctl = C.c_long(0)
+    if pool is not None:
+        pool = np.ascontiguousarray(pool, dtype=np.float64)
+        pp, n_pool, n_tot, cap = pool.ctypes.data_as(C.POINTER(C.c_double)), pool.shape[0], pool.shape[1], pool.shape[2]
+    else:
+        pp, n_pool, n_tot, cap = None, 0, 0, 0
+    alive = L.pvo_run_many(hs, idx.ctypes.data_as(C.POINTER(C.c_int)), len(envs), int(n_threads), int(ticks), int(policy), float(amp),
+                           int(tick0), pp, n_pool, cap, n_tot, C.byref(ctl))
+    if alive < 0:
+        raise MemoryError("pvo_run_many")
+    for e in envs:
+        e.tick_no += ticks
+    return int(alive), int(ctl.value)

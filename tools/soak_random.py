@@ -52,7 +52,7 @@ print("%d runs: %d green, %d ended at a deferred spawn, 0 differences" % (a.runs
 # pve_step_many (k_rollout: still ticks, staged ticks, chunked launches, trajectory outputs) == single ticks, bit for bit
 for k in range(a.many):
     kind = str(rng.choice(["k_rollout", "k_rollout", "actor", "geo", "geo", "state", "persistent", "persistent", "geo_state", "geo_table",
-                           "state_pers", "state_pers", "closed_state", "closed_geo", "closed_geo"]))
+                           "state_pers", "state_pers", "closed_state", "closed_geo", "closed_geo", "home", "home", "home"]))
     seed = int(rng.integers(1, 1 << 30))
     t0 = time.time()
     if kind in ("k_rollout", "actor"):
@@ -67,6 +67,20 @@ for k in range(a.many):
         scenarios.check_step_many(a.backend, src, n_envs=n_envs, capacity=cap, rate=rate, prefill=int(rng.choice([0, 150, 320])),
                                   chunks=chunks, trajectory_chunk=int(rng.integers(2, 30)), seed=seed)
         what = "cap %3d rate %6.0f %s chunks %s x %2d envs" % (cap, rate, src, chunks, n_envs)
+    elif kind == "home":                                        # round 6: the HOME build of the 128-slot queue kernel under random constructor
+        # arguments and loads up to a FULL intersection (more list entries than its pool holds: several BUILD .. WALK passes; deferred
+        # spawns: the table source's late gather)
+        src = str(rng.choice(["table", "table", "pool", "zero"]))
+        cfg = dict(vm=float(rng.choice([0.5, 2.0, 3.0, 5.0, 6.0])), collision_thr=float(rng.choice([0.01, 2.0, 3.0])),
+                   deltaT=float(rng.choice([0.1, 0.1, 0.2])), dis_ctl=float(rng.choice([150.0, 120.0])))
+        rate = float(rng.uniform(600.0, 3200.0))
+        n_envs = int(rng.choice([9, 40, 130, 300]))
+        chunks = tuple(int(x) for x in rng.integers(8, 120, size=int(rng.integers(2, 5))))
+        lo_a = float(rng.choice([-3.0, -3.0, -1.0]))
+        st = scenarios.check_step_many(a.backend, src, n_envs=n_envs, capacity=128, rate=rate, prefill=int(rng.choice([0, 150, 250])),
+                                       chunks=chunks, trajectory_chunk=int(rng.integers(2, 30)), seed=seed, persistent=True, cfg=cfg,
+                                       act_lo=lo_a, act_hi=float(rng.choice([-2.0, 0.0, 3.0])) if lo_a < -2 else 3.0)
+        what = "HOME %s rate %6.0f cfg %s chunks %s x %3d envs: max alive %d overflow %d" % (src, rate, cfg, chunks, n_envs, st["max_alive"], st["overflow"])
     elif kind == "persistent":                                  # the work-queue launch (round 4): intersections change hands inside the launch
         cap = int(rng.choice([64, 128, 128]))
         lo, hi = RATES[(12, cap)]
