@@ -458,13 +458,20 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             // holds ~100 controlled vehicles; pve_tick_core.h, group_end)
             T::ph_build_prep(c, t, sh, r);
             T::ph_scan_init(r);
+            if (__builtin_amdgcn_readfirstlane((int)sh.loff[NL]) <= ShT::POOL) {      // (uniform; the rule: every list in ONE pass,
+                T::template ph_build_fill<false>(c, t, sh, r, 0, NL);                 //  the very code of the 5 CAP blocks)
+                lds_barrier();
+                T::template ph_rank<false>(t, sh);
+                lds_barrier();
+                T::template ph_scan_lists<false>(c, t, sh, r, 0, NL);
+            } else
             for (int d0 = 0, pass = 0; d0 < NL; pass++) {
                 const int d1 = __builtin_amdgcn_readfirstlane(T::group_end(sh, d0));
-                T::ph_build_fill(c, t, sh, r, d0, d1);
+                T::template ph_build_fill<true>(c, t, sh, r, d0, d1);
                 lds_barrier();
-                T::ph_rank(t, sh, pass, d0, d1);
+                T::template ph_rank<true>(t, sh, pass, d0, d1);
                 lds_barrier();
-                T::ph_scan_lists(c, t, sh, r, d0, d1);
+                T::template ph_scan_lists<true>(c, t, sh, r, d0, d1);
                 d0 = d1;
                 if (d0 < NL) lds_barrier();           // (the next pass files its entries over the lists this one has just read)
             }
@@ -573,11 +580,6 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     if constexpr (PERS) q_leave(*(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R), t0_);
 }
 
-// tools/probe_kernel.sh: compile ONE variant of k_rollout (seconds instead of minutes for the whole library) to read its register
-// allocation / ISA while working on it: -DPVE_PROBE_ONE="128, 5, false, false, false, true, true"
-#ifdef PVE_PROBE_ONE
-template __global__ void k_rollout<PVE_PROBE_ONE>(const Const, const Params, const RolloutArgs);
-#else
 // General-geometry tick (lane_num 4 / 8): same workgroup-per-intersection structure, phases of
 // pve_tick_geo.h (per-route sorted lists: PAIRS -> RANK -> WALK; the membership scan only as the overflow fallback).
 // Registers: 5 waves per SIMD (<= 96 VGPR) for CAP = 128 = 10 workgroups per CU.  CAP = 64 is one wave per workgroup and its
@@ -880,6 +882,17 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     if constexpr (PERS) q_leave(*(const PVE_AS4 RolloutArgs *)(ka0_ + OFF_R), t0_);
 }
 
+// tools/probe_kernel.sh: compile ONE variant of k_rollout / k_rollout_geo (seconds instead of minutes for the whole library) to
+// read its register allocation / ISA while working on it: -DPVE_PROBE_ONE="128, 5, false, false, false, true, true" or
+// -DPVE_PROBE_GEO="128, true, 4, false, false, true, true"
+#if defined(PVE_PROBE_ONE) || defined(PVE_PROBE_GEO)
+#ifdef PVE_PROBE_ONE
+template __global__ void k_rollout<PVE_PROBE_ONE>(const Const, const Params, const RolloutArgs);
+#endif
+#ifdef PVE_PROBE_GEO
+template __global__ void k_rollout_geo<PVE_PROBE_GEO>(const GeoConst, const Params, const RolloutArgs);
+#endif
+#else
 template <int CAP>
 __global__ __launch_bounds__(64) void k_reset_geo(const GeoConst g_arg, const Params P_arg, int cap_ticks)
 {
@@ -1259,4 +1272,4 @@ struct Backend {
 };
 
 #include "pve_capi.inc"
-#endif   // PVE_PROBE_ONE
+#endif   // PVE_PROBE_ONE / PVE_PROBE_GEO

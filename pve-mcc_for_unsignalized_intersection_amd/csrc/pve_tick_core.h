@@ -934,7 +934,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_build(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         ph_build_prep(c, t, sh, r);
-        ph_build_fill(c, t, sh, r, 0, NL);
+        ph_build_fill<false>(c, t, sh, r, 0, NL);
     }
     static PVE_HD void ph_build_prep(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
@@ -954,14 +954,16 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         get_xy_f32(c, p, lane, sh.xy32[sl][0], sh.xy32[sl][1]);
     }
     // the entries of the lists [d0, d1) (HOME: one group of lists per pass; else all twelve)
+    // GRP = false: every list in one pass (the rule, and the only form of the blocks with a 5 CAP pool): no group arithmetic at all
+    template <bool GRP = Sh::HOME>
     static PVE_HD void ph_build_fill(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r, int d0, int d1)
     {
         if (!r.dctl) return;
         const int sl = r.ds, lane = r.dlane;
         const double p = r.dp;
-        const int gb = Sh::HOME ? (int)sh.loff[d0] : 0;       // entry index of the group's first list
+        const int gb = GRP ? (int)sh.loff[d0] : 0;            // entry index of the group's first list
         const int q = t - sh.cstart[lane];                    // its rank among the controlled vehicles of its lane
-        if (!Sh::HOME || (lane >= d0 && lane < d1)) {
+        if (!GRP || (lane >= d0 && lane < d1)) {
             const int e = sh.loff[lane] + q - gb;             // own lane: vd = p (ref :242-249)
             sh.u_vd[e] = p; sh.u_slot[e] = (uint8_t)sl; sh.u_list[e] = (uint8_t)lane;
         }
@@ -987,7 +989,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
             const double delta = p - tA[k] + tB[k];                            // ref :733-803 (the relation is symmetric: kk =
             const double vd = (delta > 0) ? (tC[k] + delta) : INFINITY;        // our position inside lane2lane[d]); not chosen -> never sorted
             const int e = lo[k] + so[k] + q - gb;
-            if constexpr (Sh::HOME) { if (d[k] < d0 || d[k] >= d1) continue; }   // (another pass's list)
+            if constexpr (GRP) { if (d[k] < d0 || d[k] >= d1) continue; }   // (another pass's list)
             sh.u_vd[e] = vd; sh.u_slot[e] = (uint8_t)sl; sh.u_list[e] = (uint8_t)d[k];
             lds_add(&sh.nfin[d[k]], (delta > 0) ? 1 : 0);                       // (unconditional: no guarded block per entry)
         }
@@ -1004,10 +1006,11 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     // the whole run of equal distances in slot order (every later arrival rewrites the same values; the LDS executes
     // the operations of a wave in order, so the last fix-up is the last write).  A stale word that happens to carry the
     // stamp (left-over LDS contents) only sends an entry through the fix-up, which then files just itself.
+    template <bool GRP = false>
     static PVE_HD void ph_rank(int t, Sh &sh, int salt = 0, int d0 = 0, int d1 = NL)
     {
-        const int gb = Sh::HOME ? (int)sh.loff[d0] : 0;   // (HOME: the lists [d0, d1) of this pass, entries relative to the first)
-        const int M = (Sh::HOME ? (int)sh.loff[d1] : (int)sh.loff[NL]) - gb;
+        const int gb = GRP ? (int)sh.loff[d0] : 0;        // (GRP: the lists [d0, d1) of this pass, entries relative to the first)
+        const int M = (GRP ? (int)sh.loff[d1] : (int)sh.loff[NL]) - gb;
         const unsigned tag = Sh::DIRECT ? 0u : (((unsigned)sh.hd.ticks + (unsigned)salt * 0x9E37u) << 16);
         for (int e = t; e < M; e += CAP) {
             const int d = sh.u_list[e];
@@ -1291,18 +1294,19 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
     static PVE_HD void ph_scan(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r)
     {
         ph_scan_init(r);
-        ph_scan_lists(c, t, sh, r, 0, NL);
+        ph_scan_lists<false>(c, t, sh, r, 0, NL);
     }
-    // (HOME: the lists [d0, d1) of this pass; ph_scan_init once in front of the first pass)
+    // (GRP: the lists [d0, d1) of this pass; ph_scan_init once in front of the first pass)
+    template <bool GRP = Sh::HOME>
     static PVE_HD void ph_scan_lists(const PVE_AS4 Const &c, int t, Sh &sh, Regs &r, int d0, int d1)
     {
-        const int gb = Sh::HOME ? (int)sh.loff[d0] : 0;
+        const int gb = GRP ? (int)sh.loff[d0] : 0;
         // thread d < 12: lane d is non-empty -> its list was rebuilt (ref :234); head persisted for next tick's step (ref :1517).
         // The valid bits of the rebuilt lists are combined by two ballots and ONE read-modify-write of the header word: an LDS
         // atomic or / and per lane on that one word is expanded by the compiler's atomic optimizer into a scalar loop over the
         // active lanes (s_ff1 / v_readlane / ... : ~7 instructions x 12 lanes on the first wave's path, every tick)
         const bool rebuilt = t < NL && sh.hd.lane_start[t < NL ? t + 1 : 0] > sh.hd.lane_start[t < NL ? t : 0] &&
-                             (!Sh::HOME || (t >= d0 && t < d1));
+                             (!GRP || (t >= d0 && t < d1));
         bool hvalid = false;
         if (rebuilt) {
             const int base = sh.loff[t] - gb;
@@ -1324,7 +1328,7 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 #endif
         if (!r.dctl) return;
         const int sl = r.ds, lane = r.dlane;
-        if constexpr (Sh::HOME) { if (lane < d0 || lane >= d1) return; }   // (another pass's list)
+        if constexpr (GRP) { if (lane < d0 || lane >= d1) return; }   // (another pass's list)
         const double ps = r.dp;
         const int base = sh.loff[lane] - gb, n = sh.nfin[lane];   // (entries with a finite distance: the sorted list)
         int pr; double pvd;

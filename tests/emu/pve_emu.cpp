@@ -94,11 +94,17 @@ template <int CAP, class ShT = Shared<CAP>> static void emu_rollout(const Const 
                 for (int t = 0; t < CAP; t++) T::ph_build_prep(c, t, sh, regs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_scan_init(regs[t]);
                 int pass = 0;
+                if (sh.loff[NL] <= ShT::POOL) {          // (as the kernel: ONE pass is the ungrouped code)
+                    for (int t = 0; t < CAP; t++) T::template ph_build_fill<false>(c, t, sh, regs[t], 0, NL);
+                    for (int t = 0; t < CAP; t++) T::template ph_rank<false>(t, sh);
+                    for (int t = 0; t < CAP; t++) T::template ph_scan_lists<false>(c, t, sh, regs[t], 0, NL);
+                    pass = 1;
+                } else
                 for (int d0 = 0; d0 < NL; pass++) {
                     const int d1 = T::group_end(sh, d0);
-                    for (int t = 0; t < CAP; t++) T::ph_build_fill(c, t, sh, regs[t], d0, d1);
-                    for (int t = 0; t < CAP; t++) T::ph_rank(t, sh, pass, d0, d1);
-                    for (int t = 0; t < CAP; t++) T::ph_scan_lists(c, t, sh, regs[t], d0, d1);
+                    for (int t = 0; t < CAP; t++) T::template ph_build_fill<true>(c, t, sh, regs[t], d0, d1);
+                    for (int t = 0; t < CAP; t++) T::template ph_rank<true>(t, sh, pass, d0, d1);
+                    for (int t = 0; t < CAP; t++) T::template ph_scan_lists<true>(c, t, sh, regs[t], d0, d1);
                     d0 = d1;
                 }
                 if (pass > g_emu_max_passes) g_emu_max_passes = pass;
