@@ -946,6 +946,25 @@ static std::string hip_err(const char *what, hipError_t e)
     return std::string(what) + ": " + hipGetErrorString(e);
 }
 
+// hipOccupancyMaxActiveBlocksPerMultiprocessor + the LDS allocation granule.  The runtime's answer divides the CU's 160 KB by
+// the block size, but the hardware hands LDS out in 128 granules of 1 280 B per CU (measured, tools/occupancy_probe.hip: ten
+// 128-thread workgroups of 15 360 B start at once, of 15 488 .. 16 384 B only nine although the query says ten; sixteen
+// one-wave workgroups of 10 240 B = 8 granules do).  A persistent grid sized by the query alone would park its surplus
+// workgroups in the dispatcher until the resident ones leave.
+template <typename K> static hipError_t resident_blocks(int *nb, K kernel, int threads)
+{
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, kernel, threads, 0);
+    if (e != hipSuccess) return e;
+    hipFuncAttributes fa;
+    e = hipFuncGetAttributes(&fa, (const void *)kernel);
+    if (e != hipSuccess) return e;
+    if (fa.sharedSizeBytes > 0) {
+        const int granules = (int)((fa.sharedSizeBytes + 1279) / 1280), by_lds = 128 / granules;
+        if (by_lds > 0 && by_lds < *nb) *nb = by_lds;
+    }
+    return hipSuccess;
+}
+
 // Resident workgroups of the persistent roll-out kernels, per DEVICE (a process may hold handles on several GPUs, and they
 // need not be the same part): [device][kernel family (12-lane / general geometry)][capacity 64 / 128] workgroups per CU + the
 // CU count, filled by the first persistent launch on that device.
@@ -1069,8 +1088,8 @@ struct Backend {
 #endif
             // as many workgroups as the chip holds at once (the queue needs no more; fewer when the call has fewer items)
             grid = g_occ.resident(0, cap, [&](int *nb) {
-                return (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout<64, 4, false, false, false, false, true>, 64, 0)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout<128, 4, false, false, false, false, true>, 128, 0); }, err);
+                return (cap == 64) ? resident_blocks(nb, k_rollout<64, 4, false, false, false, false, true>, 64)
+                                   : resident_blocks(nb, k_rollout<128, 4, false, false, false, false, true>, 128); }, err);
             if (grid < 0) return -1;
             const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
             if (const char *g = PVE_KNOB("PVE_PERSISTENT_GRID")) { const long long v = atoll(g); if (v > 0) grid = v; }   // A/B knob
@@ -1094,7 +1113,7 @@ struct Backend {
 #endif
         if (home5) {
             long long g5 = g_occ.resident(3, cap, [&](int *nb) {
-                return hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout<128, 5, false, false, false, true, true>, 128, 0); }, err);
+                return resident_blocks(nb, k_rollout<128, 5, false, false, false, true, true>, 128); }, err);
             if (g5 < 0) return -1;
             const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
             if (const char *g = PVE_KNOB("PVE_PERSISTENT_GRID")) { const long long v = atoll(g); if (v > 0) g5 = v; }   // A/B knob
@@ -1146,10 +1165,10 @@ struct Backend {
             // the persistent form: as many workgroups as the chip holds at once (the variants of one capacity share their register
             // budget; the actor's parameters add 2 KB of LDS: a query of its own)
             long long gq = g_occ.resident(act ? 2 : 1, cap, [&](int *nb) {
-                if (act) return (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<64, true, 4, false, false, true, true>, 64, 0)
-                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<128, true, 4, false, false, true, true>, 128, 0);
-                return (cap == 64) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<64, true, 4, false, false, true>, 64, 0)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k_rollout_geo<128, true, 4, false, false, true>, 128, 0); }, err);
+                if (act) return (cap == 64) ? resident_blocks(nb, k_rollout_geo<64, true, 4, false, false, true, true>, 64)
+                                            : resident_blocks(nb, k_rollout_geo<128, true, 4, false, false, true, true>, 128);
+                return (cap == 64) ? resident_blocks(nb, k_rollout_geo<64, true, 4, false, false, true>, 64)
+                                   : resident_blocks(nb, k_rollout_geo<128, true, 4, false, false, true>, 128); }, err);
             if (gq < 0) return -1;
             const long long items = (long long)P.n_envs * (R.n_full + R.n_taper);
             if (gq > items) gq = items;

@@ -327,7 +327,7 @@ template <int CAP> struct HomesOff {};              // (empty base: the other bl
 struct HomeRegs { double jerk_sum, closer, vir_dis; int id, sv, count; };
 // POOL_: entries of the list pool (HOME: >= 2 CAP + 36 so that the staging overlays fit; the CPU test emulator instantiates a
 // smaller pool than the kernel's 3 CAP to drive ordinary traffic through the multi-pass form)
-template <int CAP, bool LJ = (CAP == 128), bool HOME_ = false, int POOL_ = (HOME_ ? 3 : 5) * CAP>
+template <int CAP, bool LJ = (CAP == 128), bool HOME_ = false, int POOL_ = (HOME_ ? 304 * CAP / 128 : 5 * CAP)>
 struct Shared : std::conditional<HOME_, Homes<CAP>, HomesOff<CAP>>::type {
     static constexpr int NW = CAP / 64;
     static constexpr bool HOME = HOME_;
