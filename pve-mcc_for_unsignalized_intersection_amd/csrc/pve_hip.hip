@@ -454,7 +454,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         lds_barrier();
         PVE_PHASE_MARK(3)
         if constexpr (ShT::HOME) {
-            // the 3 CAP entry pool: BUILD .. WALK in passes over groups of lists that fit it (one pass unless the intersection
+            // the 304-entry pool: BUILD .. WALK in passes over groups of lists that fit it (one pass unless the intersection
             // holds ~100 controlled vehicles; pve_tick_core.h, group_end)
             T::ph_build_prep(c, t, sh, r);
             T::ph_scan_init(r);
@@ -1102,8 +1102,8 @@ struct Backend {
             else hipLaunchKernelGGL((k_rollout<128, 4, true>), dim3(P.n_envs), dim3(128), 0, s, c, P, Rk);
             return check_launch(err);
         }
-        // k_rollout<128, 5, ..>: the HOME build of the persistent kernel (128 slots; table, pool and zero sources) -- 93 / 89 registers
-        // + the 16 368 B block with the carried per-slot fields in LDS homes = 10 workgroups per CU instead of 8, no scratch
+        // k_rollout<128, 5, ..>: the HOME build of the persistent kernel (128 slots; table, pool and zero sources) -- 96 registers
+        // + the 15 264 B block with the carried per-slot fields in LDS homes = 10 workgroups per CU instead of 8, no scratch
         // (pve_tick_core.h: Homes).  Its packed seq_in_lane | id_info[1] word holds arrival cursors < 2^23.  Only the queue form:
         // a plain launch of 4096 workgroups would run as 2560 + 1536.
         const bool home_ok = pers && !act && !train && cap == 128 && P.rows < (1 << 23);

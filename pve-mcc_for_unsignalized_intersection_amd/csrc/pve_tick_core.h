@@ -317,8 +317,10 @@ PVE_HD int mad24(int a, int b, int c)
 // place, the dense thread files closer_p where it belongs, the table source reads the id where it needs it.  vir_dis stays in
 // virdis[], p / v / a in p[] / v[] / a[] (S1 reads them there, and the next action in act_next[], instead of RELOAD handing
 // them over in registers).  When vehicles move, a thread takes its values at the very end of FIN (the registers of the
-// observation row are free again) and puts them at the new slot behind barrier A.  The entry pool shrinks to 3 CAP entries to
-// pay for the homes (the block stays at 16 368 B): BUILD .. WALK run in passes over groups of lists when a tick needs more.
+// observation row are free again) and puts them at the new slot behind barrier A.  The entry pool shrinks to 304 entries to pay
+// for the homes AND to bring the block down to 15 264 B = 12 LDS granules of 1 280 B: ten workgroups per CU are resident only
+// at <= 15 360 B (tools/occupancy_probe.hip; the runtime's occupancy query says ten up to 16 384 B, the hardware starts nine).
+// BUILD .. WALK run in passes over groups of lists when a tick needs more entries than the pool holds.
 template <int CAP> struct Homes {
     double h_jerk_sum[CAP], h_closer[CAP];
     int h_id[CAP], h_sv[CAP], h_count[CAP];          // h_sv = seq_in_lane << 8 | id_info[1] (id_info[1] < CAP <= 128, rows < 2^23)
@@ -326,7 +328,7 @@ template <int CAP> struct Homes {
 template <int CAP> struct HomesOff {};              // (empty base: the other blocks keep their size to the byte)
 struct HomeRegs { double jerk_sum, closer, vir_dis; int id, sv, count; };
 // POOL_: entries of the list pool (HOME: >= 2 CAP + 36 so that the staging overlays fit; the CPU test emulator instantiates a
-// smaller pool than the kernel's 3 CAP to drive ordinary traffic through the multi-pass form)
+// smaller pool than the kernel's 304 entries to drive ordinary traffic through the multi-pass form)
 template <int CAP, bool LJ = (CAP == 128), bool HOME_ = false, int POOL_ = (HOME_ ? 304 * CAP / 128 : 5 * CAP)>
 struct Shared : std::conditional<HOME_, Homes<CAP>, HomesOff<CAP>>::type {
     static constexpr int NW = CAP / 64;
@@ -916,9 +918,9 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
 
     // ============================================================== BUILD: every controlled vehicle files
     // itself into its own lane's list and into the lists of the lanes it conflicts with (ref :240-270)
-    // HOME (entry pool of 3 CAP entries): the lists of a tick are worked in GROUPS of consecutive lists [d0, d1) that fit the
+    // HOME (entry pool of 304 entries): the lists of a tick are worked in GROUPS of consecutive lists [d0, d1) that fit the
     // pool -- BUILD files, RANK sorts and WALK reads one group per pass, entry indices relative to the group's first list.  One
-    // group is the rule (loff[NL] = own + conflict entries of every controlled vehicle <= 5 per vehicle; 3 CAP holds ~100
+    // group is the rule (loff[NL] = own + conflict entries of every controlled vehicle <= 5 per vehicle; 304 hold ~80
     // controlled vehicles); a single list never exceeds CAP entries, so every group makes progress.  Uniform.
     static PVE_HD int group_end(const Sh &sh, int d0)
     {

@@ -51,7 +51,7 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
 // k_base: first tick of this launch / queue item within the call's output blocks (0 for a chunked launch, whose Params are
 // shifted to its first block already; the item's first tick for the sequentially emulated work queue)
 // ShT: Shared<CAP> (the default block), or the HOME block of k_rollout<128, 5, ..> (carried fields in LDS homes, entry pool of
-// 3 CAP entries worked in passes; PVE_EMU_HOME=1) -- PVE_EMU_HOME=2 takes a still smaller pool so that ordinary traffic runs
+// 304 entries worked in passes; PVE_EMU_HOME=1) -- PVE_EMU_HOME=2 takes a still smaller pool so that ordinary traffic runs
 // through the multi-pass form
 static int g_emu_max_passes = 0, g_emu_max_entries = 0; // (diagnostics of the tests: the most passes / list entries a tick has taken)
 extern "C" int pve_emu_max_passes(void) { const int v = g_emu_max_passes; g_emu_max_passes = 0; return v; }
@@ -336,7 +336,7 @@ struct Backend {
     {
         if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2) return 1;
         // PVE_EMU_HOME (tests): the HOME block of k_rollout<128, 5, ..> for every 128-slot roll-out without training outputs
-        // (1 = the kernel's pool of 3 CAP entries, 2 = a pool of 296 entries: ordinary traffic takes several passes)
+        // (1 = the kernel's pool of 304 entries, 2 = a pool of 296 entries, the smallest the staging overlays admit)
         const char *hm = getenv("PVE_EMU_HOME");
         const int home = (hm && cap == 128 && !P_in.out.obs_pre && !P_in.out.state_pre) ? atoi(hm) : 0;
         const int rc = run_launch(c, P_in, R, cap, [&](const Const &cc, const Params &P, const RolloutArgs &Rk, int kb) {

@@ -1,5 +1,5 @@
 """-m gpu: the HOME build of the persistent 128-slot kernel (k_rollout<128, 5, ..>: carried per-slot fields in LDS homes, entry
-pool of 3 CAP entries worked in passes, 10 workgroups per CU) through the C ABI -- == single ticks of k_tick bit for bit, which
+pool of 304 entries worked in passes, 10 workgroups per CU) through the C ABI -- == single ticks of k_tick bit for bit, which
 the parity suite holds to the oracle; the CPU twin (tests/test_home_block_emulated.py) runs the same phase bodies on the emulator
 and counts the passes.  Also the table source's LATE spawn-action gather (a full intersection: who spawns is known in FIN only;
 ADVICE r5) on both kernel builds."""
@@ -18,7 +18,7 @@ def test_gpu_home_kernel_equals_single_ticks(source):
 
 def test_gpu_home_kernel_full_intersection_multi_pass_and_late_spawn_gather():
     """3000 veh/h/lane, vm = 3 m/s, braking, (almost) no collisions: 128 slots fill up with controlled vehicles -> more than
-    3 CAP list entries (several BUILD .. WALK passes: asserted on the emulator with the same streams' twin) and deferred spawns
+    304 list entries (several BUILD .. WALK passes: asserted on the emulator with the same streams' twin) and deferred spawns
     (overflow > 0: the table source gathers the spawned vehicle's first action behind FIN)."""
     st = scenarios.check_step_many(BACKEND, "table", n_envs=6, chunks=(250, 40, 7, 60), trajectory_chunk=10, seed=191, rate=3000.0,
                                    cfg=dict(vm=3.0, collision_thr=0.01), act_lo=-3.0, act_hi=-2.0, persistent=True)

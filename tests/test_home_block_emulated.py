@@ -1,8 +1,8 @@
 """CPU parity of the HOME block of k_rollout<128, 5, ..> (csrc/pve_tick_core.h: Shared<128, false, true>): the 96-register /
 10-workgroups-per-CU build of the resident kernel keeps the carried per-slot fields (jerk_sum, closer_p, id, seq | vnum,
 count, vir_dis, p / v / a, the next action) in LDS instead of registers and works the virtual-lane lists in passes over an
-entry pool of 3 CAP entries.  The emulator (tests/emu) runs the same phase bodies with that block when PVE_EMU_HOME is set
-(1 = the kernel's pool, 2 = a pool of 296 entries so that ordinary traffic takes several passes) -- every roll-out must still
+entry pool of 304 entries.  The emulator (tests/emu) runs the same phase bodies with that block when PVE_EMU_HOME is set
+(1 = the kernel's pool of 304 entries, 2 = 296) -- every roll-out must still
 equal single ticks of k_tick bit for bit (ref traffic_interaction_scene.py:1501-1539, :222-376, :435-444)."""
 import ctypes as C
 
@@ -47,14 +47,14 @@ def test_home_block_through_the_work_queue(monkeypatch, mode, source):
 
 def test_home_block_full_intersection_takes_several_passes_of_the_kernel_pool(monkeypatch):
     """3000 veh/h/lane, vm = 3 m/s, full braking and (almost) no collisions: the 128 slots fill up with controlled vehicles
-    and the lists need more than 3 CAP entries -- the multi-pass form with the pool size the HIP kernel has (and deferred
+    and the lists need more than 304 entries -- the multi-pass form with the pool size the HIP kernel has (and deferred
     spawns / a full intersection on the table source's late spawn-action gather)."""
     monkeypatch.setenv("PVE_EMU_HOME", "1")
     _passes()
     st = scenarios.check_step_many(BACKEND, "table", n_envs=2, chunks=(250, 40, 7, 60), trajectory_chunk=10, seed=191, rate=3000.0,
                                    cfg=dict(vm=3.0, collision_thr=0.01), act_lo=-3.0, act_hi=-2.0)
     assert st["max_alive"] >= 120 and st["overflow"] > 0, st
-    assert _passes() >= 2, "a full intersection must overflow the 3 CAP entry pool"
+    assert _passes() >= 2, "a full intersection must overflow the 304-entry pool"
 
 
 def test_home_block_symmetric_lanes_equal_distances(monkeypatch):
