@@ -117,7 +117,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(CAP == 64 ?
     if (P.out.state_pre) {            // uniform branch: optional training output
         __threadfence_block();
         __syncthreads();
-        T::ph_state(P, env, t, sh, r);
+        T::ph_state_publish(P.out, t, sh, r);
+        __syncthreads();
+        T::ph_state_coop(P, P.out, env, t, sh);
         PVE_PHASE_MARK(10)
     }
     if (P.phase_cycles && (t & 63) == 0) {
@@ -538,7 +540,13 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             lds_barrier();                            // A: nobody reads the tick's work arrays any more
             // (uniform; barrier A also orders the obs_pre rows of this tick.  PERS: the stale rows of an item's first tick are what
             //  ANOTHER workgroup's item stored -- block k - 1 of the trajectory --: coherent loads)
-            if (TRAIN && O.state_pre) T::template ph_state<PERS>(P, O, env, t, sh, r);
+            if constexpr (TRAIN) {
+                if (O.state_pre) {                       // (uniform) the 7 x 28 states: descriptors, barrier, cooperative write
+                    T::ph_state_publish(O, t, sh, r);
+                    lds_barrier();
+                    T::template ph_state_coop<PERS>(P, O, env, t, sh);
+                }
+            }
             T::ph_stage(c, t, sh, r, fc);
             T::ph_home_put(t, sh, fc, hr);
             if constexpr (IDT) { if (fc.sp_slot >= 0) sh.act_next[fc.sp_slot] = sp_act; }
@@ -1106,6 +1114,8 @@ struct Backend {
         // + the 15 264 B block with the carried per-slot fields in LDS homes = 10 workgroups per CU instead of 8, no scratch
         // (pve_tick_core.h: Homes).  Its packed seq_in_lane | id_info[1] word holds arrival cursors < 2^23.  Only the queue form:
         // a plain launch of 4096 workgroups would run as 2560 + 1536.
+        // (The training outputs through this block -- k_rollout<128, 5, .., TRAIN, .., PERS>: 94-96 registers -- were measured: 137-141
+        //  against 129-131 us per tick; the trainer's roll-out keeps the register build.)
         const bool home_ok = pers && !act && !train && cap == 128 && P.rows < (1 << 23);
         bool home5 = PVE_HOME_DEFAULT != 0 && home_ok;
 #ifdef PVE_AB_KNOBS

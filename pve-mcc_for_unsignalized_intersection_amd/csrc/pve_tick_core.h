@@ -181,6 +181,50 @@ template <bool COH, class T> PVE_HD T gld(const T *p)
     return *p;
 #endif
 }
+// The 7 x 28 state of one vehicle (ref :1325-1337): seven observation rows (28 values: 112 B as float32, 224 B as float64; rows are
+// 16-byte aligned) gathered from srcs[0..6] (nullptr = an absent neighbour: zeros) into dst, in chunks of 112 bytes = 7 pieces of
+// 16 bytes: the 7 loads of a chunk go out back to back, then its 7 stores.  (An element-wise `dst[k] = src[k]` loop is one full
+// memory round trip per element -- the compiler cannot exclude that dst aliases src --, 196 of them per state: 305 us per tick of
+// 4096 x 128 with the training outputs against 129 us in this form.  A two-deep pipeline -- the loads of chunk c + 1 in front of
+// the stores of chunk c -- measured 126 us but costs 28 more registers: 8-15 spilled in the closed-loop and 8-lane trainer variants.)
+// coh bit q: row q may have been stored by ANOTHER workgroup of this launch (cf. gld): agent-scope coherent loads (`sc1`, served
+// by the L2) as ONE asm statement that ends with the wait for its own loads (the compiler does not track loads issued by asm).
+template <class ROW> PVE_HD void gather_state(const ROW *const (&srcs)[NNB + 1], unsigned coh, ROW *dst)
+{
+#if PVE_DEVICE_CODE
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int CPR = (int)sizeof(ROW) * OBSW / 112;     // chunks per row: 1 (float32) or 2 (float64)
+    constexpr int NC = (NNB + 1) * CPR;
+    v4f buf[7];
+    auto fetch = [&](int c, v4f (&q)[7]) {
+        const ROW *row = srcs[c / CPR];
+        const char *sp = (const char *)row + 112 * (c % CPR);
+        if (!row) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) q[i] = v4f{0.f, 0.f, 0.f, 0.f};
+        } else if ((coh >> (c / CPR)) & 1u) {
+            asm volatile("global_load_dwordx4 %0, %7, off sc1\n\tglobal_load_dwordx4 %1, %7, off offset:16 sc1\n\t"
+                         "global_load_dwordx4 %2, %7, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %7, off offset:48 sc1\n\t"
+                         "global_load_dwordx4 %4, %7, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %7, off offset:80 sc1\n\t"
+                         "global_load_dwordx4 %6, %7, off offset:96 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]) : "v"(sp) : "memory");
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; i++) q[i] = ((const v4f *)sp)[i];
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        fetch(c, buf);
+        v4f *d4 = (v4f *)((char *)dst + 112 * c);
+#pragma unroll
+        for (int i = 0; i < 7; i++) d4[i] = buf[i];
+    }
+#else
+    for (int q = 0; q <= NNB; q++)
+        for (int k = 0; k < OBSW; k++) dst[q * OBSW + k] = srcs[q] ? srcs[q][k] : (ROW)0;
+#endif
+}
 // sorted position -> entry: the low half of a tagged word (Shared<128>, see ph_rank) or a plain 16-bit index (SharedGeo)
 template <class W> PVE_HD int sidx_at(const W *s, int i)
 {
@@ -2092,20 +2136,17 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         const int sl = r.ds;
         ROW *dst = (ROW *)O.state_pre + (base + sl) * (size_t)((NNB + 1) * OBSW);
         const ROW *pre = (const ROW *)O.obs_pre, *prev = (const ROW *)O.obs_prev_post;
-        const ROW *own = pre + (base + sl) * OBSW;
-        for (int k = 0; k < OBSW; k++) dst[k] = own[k];
+        const ROW *srcs[NNB + 1];
+        unsigned coh = 0;
+        srcs[0] = pre + (base + sl) * OBSW;
+#pragma unroll
         for (int q = 0; q < NNB; q++) {
             const int x = r.kr[q];
-            ROW *row = dst + (q + 1) * OBSW;
-            if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = (ROW)0; continue; }
-            if (COH && !(x < sl)) {
-                const ROW *src = prev + (base + x) * OBSW;
-                for (int k = 0; k < OBSW; k++) row[k] = gld<true>(src + k);
-                continue;
-            }
-            const ROW *src = (x < sl) ? (pre + (base + x) * OBSW) : (prev + (base + x) * OBSW);
-            for (int k = 0; k < OBSW; k++) row[k] = src[k];
+            const bool fresh = x < sl;                    // the neighbour precedes us in order: its row of THIS tick (ref :1332)
+            srcs[q + 1] = x < 0 ? (const ROW *)nullptr : ((fresh ? pre : prev) + (base + x) * OBSW);
+            if (COH && x >= 0 && !fresh) coh |= 2u << q;
         }
+        gather_state<ROW>(srcs, coh, dst);
     }
     template <bool COH = false, class OutT>
     static PVE_HD void ph_state(const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh, Regs &r)
@@ -2115,6 +2156,93 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         else state_rows<double, COH>(O, (size_t)env * CAP, r);
     }
     static PVE_HD void ph_state(const PVE_AS4 Params &P, int env, int t, Sh &sh, Regs &r) { ph_state(P, P.out, env, t, sh, r); }
+
+    // ---- the same states written COOPERATIVELY (round 6; the dense-mapping kernels): a vehicle's state is 7 x 112 B (float32) or
+    // 7 x 224 B (float64) of CONTIGUOUS output -- one wave instruction (two for float64 rows) writes all of it, lane g its 16-byte
+    // piece g, instead of every dense thread writing its own state in 49 / 98 pieces 784 / 1 568 B apart from its neighbour lanes'
+    // (the L2 had to merge them into lines).  PUBLISH: dense thread d files where its 7 rows come from -- 8 bytes in the vehicle's
+    // dead virdis[] cell pair: byte q = source slot | fresh << 7 (fresh: the row of THIS tick, obs_pre; else the one stored last
+    // tick, ref :1332; an absent neighbour names the vehicle's own slot, which is never its own neighbour), byte 7 = its slot;
+    // COOP (behind a barrier): the waves deal the vehicles among themselves, U at a time, loads back to back, then the stores.
+    template <class OutT>
+    static PVE_HD void ph_state_publish(const OutT &O, int t, Sh &sh, const Regs &r)
+    {
+        static_assert(!Sh::HOME, "the HOME block keeps vir_dis in virdis[]: no training outputs through it");
+        if (!O.state_pre || !r.dctl) return;
+        uint8_t *desc = (uint8_t *)sh.virdis + 8 * t;
+        const int sl = r.ds;
+        desc[0] = (uint8_t)(sl | 128);
+#pragma unroll
+        for (int q = 0; q < NNB; q++) {
+            const int x = r.kr[q];
+            desc[q + 1] = (uint8_t)(x < 0 ? sl : (x | (x < sl ? 128 : 0)));
+        }
+        desc[7] = (uint8_t)sl;
+    }
+    template <class ROW, bool COH, class OutT>
+    static PVE_HD void state_coop(const OutT &O, size_t base, int t, Sh &sh)
+    {
+        constexpr int RB = (int)sizeof(ROW) * OBSW, PPR = RB / 16, PPV = 7 * PPR, NP = (PPV + 48) / 49;   // 112 / 224 B, 7 / 14, 49 / 98, 1 / 2
+        const int lane = t & 63, w = t >> 6;
+        const int n = mask_count<NW>(sh.m_ctl);
+        const uint8_t *desc = (const uint8_t *)sh.virdis;
+        const char *pre = (const char *)O.obs_pre + base * RB, *prev = (const char *)O.obs_prev_post + base * RB;
+        char *dstb = (char *)O.state_pre + base * (size_t)(7 * RB);
+#if PVE_DEVICE_CODE
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        constexpr int U = 4;                              // vehicles per batch and wave
+        if (lane >= 49) return;
+        for (int d0 = w; d0 < n; d0 += NW * U) {
+            v4f q[U][NP]; unsigned off[U][NP]; bool zero[U][NP];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int d = d0 + u * NW, dc = d < n ? d : w;       // (clamped: every lane of the batch issues its loads)
+                const int sl = desc[8 * dc + 7];
+#pragma unroll
+                for (int h = 0; h < NP; h++) {
+                    const int g = lane + 49 * h, qq = g / PPR, i = g - qq * PPR;
+                    const int b = desc[8 * dc + qq];
+                    zero[u][h] = qq > 0 && (b & 127) == sl;
+                    const char *src = ((b & 128) ? pre : prev) + (unsigned)((b & 127) * RB + 16 * i);
+                    off[u][h] = (unsigned)(sl * 7 * RB + 16 * g);
+                    if constexpr (COH) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(q[u][h]) : "v"(src) : "memory");
+                    else q[u][h] = *(const v4f *)src;
+                }
+            }
+            if constexpr (COH) {                          // (the asm loads above: the compiler does not count them)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int h = 0; h < NP; h++) asm volatile("" : "+v"(q[u][h]));
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (d0 + u * NW >= n) break;
+#pragma unroll
+                for (int h = 0; h < NP; h++) *(v4f *)(dstb + off[u][h]) = zero[u][h] ? v4f{0.f, 0.f, 0.f, 0.f} : q[u][h];
+            }
+        }
+#else
+        if (lane >= 49) return;
+        for (int d = w; d < n; d += NW) {
+            const int sl = desc[8 * d + 7];
+            for (int g = lane; g < PPV; g += 49) {
+                const int qq = g / PPR, i = g - qq * PPR, b = desc[8 * d + qq];
+                char *dp = dstb + (size_t)sl * 7 * RB + 16 * g;
+                if (qq > 0 && (b & 127) == sl) memset(dp, 0, 16);
+                else memcpy(dp, ((b & 128) ? pre : prev) + (size_t)(b & 127) * RB + 16 * i, 16);
+            }
+        }
+#endif
+    }
+    template <bool COH = false, class OutT>
+    static PVE_HD void ph_state_coop(const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh)
+    {
+        if (!O.state_pre) return;
+        if (P.obs_f32) state_coop<float, COH>(O, (size_t)env * CAP, t, sh);
+        else state_coop<double, COH>(O, (size_t)env * CAP, t, sh);
+    }
 
     // ============================================================== COMPACT (delete_vehicle only)
     static PVE_HD void ph_c_load(const PVE_AS4 Params &P, int env, int t, Sh &sh, CRegs &r)

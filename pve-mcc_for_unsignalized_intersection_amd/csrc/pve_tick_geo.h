@@ -1146,21 +1146,17 @@ template <int CAP> struct TickGeo {
     {
         ROW *dst = (ROW *)O.state_pre + (base + t) * (size_t)((NNB + 1) * OBSW);
         const ROW *pre = (const ROW *)O.obs_pre, *prev = (const ROW *)O.obs_prev_post;
-        const ROW *own = pre + (base + t) * OBSW;
-        for (int k = 0; k < OBSW; k++) dst[k] = own[k];
+        const ROW *srcs[NNB + 1];
+        unsigned coh = 0;
+        srcs[0] = pre + (base + t) * OBSW;
+#pragma unroll
         for (int q = 0; q < NNB; q++) {
             const int x = r.kr[q];
-            ROW *row = dst + (q + 1) * OBSW;
-            if (x < 0) { for (int k = 0; k < OBSW; k++) row[k] = (ROW)0; continue; }
             const bool fresh = (r.mmask >> q) & 1;
-            if (COH && !fresh) {
-                const ROW *src = prev + (base + x) * OBSW;
-                for (int k = 0; k < OBSW; k++) row[k] = gld<true>(src + k);
-                continue;
-            }
-            const ROW *src = fresh ? (pre + (base + x) * OBSW) : (prev + (base + x) * OBSW);
-            for (int k = 0; k < OBSW; k++) row[k] = src[k];
+            srcs[q + 1] = x < 0 ? (const ROW *)nullptr : ((fresh ? pre : prev) + (base + x) * OBSW);
+            if (COH && x >= 0 && !fresh) coh |= 2u << q;
         }
+        gather_state<ROW>(srcs, coh, dst);
     }
     template <bool COH = false, class OutT>
     static PVE_HD void ph_state(const PVE_AS4 Params &P, const OutT &O, int env, int t, Sh &sh, Regs &r)

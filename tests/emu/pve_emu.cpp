@@ -41,8 +41,10 @@ template <int CAP> static void emu_tick(const Const &c, const Params &P)
         for (int t = 0; t < CAP; t++) T::ph_lock(c, t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_lock2(t, sh, regs[t]);
         for (int t = 0; t < CAP; t++) T::ph_final(c, P, env, t, sh, regs[t]);
-        if (P.out.state_pre)
-            for (int t = 0; t < CAP; t++) T::ph_state(P, env, t, sh, regs[t]);
+        if (P.out.state_pre) {                       // (the 7 x 28 states: descriptors, barrier, cooperative write)
+            for (int t = 0; t < CAP; t++) T::ph_state_publish(P.out, t, sh, regs[t]);
+            for (int t = 0; t < CAP; t++) T::ph_state_coop(P, P.out, env, t, sh);
+        }
     }
     delete shp;
 }
@@ -145,7 +147,12 @@ template <int CAP, class ShT = Shared<CAP>> static void emu_rollout(const Const 
                 for (int t = 0; t < CAP; t++) T::ph_stage_header(t, sh, fcs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_carry_over(t, sh, regs[t], fcs[t]);
             } else {
-                if (O.state_pre) for (int t = 0; t < CAP; t++) T::ph_state(P, O, env, t, sh, regs[t]);
+                if (O.state_pre) {
+                    if constexpr (!ShT::HOME) {
+                        for (int t = 0; t < CAP; t++) T::ph_state_publish(O, t, sh, regs[t]);
+                        for (int t = 0; t < CAP; t++) T::ph_state_coop(P, O, env, t, sh);
+                    }
+                }
                 for (int t = 0; t < CAP; t++) T::ph_stage(c, t, sh, regs[t], fcs[t]);
                 for (int t = 0; t < CAP; t++) T::ph_home_put(t, sh, fcs[t], hrs[t]);
                 if (idt) for (int t = 0; t < NL; t++) if (fcs[t].sp_slot >= 0) sh.act_next[fcs[t].sp_slot] = sp_act[t];

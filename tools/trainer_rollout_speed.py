@@ -1,0 +1,19 @@
+"""Diagnostics: the trainer's roll-out through the work queue (obs_pre + state_pre of every tick into trajectory blocks, float32
+rows): us per tick of 4096 x 128 intersections.  python tools/trainer_rollout_speed.py [label]"""
+import sys, time, torch, numpy as np
+sys.path.insert(0, '/root/repo')
+import bench, pve_mcc_amd
+from pve_mcc_amd.arrivals import synthetic_arrivals
+n, cap, K = 4096, 128, 20
+arr = synthetic_arrivals(n, rate=1100.0, horizon_s=200.0, seed=20250213)
+env = pve_mcc_amd.BatchedIntersections(n, cap, arr, device="cuda:0", outputs=("obs_post", "obs_pre", "state_pre", "reward", "flags", "env_out"), obs_dtype=torch.float32)
+env.reset(); env.set_action_pool(torch.as_tensor(bench.action_pool(n, cap, 99), device="cuda:0"))
+ring = [env.alloc_trajectory(K) for _ in range(2)]
+for rep in range(15):                                 # prefill to steady state (state_pre needs trajectory roll-outs)
+    env.step_many(K, trajectory=ring[rep & 1], chunk=10, persistent=True)
+ts = []
+for rep in range(8):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    env.step_many(K, trajectory=ring[rep & 1], chunk=10, persistent=True)
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / K * 1e6)
+print("trainer roll-out (state_pre, f32 rows, %s): %.2f us per tick (median of 8), launch %s" % (sys.argv[1] if len(sys.argv) > 1 else "", np.median(ts), env.last_launch()))
