@@ -330,7 +330,9 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // the first wave carries the dense-mapped phases (the critical chain of the workgroup), the second one mostly waits at
     // the barriers: the first wave gets the issue slots first (30.0 -> 29.6 us per tick; not in k_tick, where the closed
     // loop's actor kernel shares the chip and loses more than the tick gains)
-    if (CAP > 64 && __builtin_amdgcn_readfirstlane(t0_) < 64) __builtin_amdgcn_s_setprio(3);
+    // (round 6, the HOME build with its 5 waves per SIMD: the second wave at 2 instead of 0 -- whatever it runs is what the first wave
+    //  waits for at the next barrier: 22.83 vs 22.95 us steady; 3 / 3 and 2 / 3 are worse: 23.1 / 23.45)
+    if (CAP > 64) { if (__builtin_amdgcn_readfirstlane(t0_) < 64) __builtin_amdgcn_s_setprio(3); else if (WPE == 5) __builtin_amdgcn_s_setprio(2); }
     KernargPtr kav_ = ka0_;
     Regs r;
     FinCarry fc;
