@@ -71,3 +71,23 @@ def test_home_block_driver_shape_vs_oracle(monkeypatch):
     m, _ = scenarios.check_driver_shape_vs_oracle(BACKEND, n_envs=6, n_sub=1, n_sample=6, calls=(30, 30, 5, 20), chunk=12, persistent=True,
                                                   table=True)
     assert m["ctl_steps"] > 0
+
+
+def test_home_block_items_of_one_and_two_ticks(monkeypatch):
+    """every tick is an item's LAST tick (the jerks park in the free act_next[] cells, the state is flushed and re-loaded per item)"""
+    import numpy as np
+    import torch
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    from tests.hip_adapter import make_batch
+    monkeypatch.setenv("PVE_EMU_HOME", "1")
+    arr = synthetic_arrivals(3, rate=1300.0, horizon_s=60.0, seed=5)
+    one, many = (make_batch(arr, 3, 128, BACKEND, outputs=("obs_post", "reward", "flags", "env_out")) for _ in range(2))
+    one.reset(); many.reset()
+    table = torch.as_tensor(np.random.default_rng(5).uniform(-3, 3, size=(17, 120)))
+    one.set_action_table(table); many.set_action_table(table)
+    for n, ch in ((150, 25), (7, 1), (9, 2), (5, 1), (40, 3)):
+        for _ in range(n):
+            one.step(one.actions_from_table())
+        many.step_many(n, source="table", chunk=ch, persistent=True)
+        assert many.last_launch() == "persistent"
+        scenarios.batches_equal(one, many, "items of <= %d ticks" % ch)
