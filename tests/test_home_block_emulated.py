@@ -91,3 +91,24 @@ def test_home_block_items_of_one_and_two_ticks(monkeypatch):
         many.step_many(n, source="table", chunk=ch, persistent=True)
         assert many.last_launch() == "persistent"
         scenarios.batches_equal(one, many, "items of <= %d ticks" % ch)
+
+
+def test_home_block_float32_observation_rows(monkeypatch):
+    """PVE_CFG_OBS_F32 through the HOME block: rows, state and headers == single ticks, bit for bit"""
+    import numpy as np
+    import torch
+    from pve_mcc_amd.arrivals import synthetic_arrivals
+    from tests.hip_adapter import make_batch
+    monkeypatch.setenv("PVE_EMU_HOME", "1")
+    arr = synthetic_arrivals(4, rate=1200.0, horizon_s=50.0, seed=6)
+    one, many = (make_batch(arr, 4, 128, BACKEND, outputs=("obs_post", "reward", "flags", "env_out"), obs_dtype=torch.float32)
+                 for _ in range(2))
+    one.reset(); many.reset()
+    pool = torch.as_tensor(np.random.default_rng(6).uniform(-3, 3, size=(5, 4, 128)))
+    many.set_action_pool(pool)
+    for n, ch in ((120, 25), (33, 7), (50, 12)):
+        for _ in range(n):
+            one.step(pool[one.ticks % 5])
+        many.step_many(n, source="pool", chunk=ch, persistent=True)
+        assert many.last_launch() == "persistent" and many.obs.dtype == torch.float32
+        scenarios.batches_equal(one, many, "float32 rows, items of <= %d ticks" % ch)

@@ -4,9 +4,15 @@ import sys, time, torch, numpy as np
 sys.path.insert(0, '/root/repo')
 import bench, pve_mcc_amd
 from pve_mcc_amd.arrivals import synthetic_arrivals
+import os
 n, cap, K = 4096, 128, 20
-arr = synthetic_arrivals(n, rate=1100.0, horizon_s=200.0, seed=20250213)
-env = pve_mcc_amd.BatchedIntersections(n, cap, arr, device="cuda:0", outputs=("obs_post", "obs_pre", "state_pre", "reward", "flags", "env_out"), obs_dtype=torch.float32)
+LN = int(os.environ.get("LANE_NUM", "12"))            # LANE_NUM=4 / 8: k_rollout_geo<.., TRAIN[, PERS]>
+rate = {12: 1100.0, 8: 1500.0, 4: 1800.0}[LN]
+arr = synthetic_arrivals(n, rate=rate, horizon_s=200.0, seed=20250213, lane_num=LN)
+from pve_mcc_amd.arrivals import synthetic_intentions
+ch = synthetic_intentions(n, arr.shape[1], seed=20250213) if LN == 8 else None
+env = pve_mcc_amd.BatchedIntersections(n, cap, arr, device="cuda:0", outputs=("obs_post", "obs_pre", "state_pre", "reward", "flags", "env_out"), obs_dtype=torch.float32,
+                                       lane_num=LN, intentions=ch)
 env.reset(); env.set_action_pool(torch.as_tensor(bench.action_pool(n, cap, 99), device="cuda:0"))
 ring = [env.alloc_trajectory(K) for _ in range(2)]
 for rep in range(15):                                 # prefill to steady state (state_pre needs trajectory roll-outs)
@@ -16,4 +22,4 @@ for rep in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     env.step_many(K, trajectory=ring[rep & 1], chunk=10, persistent=True)
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / K * 1e6)
-print("trainer roll-out (state_pre, f32 rows, %s): %.2f us per tick (median of 8), launch %s" % (sys.argv[1] if len(sys.argv) > 1 else "", np.median(ts), env.last_launch()))
+print("trainer roll-out (%d lanes, state_pre, f32 rows, %s): %.2f us per tick (median of 8), launch %s" % (LN, sys.argv[1] if len(sys.argv) > 1 else "", np.median(ts), env.last_launch()))
