@@ -358,7 +358,6 @@ struct Backend {
     {
         const bool train = P_in.out.obs_pre || P_in.out.state_pre;
         if (getenv("PVE_NO_ROLLOUT_KERNEL") || R.source == 2 || (train && R.source == 3)) return 1;
-        if (R.queue && train && g.lane_num == 4) return 1;                    // (as the HIP backend: the 4-lane trainer roll-out stays chunked)
         const int rc = run_launch(g, P_in, R, cap, [&](const GeoConst &gg, const Params &P, const RolloutArgs &Rk, int kb) {
             if (cap == 64) emu_rollout_geo<64>(gg, P, Rk, kb); else emu_rollout_geo<128>(gg, P, Rk, kb); });
         if (rc < 0) err = "emulated work queue: inconsistent item schedule";

@@ -119,10 +119,12 @@ def test_geo_work_queue_table_source_emulated(lane_num, cap):
 
 
 def test_geo_work_queue_training_outputs_emulated():
-    """The trainer's roll-out of the 8-lane layout through the work queue (k_rollout_geo<.., TRAIN, PERS>; the 4-lane layout
-    keeps chunked launches): obs_pre / state_pre / 7-action vectors of every tick against the oracle."""
+    """The trainer's roll-out of the 4- / 8-lane layouts through the work queue (k_rollout_geo<.., TRAIN, PERS>; the 4-lane
+    variant: round 6): obs_pre / state_pre / 7-action vectors of every tick against the oracle."""
     scenarios.check_step_many_state_rows(BACKEND, n_envs=3, capacity=64, calls=(25, 12, 30), chunk=7, lane_num=8, persistent=True,
                                          obs_dtype=torch.float32, min_ctl_per_tick=1)
     scenarios.check_step_many_state_rows(BACKEND, n_envs=2, capacity=128, calls=(20, 9), chunk=6, lane_num=4, persistent=True,
                                          min_ctl_per_tick=1)
+    scenarios.check_step_many_state_rows(BACKEND, n_envs=3, capacity=64, calls=(25, 12, 30), chunk=7, lane_num=4, persistent=True,
+                                         obs_dtype=torch.float32, min_ctl_per_tick=1)
 
