@@ -52,7 +52,8 @@ print("%d runs: %d green, %d ended at a deferred spawn, 0 differences" % (a.runs
 # pve_step_many (k_rollout: still ticks, staged ticks, chunked launches, trajectory outputs) == single ticks, bit for bit
 for k in range(a.many):
     kind = str(rng.choice(["k_rollout", "k_rollout", "actor", "geo", "geo", "state", "persistent", "persistent", "geo_state", "geo_table",
-                           "state_pers", "state_pers", "closed_state", "closed_geo", "closed_geo", "home", "home", "home"]))
+                           "state_pers", "state_pers", "closed_state", "closed_geo", "closed_geo", "home", "home", "home",
+                           "closed_geo_state", "closed_geo_state", "geo_state"]))
     seed = int(rng.integers(1, 1 << 30))
     t0 = time.time()
     if kind in ("k_rollout", "actor"):
@@ -126,6 +127,18 @@ for k in range(a.many):
                                             capacity=cap, chunks=chunks, rate=rate, trajectory_chunk=int(rng.integers(2, 20)), seed=seed,
                                             obs_dtype=torch.float32 if rng.random() < 0.5 else torch.float64, persistent=pers, strict=False)
         what = "%d lanes cap %3d rate %6.0f closed loop chunks %s persistent %s" % (ln, cap, rate, chunks, pers)
+    elif kind == "closed_geo_state":                            # round 6: closed loop + training outputs for 4 / 8 lanes (k_rollout_geo<.., TRAIN, .., ACT>)
+        import torch
+        ln = int(rng.choice([4, 8]))
+        cap = int(rng.choice([64, 128]))
+        lo, hi = RATES[(ln, cap)]
+        rate = float(rng.uniform(lo, hi * 0.7))
+        calls = tuple(int(x) for x in rng.integers(5, 50, size=int(rng.integers(2, 4))))
+        pers = bool(rng.random() < 0.4)
+        scenarios.check_closed_loop_state_rows(a.backend, n_envs=int(rng.choice([4, 30])), capacity=cap, rate=rate, calls=calls,
+                                               chunk=int(rng.choice([0, 3, 7, 16])), seed=seed, persistent=pers, lane_num=ln,
+                                               want_launch=("resident",), obs_dtype=torch.float32 if rng.random() < 0.5 else torch.float64)
+        what = "%d lanes cap %3d closed-loop state rows calls %s rate %6.0f persistent %s" % (ln, cap, calls, rate, pers)
     elif kind in ("geo_state", "geo_table"):                    # f3 x f4 (round 4): training outputs / id-indexed table for 4 / 8 lanes
         import torch
         ln = int(rng.choice([4, 8]))
@@ -135,7 +148,7 @@ for k in range(a.many):
         if kind == "geo_state":
             dt = torch.float32 if rng.random() < 0.5 else torch.float64
             calls = tuple(int(x) for x in rng.integers(5, 60, size=int(rng.integers(2, 5))))
-            pers = bool(rng.random() < 0.5)                     # (round 5: 8 lanes through the work queue; 4 lanes stay chunked)
+            pers = bool(rng.random() < 0.5)                     # (8 lanes through the work queue: round 5; 4 lanes: round 6)
             scenarios.check_step_many_state_rows(a.backend, n_envs=int(rng.choice([2, 5, 30])) if pers else int(rng.choice([2, 5])),
                                                  capacity=cap, calls=calls, rate=rate, seed=seed, obs_dtype=dt,
                                                  chunk=int(rng.choice([3, 7, 16])) if pers else int(rng.choice([0, 7, 16])), lane_num=ln,
