@@ -642,10 +642,10 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu((CAP == 64 
         lds_barrier();
     }
     T::ph_pairs_fill(g, t, sh);
-    if (FIX4) T::ph_fix_table(g, t, sh, r);
     lds_barrier();
     PVE_PHASE_MARK(4)
     T::ph_load_late(P, env, t, sh, r);
+    if (FIX4) T::ph_fix_table(g, t, sh, r);      // (behind FILL: its rows are the back entries' indices)
     T::ph_rank(t, sh, env);
     lds_barrier();
     PVE_PHASE_MARK(5)
@@ -813,8 +813,8 @@ __global__ __launch_bounds__(CAP) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             lds_barrier();
         }
         T::ph_pairs_fill(g, t, sh);
-        if (FIX4) T::ph_fix_table(g, t, sh, r);
         lds_barrier();
+        if (FIX4) T::ph_fix_table(g, t, sh, r);      // (behind FILL: its rows are the back entries' indices)
         T::ph_rank(t, sh);
         lds_barrier();
         T::template ph_scan<FIX4>(g, t, sh, r);

@@ -341,8 +341,12 @@ template <int CAP> struct TickGeo {
             if (COUNT) { lds_add(&sh.cnt2[d], 1); continue; }
             // (4-lane layout, list of a left-turn route, member of the opposing left-turn route: from the back, not sorted)
             const bool back = (g.lane_num == 4) & (ty == 0) & (rt == (int)sh.tab.opp[d]) & !own;
-            const int e = back ? (sh.lbase[d + 1] - 1 - lds_claim(&sh.ofill[d], 1)) : (sh.lbase[d] + lds_claim(&sh.fill[d], 1));
+            const int qb = back ? lds_claim(&sh.ofill[d], 1) : 0;
+            const int e = back ? (sh.lbase[d + 1] - 1 - qb) : (sh.lbase[d] + lds_claim(&sh.fill[d], 1));
             sh.u_vd[e] = vo; sh.u_slot[e] = (uint8_t)x; sh.u_list[e] = (uint8_t)(back ? 0xFF : d);
+            // (x is a back entry of exactly one list, opp[its route]: its index there = its row of the far-conflict table;
+            //  rk[x], the rank ORDER2 consumed, is free to hold it -- bit 7 = "filed")
+            if (back) sh.rk[x] = (uint8_t)(0x80 | qb);
         }
     }
     // The common case -- the capacity upper bounds fit the entry pool -- needs neither the counting pass nor the two
@@ -364,19 +368,22 @@ template <int CAP> struct TickGeo {
         }
     }
     // one thread per controlled vehicle x of a left-turn route (4-lane layout): the value of x's entry in the list of the
-    // OPPOSING left-turn route d after each of d's egos, in slot order (ref :1301-1319).  Same phase as FILL (reads only
-    // positions, counts and masks; writes beyond the capacity bound of the entry pool).
+    // OPPOSING left-turn route d after each of d's egos, in slot order (ref :1301-1319).  Round 6: in the RANK phase (behind
+    // FILL's barrier), row = the index q of x's entry among the back entries of list d (rk[x], filed by FILL) -- an ego of d
+    // then reads entry q and table cell (q, its column) without the slot -> rank -> row chain.  Reads positions, masks and
+    // its own back entry; writes beyond the capacity bound of the entry pool (RANK reads there only masked-out tail values).
     static PVE_HD void ph_fix_table(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
     {
         if (g.lane_num != 4 || !sh.fix_ok) return;
         if (!(r.alive && r.ctl) || r.route % 3 != 0) return;
         const int d = sh.tab.opp[r.route];                    // (the relation is symmetric: opp[opp[d]] = d)
         if (d < 0) return;
+        const int q = sh.rk[t];
+        if (!(q & 0x80)) return;                              // not in list d: no back entry, no row
         const int li = sh.tab.dir_lane[d], m = sh.tab.dir_index[d];
-        double vc;
-        if (!member(g, sh, d, li, m, t, vc)) return;          // not in list d: its row is never read
+        double vc = sh.u_vd[sh.lbase[d + 1] - 1 - (q & 0x7F)];   // its build-time value in list d (= member())
         const int ls = sh.hd.lane_start[li], le = sh.hd.lane_start[li + 1];
-        double *row = sh.u_vd + sh.tstart + sh.tbase[d / 3] + mul24((int)sh.rk[t], sh.rc[d]);
+        double *row = sh.u_vd + sh.tstart + sh.tbase[d / 3] + mul24(q & 0x7F, sh.rc[d]);
         int i = 0;
         for (int w2 = 0; w2 < NW; w2++) {
             u64 eb = sh.m_ctl[w2] & sh.m_int[m][w2] & below_sel(le - w2 * 64) & ~below_sel(ls - w2 * 64);
@@ -518,12 +525,134 @@ template <int CAP> struct TickGeo {
         return vc;
     }
 
+    // 4-lane layout, ego of a left-turn route d (ref :1301-1319, :1340-1405): predecessor and 6 nearest from the sorted list
+    // (everything but the opposing left-turn route's entries: the 12-lane kernel's window walk, Tick::walk_window) AND the `no`
+    // unsorted opposing entries at the back of the list's capacity (entry eb - q; current value as this ego sees it = table cell
+    // (q, its column): u_vd[tcell + q * tcols]) in ONE selection on 32-bit keys -- the float32 image of |d| with the low 5 bits
+    // replaced by the candidate code (0..5 / 8..13: the window, 16 + q: opposing entry q).  Per opposing entry: three
+    // independent LDS reads, the predecessor test on the build-time value (ref :1353), one key, six v_min_u32 / v_max_u32 pairs
+    // (round 5: a float64 insertion chain of ~80 instructions per entry).  The slots and values of the 6 winners are read once
+    // they are known.  -> true = not decided here (pr / pvo / pvd, the predecessor, are final all the same; the caller takes
+    // Tick::walk_window_exact for the window and the float64 insertion for the opposing entries): the window's own
+    // ambiguities (Tick::walk_window), more than 16 opposing entries, an opposing entry whose key agrees with a neighbour's
+    // in the upper 27 bits, a sixth winner not separated from the best loser, float64 distances of the winners that decrease
+    // or -- with an opposing entry involved -- are equal (the reference's stable sort then decides by list position).
+    static PVE_HD bool walk_merge4(Sh &sh, int base, int n, int s, double ps, int t, int eb, int no, int tcell, int tcols, Regs &r,
+                                   int &pr, double &pvo, double &pvd)
+    {
+        const auto *sidx = sh.s_idx + base;
+        const int last = n - 1;
+        double lraw[NNB + 1], rraw[NNB];
+        int prs = -1;
+#pragma unroll
+        for (int i = 0; i < NNB + 1; i++) {
+            const int pos = s - 1 - i, pc = pos >= 0 ? pos : 0;
+            const int e = sidx_at(sidx, pc);
+            lraw[i] = sh.u_vd[e];
+            if (i == 0) prs = (int)sh.u_slot[e];
+        }
+#pragma unroll
+        for (int i = 0; i < NNB; i++) {
+            const int pos = s + 1 + i, pc = pos <= last ? pos : last;
+            rraw[i] = sh.u_vd[sidx_at(sidx, pc)];
+        }
+        pr = (s > 0) ? prs : -1; pvd = (s > 0) ? lraw[0] : 0.0;                      // ref :1353-1354
+        pvo = pvd;                                        // build-time distance of the predecessor (order), pvd = its current value
+        double dl[NNB + 1], dr[NNB];
+#pragma unroll
+        for (int i = 0; i < NNB + 1; i++) dl[i] = fabs(lraw[i] - ps);                 // ref :1388
+#pragma unroll
+        for (int i = 0; i < NNB; i++) dr[i] = fabs(rraw[i] - ps);
+        bool amb = no > 16;
+#pragma unroll
+        for (int i = 1; i < NNB + 1; i++) amb = amb | ((s - 1 - i >= 0) & (dl[i] == dl[i - 1]));
+        unsigned kl[NNB], kq[NNB];
+#pragma unroll
+        for (int i = 0; i < NNB; i++) {
+            const unsigned cl = (unsigned)i, cr = 8u + (unsigned)i;
+            const unsigned bl = Base::f32_bits((float)dl[i]), br = Base::f32_bits((float)dr[i]);
+            kl[i] = (s - 1 - i >= 0) ? ((bl & ~31u) | cl) : (0xFF800000u | (cl << 5) | cl);
+            kq[i] = (s + 1 + i <= last) ? ((br & ~31u) | cr) : (0xFF800000u | (cr << 5) | cr);
+        }
+        unsigned w[NNB], acc = ~0u;                   // acc = the smallest XOR of a (winner, loser) pair of the merge step
+#pragma unroll
+        for (int i = 0; i < NNB; i++) {
+            const unsigned a = kl[i], b = kq[NNB - 1 - i];
+            w[i] = Base::umin(a, b);
+            // (an EXACT float64 tie of a left and a right candidate is decided by the codes: left first, the reference's
+            //  list order -- the frequent case, equally spaced platoons; only unequal distances need separated keys)
+            acc = Base::umin(acc, (dl[i] == dr[NNB - 1 - i]) ? ~0u : (a ^ b));
+        }
+#define PVE_CE(A, B) { const unsigned lo_ = Base::umin(w[A], w[B]), hi_ = Base::umax(w[A], w[B]); w[A] = lo_; w[B] = hi_; }
+        PVE_CE(0, 5) PVE_CE(1, 3) PVE_CE(2, 4)
+        PVE_CE(1, 2) PVE_CE(3, 4)
+        PVE_CE(0, 3) PVE_CE(2, 5)
+        PVE_CE(0, 1) PVE_CE(2, 3) PVE_CE(4, 5)
+        PVE_CE(1, 2) PVE_CE(3, 4)
+#undef PVE_CE
+        amb = amb | (acc < 32u);
+        // the opposing entries: predecessor by build-time order, key into the sorted six (the seventh = the best loser so far)
+        unsigned lose = ~0u;
+        const int nq = no > 16 ? 0 : no;
+        for (int q = 0; q < nq; q++) {
+            const int x = sh.u_slot[eb - q];
+            const double vo = sh.u_vd[eb - q];
+            const double vc = sh.u_vd[tcell + mul24(q, tcols)];
+            const bool before = vo < ps || (vo == ps && x < t);
+            if (before && (pr < 0 || vo > pvo || (vo == pvo && x > pr))) { pvo = vo; pr = x; pvd = vc; }
+            unsigned key = (Base::f32_bits((float)fabs(vc - ps)) & ~31u) | (16u + (unsigned)q);
+#pragma unroll
+            for (int k = 0; k < NNB; k++) {
+                const unsigned lo_ = Base::umin(w[k], key);
+                key = Base::umax(w[k], key);
+                w[k] = lo_;
+            }
+            lose = Base::umin(lose, key);
+        }
+        // an opposing entry next to a key it is not separated from in the upper 27 bits: not decided on these keys (two window
+        // keys among the six: their codes order them as in Tick::walk_window, and the float64 check below sees both)
+#pragma unroll
+        for (int k = 1; k < NNB; k++) amb = amb | (((w[k] ^ w[k - 1]) < 32u) & (((w[k] | w[k - 1]) & 16u) != 0u) & ((int)w[k] >= 0));
+        // (the best loser is not read back: ANY loser the sixth is not separated from leaves the decision to the float64 keys)
+        amb = amb | (((w[NNB - 1] ^ lose) < 32u) & ((int)w[NNB - 1] >= 0));
+        // the winners' slots and values: index reads back to back, then the value reads
+        int es[NNB], ev[NNB];
+#pragma unroll
+        for (int k = 0; k < NNB; k++) {
+            const int code = (int)(w[k] & 31u);
+            const bool mg = (code & 16) != 0;
+            const int pos = (code & 8) ? (s - 7 + code) : (s - 1 - code);        // = s + 1 + (code - 8) on the right
+            const int pc = ((int)w[k] >= 0 && !mg) ? pos : 0;                    // (the keys of absent candidates have bit 31 set)
+            const int e = sidx_at(sidx, pc);
+            const int q = code & 15;
+            es[k] = mg ? eb - q : e;
+            ev[k] = mg ? tcell + mul24(q, tcols) : e;
+        }
+        int sl[NNB]; double vv[NNB], dk[NNB];
+#pragma unroll
+        for (int k = 0; k < NNB; k++) { sl[k] = (int)sh.u_slot[es[k]]; vv[k] = sh.u_vd[ev[k]]; }
+#pragma unroll
+        for (int k = 0; k < NNB; k++) dk[k] = fabs(vv[k] - ps);
+#pragma unroll
+        for (int k = 1; k < NNB; k++)
+            amb = amb | (((int)w[k] >= 0) & ((dk[k] < dk[k - 1]) | ((dk[k] == dk[k - 1]) & (((w[k] | w[k - 1]) & 16u) != 0u))));
+        if (amb) return true;
+#pragma unroll
+        for (int k = 0; k < NNB; k++) {
+            const bool ok = (int)w[k] >= 0;
+            r.kr[k] = ok ? sl[k] : -1;
+            r.kv[k] = ok ? vv[k] : 0.0;
+        }
+        return false;
+    }
+
     // ============================================================== SCAN: list heads, predecessor, 6 nearest
     // FIX4 = false compiles the 4-lane far-conflict path out (the launcher picks it for lane_num 8 / 12: the registers
     // that path needs would otherwise be spilled in the common phases of every layout)
     template <bool FIX4 = true>
     static PVE_HD void ph_scan(const PVE_AS4 GeoConst &g, int t, Sh &sh, Regs &r)
     {
+        constexpr bool KEYMERGE = FIX4 && CAP == 128;      // (walk_merge4: measured a gain at 128 slots, a loss at 64)
         r.reward = 0; r.hit = 0; r.hdr = -1;
 #pragma unroll
         for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
@@ -587,7 +716,7 @@ template <int CAP> struct TickGeo {
         }
         const int tcols = sh.rc[d];
         auto adj = [&](int x, double vo) -> double {
-            return tabf ? sh.u_vd[mad24((int)sh.rk[x], tcols, tcol)] : adjusted(g, sh, m, ls, le, t, vo);
+            return tabf ? sh.u_vd[mad24((int)sh.rk[x] & 0x7F, tcols, tcol)] : adjusted(g, sh, m, ls, le, t, vo);
         };
         double bvo = -INFINITY, bvc = 0; int bslot = -1;
         // the 6 nearest so far, sorted by |vd - vd_self|: only (distance, slot) travel through the insertion chain;
@@ -637,46 +766,74 @@ template <int CAP> struct TickGeo {
             // the predecessor by build-time order (ref :1353), the 6 nearest by current distance (ref :1383-1397).  Equal
             // distances between a merged entry and a winner -- the reference's stable sort then decides by list position, which
             // the split list does not carry -- take the exact insertion below.
-            int pr; double pvd;
-            Base::walk_window(sh, sh.lbase[d], sh.fill[d], sh.mypos[t], me, r, pr, pvd);
-            double pvo = pvd;                                 // build-time distance of the predecessor (order), pvd = its current value
-            bool amb = false;
-            if (fix) {
-                const int no = sh.ofill[d], eb = sh.lbase[d + 1] - 1;
-                // most opposing entries are farther away than the 6th winner: the insertion chain (~80 vector instructions
-                // per entry) only runs in waves where some lane's entry can enter the 6 -- at 4 waves per SIMD every vector
-                // instruction of this loop is 16 cycles of the SIMD
-                double dk[NNB];
-                bool have_dk = false;
-                double d5 = r.kr[NNB - 1] >= 0 ? fabs(r.kv[NNB - 1] - me) : INFINITY;
-                for (int q = 0; q < no; q++) {
-                    const int x = sh.u_slot[eb - q];
-                    const double vo = sh.u_vd[eb - q];
-                    const double vc = adj(x, vo);
-                    const bool before = vo < me || (vo == me && x < t);
-                    if (before && (pr < 0 || vo > pvo || (vo == pvo && x > pr))) { pvo = vo; pr = x; pvd = vc; }
-                    double cd = fabs(vc - me), cv = vc; int cs = x;
+            int pr; double pvd, pvo;
+            bool amb = false, seeded = false;
+            if (KEYMERGE && g.lane_num == 4) {
+                // (round 6, 128 slots: the window walk and the merge of the opposing entries as ONE selection on 32-bit keys --
+                //  every ego of the layout through the same code, the egos of the other routes with no opposing entries: a wave
+                //  that mixes routes walks its windows once)
+                const bool mg = fix && tabf;
+                amb = walk_merge4(sh, sh.lbase[d], sh.fill[d], sh.mypos[t], me, t, sh.lbase[d + 1] - 1, mg ? sh.ofill[d] : 0, tcol, tcols, r, pr,
+                                  pvo, pvd);
+                if (amb) {
+                    // not decided on the keys (~0.8 % of the egos, mostly the ulp-level near ties of equally spaced platoons): the
+                    // window exactly, then the opposing entries through the float64 insertion with its full tie-breaks; the
+                    // predecessor is already known.  (the 64-slot form of that insertion, below, was measured here too: its
+                    // registers cost the fast path more than this path's re-derivation of the winners: 33.9 vs 32.5 us)
+                    Base::walk_window_exact(sh, sh.lbase[d], sh.fill[d], sh.mypos[t], me, r);
+                    if (mg) {
+#pragma unroll
+                        for (int k = 0; k < NNB; k++) { ks[k] = r.kr[k]; kd[k] = r.kr[k] >= 0 ? fabs(r.kv[k] - me) : INFINITY; }
+                        bslot = pr; bvo = pr >= 0 ? pvo : -INFINITY; bvc = pvd;
+                        const int no = sh.ofill[d], eb = sh.lbase[d + 1] - 1;
+                        for (int q = 0; q < no; q++) consider(sh.u_slot[eb - q], sh.u_vd[eb - q]);
+                        seeded = true;
+                    } else amb = false;                   // (no opposing entries: the exact window is the answer)
+                }
+                if (fix && !tabf) { amb = true; seeded = false; }   // (no room for the table behind the pool, rare: every member below)
+            } else {
+                // (capacity 64 -- lighter traffic: most opposing entries are farther away than the 6th winner, and the wave-level
+                //  skip of the insertion below is cheaper than a key per entry: 26.5 vs 29.0 us per tick of 4096 x 64 -- and the
+                //  layouts without the far-conflict path)
+                Base::walk_window(sh, sh.lbase[d], sh.fill[d], sh.mypos[t], me, r, pr, pvd);
+                pvo = pvd;                                        // build-time distance of the predecessor (order), pvd = its current value
+                if (fix) {
+                    const int no = sh.ofill[d], eb = sh.lbase[d + 1] - 1;
+                    // most opposing entries are farther away than the 6th winner: the insertion chain (~80 vector instructions
+                    // per entry) only runs in waves where some lane's entry can enter the 6 -- at 4 waves per SIMD every vector
+                    // instruction of this loop is 16 cycles of the SIMD
+                    double dk[NNB];
+                    bool have_dk = false;
+                    double d5 = r.kr[NNB - 1] >= 0 ? fabs(r.kv[NNB - 1] - me) : INFINITY;
+                    for (int q = 0; q < no; q++) {
+                        const int x = sh.u_slot[eb - q];
+                        const double vo = sh.u_vd[eb - q];
+                        const double vc = adj(x, vo);
+                        const bool before = vo < me || (vo == me && x < t);
+                        if (before && (pr < 0 || vo > pvo || (vo == pvo && x > pr))) { pvo = vo; pr = x; pvd = vc; }
+                        double cd = fabs(vc - me), cv = vc; int cs = x;
 #if PVE_DEVICE_CODE
-                    if (__builtin_amdgcn_ballot_w64(cd <= d5) == 0) continue;
+                        if (__builtin_amdgcn_ballot_w64(cd <= d5) == 0) continue;
 #else
-                    if (!(cd <= d5)) continue;
+                        if (!(cd <= d5)) continue;
 #endif
-                    if (!have_dk) {
+                        if (!have_dk) {
 #pragma unroll
-                        for (int k = 0; k < NNB; k++) dk[k] = r.kr[k] >= 0 ? fabs(r.kv[k] - me) : INFINITY;
-                        have_dk = true;
-                    }
-                    bool ins = false;
+                            for (int k = 0; k < NNB; k++) dk[k] = r.kr[k] >= 0 ? fabs(r.kv[k] - me) : INFINITY;
+                            have_dk = true;
+                        }
+                        bool ins = false;
 #pragma unroll
-                    for (int k = 0; k < NNB; k++) {
-                        amb = amb | (cd == dk[k]);
-                        const bool sw = ins | (cd < dk[k]);
-                        ins = sw;
-                        const double td = sw ? dk[k] : cd, tv = sw ? r.kv[k] : cv; const int ts = sw ? r.kr[k] : cs;
-                        dk[k] = sw ? cd : dk[k]; r.kv[k] = sw ? cv : r.kv[k]; r.kr[k] = sw ? cs : r.kr[k];
-                        cd = td; cv = tv; cs = ts;
+                        for (int k = 0; k < NNB; k++) {
+                            amb = amb | (cd == dk[k]);
+                            const bool sw = ins | (cd < dk[k]);
+                            ins = sw;
+                            const double td = sw ? dk[k] : cd, tv = sw ? r.kv[k] : cv; const int ts = sw ? r.kr[k] : cs;
+                            dk[k] = sw ? cd : dk[k]; r.kv[k] = sw ? cv : r.kv[k]; r.kr[k] = sw ? cs : r.kr[k];
+                            cd = td; cv = tv; cs = ts;
+                        }
+                        d5 = dk[NNB - 1];
                     }
-                    d5 = dk[NNB - 1];
                 }
             }
             if (!amb) {
@@ -687,17 +844,14 @@ template <int CAP> struct TickGeo {
                 r.count += 1;                                                               // ref :292
                 return;
             }
-            // (exact distance ties with a merged entry: every member through the full-key insertion)
-#pragma unroll
-            for (int k = 0; k < NNB; k++) { r.kr[k] = -1; r.kv[k] = 0; }
-            {
+            if (!seeded) {                                // every member through the full-key insertion
                 const int no = sh.ofill[d], eb = sh.lbase[d + 1] - 1;
                 for (int q = 0; q < no; q++) consider(sh.u_slot[eb - q], sh.u_vd[eb - q]);
-            }
-            const int e1 = sh.lbase[d] + sh.fill[d];
-            for (int e = sh.lbase[d]; e < e1; e++) {
-                const int x = sh.u_slot[e];
-                if (x != t) consider(x, sh.u_vd[e]);
+                const int e1 = sh.lbase[d] + sh.fill[d];
+                for (int e = sh.lbase[d]; e < e1; e++) {
+                    const int x = sh.u_slot[e];
+                    if (x != t) consider(x, sh.u_vd[e]);
+                }
             }
         } else {
             for (int w = 0; w < NW; w++)

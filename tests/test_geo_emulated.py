@@ -47,6 +47,19 @@ def test_geo_fuzz_random_tapes(lane_num, rate, cap, quant, seed):
     assert coll > 0 and lock > 0
 
 
+@pytest.mark.parametrize("rate,quant,scale,seed", [(2400.0, None, 2.0, 61), (2700.0, 0.5, 3.0, 62), (1900.0, 1.0, 0.5, 63), (2200.0, 3.0, 3.0, 64),
+                                                   (1500.0, None, 3.0, 65)])
+def test_four_lane_far_conflict_key_merge_at_128_slots(rate, quant, scale, seed):
+    """Round 6 (VERDICT r5 #2a): TickGeo::walk_merge4 -- the 4-lane layout's window walk + merge of the opposing left-turn
+    entries (ref :1301-1319, :1340-1405) as one selection on 32-bit keys, the kernels' form at 128 slots -- against the
+    sequential oracle under dense traffic: continuous tapes (the ulp-level near ties of equally spaced platoons take the exact
+    window + float64 insertion), quantised tapes (exact distance ties, several opposing entries clamped to the ego's own
+    position +- 1), every tick, every field."""
+    coll, lock = scenarios.check_geo_fuzz_vs_oracle(BACKEND, 4, n_envs=6, capacity=128, ticks=500, rate=rate, seed=seed, action_scale=scale,
+                                                    quantize=quant)
+    assert coll > 0 and lock > 0
+
+
 def test_left_neighbours_one_ulp_apart_share_a_distance():
     """Regression (found by tools/soak.py): two LEFT neighbours whose virtual distances differ by one ulp have the same
     float64 |vd - vd_self|; the reference's stable sort then keeps LIST order (ascending vd), i.e. the farther one first.

@@ -248,6 +248,19 @@ def test_gpu_geo_fuzz_random_tapes(lane_num, rate, cap, quant, seed):
     assert coll > 0 and lock > 0
 
 
+@pytest.mark.parametrize("rate,quant,scale,seed", [(2400.0, None, 2.0, 61), (2700.0, 0.5, 3.0, 62), (1900.0, 1.0, 0.5, 63), (2200.0, 3.0, 3.0, 64),
+                                                   (1500.0, None, 3.0, 65)])
+def test_gpu_four_lane_far_conflict_key_merge_at_128_slots(rate, quant, scale, seed):
+    """Round 6 (VERDICT r5 #2a): TickGeo::walk_merge4 (the 4-lane window walk + merge of the opposing left-turn entries on
+    32-bit keys; ref :1301-1319, :1340-1405) in k_tick_geo<128, .., FIX4> vs the sequential oracle under dense traffic,
+    continuous and quantised tapes, every tick, every field; + the resident kernel == single ticks on the same traffic."""
+    coll, lock = scenarios.check_geo_fuzz_vs_oracle(BACKEND, 4, n_envs=24, capacity=128, ticks=500, rate=rate, seed=seed, action_scale=scale,
+                                                    quantize=quant)
+    assert coll > 0 and lock > 0
+    scenarios.check_step_many_geo(BACKEND, 4, n_envs=12, capacity=128, chunks=(1, 7, 60, 25), trajectory_chunk=9, rate=rate, seed=seed,
+                                  quantize=quant)
+
+
 def test_gpu_left_neighbours_one_ulp_apart_share_a_distance():
     """Regression (found by tools/soak.py): two left neighbours whose virtual distances differ by one ulp have the same
     float64 distance to the ego; the reference keeps list order (ascending vd) for them.  8 lanes, seed 3110, tick 152."""
