@@ -1221,8 +1221,30 @@ template <int CAP, class ShT = Shared<CAP>> struct Tick {
         double dk[NNB];
 #pragma unroll
         for (int k = 0; k < NNB; k++) dk[k] = fabs(vv[k] - ps);
+        // Round 6: a decrease can only sit between a left and a right winner whose float32 images agree (rounding is monotone,
+        // one side alone is in walking order) -- the ulp-level near ties of equally spaced platoons, 0.45 % of the egos of the
+        // headline workload, i.e. every fifth wave-tick used to run walk_window_exact for one of its ~51 egos.  The winners
+        // are the right SET (the merge step's pairs are separated); one pass of adjacent exchanges on the float64 distances
+        // puts a pair in order, in the waves that hold one; a longer run (rare: 14 of 4.2 M egos) still takes the exact path.
+        bool dec = false;
 #pragma unroll
-        for (int k = 1; k < NNB; k++) amb = amb | (((int)w[k] >= 0) & (dk[k] < dk[k - 1]));
+        for (int k = 1; k < NNB; k++) dec = dec | (((int)w[k] >= 0) & (dk[k] < dk[k - 1]));
+#if PVE_DEVICE_CODE
+        if (__builtin_amdgcn_ballot_w64(dec) != 0)
+#else
+        if (dec)
+#endif
+        {
+#pragma unroll
+            for (int k = 1; k < NNB; k++) {
+                const bool sw = ((int)w[k] >= 0) & (dk[k] < dk[k - 1]);
+                const double td = sw ? dk[k - 1] : dk[k], tv = sw ? vv[k - 1] : vv[k]; const int ts = sw ? sl[k - 1] : sl[k];
+                dk[k - 1] = sw ? dk[k] : dk[k - 1]; vv[k - 1] = sw ? vv[k] : vv[k - 1]; sl[k - 1] = sw ? sl[k] : sl[k - 1];
+                dk[k] = td; vv[k] = tv; sl[k] = ts;
+            }
+#pragma unroll
+            for (int k = 1; k < NNB; k++) amb = amb | (((int)w[k] >= 0) & (dk[k] < dk[k - 1]));
+        }
         if (!amb) {
 #pragma unroll
             for (int k = 0; k < NNB; k++) {
