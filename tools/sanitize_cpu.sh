@@ -11,6 +11,7 @@ make -s -C oracle CFLAGS="-O1 -g -fPIC -std=c11 -ffp-contract=off -fno-fast-math
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
     python -m pytest tests/test_kernel_emulated.py tests/test_oracle_golden.py tests/test_fuzz_emulated.py \
     tests/test_capi.py tests/test_actor.py tests/test_geo_emulated.py tests/test_oracle_geo.py tests/test_compat_class.py \
+    tests/test_home_block_emulated.py tests/test_ctor_kwargs.py \
     -x -q -p no:cacheprovider
 # back to the normal builds
 make -s -C tests/emu clean && make -s -C tests/emu
